@@ -1,0 +1,256 @@
+"""ctypes binding of libadvntr_hip.so (include/advntr_hip.h) -- the only way into the HIP engine.
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible, every scoring call
+raises.  `load()` only dlopens the library (no GPU needed), so symbol/ABI checks run anywhere.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadvntr_hip.so")
+
+OK, ERR_ARG, ERR_SYMBOL, ERR_DEVICE, ERR_TOO_LARGE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY = 1, 2, 4
+SUMMARY_INTS = 8
+SUM_RU, SUM_MATCHES, SUM_REPEAT_BP, SUM_LEFT_BP, SUM_RIGHT_BP, SUM_LEFT_MATCH, SUM_RIGHT_MATCH, SUM_PATH_LEN = range(8)
+
+SC_EMIT, SC_MATCH, SC_SUFFIX, SC_PREFIX = 0x1, 0x2, 0x4, 0x8
+SC_UNIT_START, SC_UNIT_END, SC_SKIP, SC_FIX = 0x10, 0x20, 0x40, 0x80
+SC_BASE_SHIFT, SC_BASE_VALID = 8, 0x400
+
+# every symbol include/advntr_hip.h declares: (restype, argtypes)
+_vp, _i32, _u32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int64
+SYMBOLS = {
+    "advntr_device_count": (ctypes.c_int, []),
+    "advntr_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "advntr_last_error": (ctypes.c_char_p, []),
+    "advntr_version": (ctypes.c_char_p, []),
+    "advntr_hmm_create": (_vp, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "advntr_hmm_destroy": (None, [_vp]),
+    "advntr_hmm_has_column_program": (ctypes.c_int, [_vp]),
+    "advntr_hmm_info": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "advntr_viterbi_batch": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _u32]),
+    "advntr_forward_batch": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _u32]),
+    "advntr_batch_create": (_vp, [_vp, _i32, _vp, _vp, _vp, _i32, _u32]),
+    "advntr_batch_destroy": (None, [_vp]),
+    "advntr_batch_run": (ctypes.c_int, [_vp]),
+    "advntr_batch_sync": (ctypes.c_int, [_vp]),
+    "advntr_batch_run_timed": (ctypes.c_int, [_vp, _i32, _vp]),
+    "advntr_batch_fetch": (ctypes.c_int, [_vp, _vp, _vp]),
+    "advntr_batch_fetch_paths": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "advntr_batch_result_ptrs": (ctypes.c_int, [_vp, _vp, _vp]),
+    "advntr_batch_device_bytes": (_i64, [_vp]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "advntr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """dlopen the engine and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return load().advntr_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != OK:
+        msg = last_error()
+        if rc == ERR_SYMBOL:
+            raise ValueError("Symbol is not defined in a distribution (%s)" % msg)  # reference: hmm.pyx:72,79
+        raise EngineError(rc, msg)
+
+
+def require_gpu():
+    n = load().advntr_device_count()
+    if n <= 0:
+        raise EngineError(ERR_DEVICE, "no HIP device visible; the scoring path runs on MI355X only (no CPU fallback)")
+    return n
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _CODE[ord(_c)] = _i
+
+
+def encode_reads(seqs):
+    """list of str/bytes/uint8 arrays -> (bases uint8, read_off int64).  Unknown symbols become code 255,
+    which the engine rejects with ADVNTR_ERR_SYMBOL (the reference's ValueError)."""
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    parts = []
+    for i, s in enumerate(seqs):
+        if isinstance(s, str):
+            a = _CODE[np.frombuffer(s.encode("latin-1", "replace"), dtype=np.uint8)]
+        elif isinstance(s, (bytes, bytearray)):
+            a = _CODE[np.frombuffer(bytes(s), dtype=np.uint8)]
+        elif isinstance(s, np.ndarray) and s.dtype == np.uint8:
+            a = s
+        else:
+            a = _CODE[np.frombuffer("".join(s).encode("latin-1", "replace"), dtype=np.uint8)]
+        parts.append(a)
+        off[i + 1] = off[i] + len(a)
+    bases = np.concatenate(parts).astype(np.uint8) if parts and off[-1] else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), off
+
+
+class DeviceModel(object):
+    """Owns one advntr_hmm handle (a baked model resident in HBM)."""
+
+    def __init__(self, m, silent_start, start_index, end_index, in_ptr, in_src, in_logp, emis_logp, state_class=None):
+        L = load()
+        require_gpu()
+        self.m, self.silent_start = int(m), int(silent_start)
+        in_ptr = np.ascontiguousarray(in_ptr, dtype=np.int32)
+        in_src = np.ascontiguousarray(in_src, dtype=np.int32)
+        in_logp = np.ascontiguousarray(in_logp, dtype=np.float64)
+        emis = np.ascontiguousarray(emis_logp, dtype=np.float64)
+        cls = None if state_class is None else np.ascontiguousarray(state_class, dtype=np.uint16)
+        self._h = L.advntr_hmm_create(m, silent_start, start_index, end_index, len(in_src), ptr(in_ptr),
+                                      ptr(in_src), ptr(in_logp), ptr(emis), ptr(cls))
+        if not self._h:
+            raise EngineError(ERR_ARG, last_error())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def has_column_program(self):
+        return bool(load().advntr_hmm_has_column_program(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().advntr_hmm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _handles(models):
+    arr = (ctypes.c_void_p * len(models))(*[m.handle for m in models])
+    return arr
+
+
+def viterbi_batch(models, bases, read_off, read_model, flags=0, want_paths=False, want_summary=True):
+    """One-shot scoring from host buffers.  Returns (logp, summary|None, paths|None)."""
+    L = load()
+    n = len(read_off) - 1
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    read_model = np.ascontiguousarray(read_model, np.int32)
+    logp = np.zeros(n, np.float64)
+    summ = np.zeros((n, SUMMARY_INTS), np.int32) if want_summary else None
+    out_path = out_off = out_len = None
+    if want_paths:
+        flags |= FLAG_PATH
+        caps = (read_off[1:] - read_off[:-1]) + np.array([models[i].m for i in read_model], np.int64) + 2
+        out_off = np.zeros(n + 1, np.int64)
+        np.cumsum(caps, out=out_off[1:])
+        out_path = np.zeros(max(int(out_off[-1]), 1), np.int32)
+        out_len = np.zeros(n, np.int32)
+    check(L.advntr_viterbi_batch(_handles(models), len(models), ptr(bases), ptr(read_off), ptr(read_model), n,
+                                 ptr(logp), ptr(summ), ptr(out_path), ptr(out_off), ptr(out_len), flags))
+    paths = None
+    if want_paths:
+        paths = []
+        for r in range(n):
+            ln = int(out_len[r])
+            if ln == -2:
+                raise EngineError(ERR_ARG, "path of read %d exceeds the reference capacity n+m" % r)
+            paths.append(out_path[out_off[r]:out_off[r] + ln].tolist() if ln > 0 else None)
+    return logp, summ, paths
+
+
+def forward_batch(models, bases, read_off, read_model, flags=0):
+    L = load()
+    n = len(read_off) - 1
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    read_model = np.ascontiguousarray(read_model, np.int32)
+    logp = np.zeros(n, np.float64)
+    check(L.advntr_forward_batch(_handles(models), len(models), ptr(bases), ptr(read_off), ptr(read_model), n,
+                                 ptr(logp), flags))
+    return logp
+
+
+class DeviceBatch(object):
+    """Device-resident batch (advntr_batch_*): upload once, run many times, fetch."""
+
+    def __init__(self, models, bases, read_off, read_model, flags=0):
+        L = load()
+        self.models = list(models)
+        self.n_reads = len(read_off) - 1
+        bases = np.ascontiguousarray(bases, np.uint8)
+        read_off = np.ascontiguousarray(read_off, np.int64)
+        read_model = np.ascontiguousarray(read_model, np.int32)
+        self.flags = flags
+        self._h = L.advntr_batch_create(_handles(self.models), len(self.models), ptr(bases), ptr(read_off),
+                                        ptr(read_model), self.n_reads, flags)
+        if not self._h:
+            msg = last_error()
+            if "base code" in msg:
+                raise ValueError("Symbol is not defined in a distribution (%s)" % msg)
+            raise EngineError(ERR_ARG, msg)
+
+    def run(self):
+        check(load().advntr_batch_run(self._h))
+
+    def sync(self):
+        check(load().advntr_batch_sync(self._h))
+
+    def run_timed(self, iters):
+        ms = ctypes.c_float(0)
+        check(load().advntr_batch_run_timed(self._h, iters, ctypes.byref(ms)))
+        return ms.value
+
+    def fetch(self):
+        logp = np.zeros(self.n_reads, np.float64)
+        summ = None if (self.flags & FLAG_NO_SUMMARY) else np.zeros((self.n_reads, SUMMARY_INTS), np.int32)
+        check(load().advntr_batch_fetch(self._h, ptr(logp), ptr(summ)))
+        return logp, summ
+
+    def device_bytes(self):
+        return int(load().advntr_batch_device_bytes(self._h))
+
+    def result_ptrs(self):
+        a, b = ctypes.c_void_p(0), ctypes.c_void_p(0)
+        check(load().advntr_batch_result_ptrs(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().advntr_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,539 @@
+// engine.hip -- host side of libadvntr_hip.so: the C ABI of include/advntr_hip.h, model upload,
+// device-resident read batches and kernel launches.  gfx950 only; no CPU fallback anywhere: every
+// entry point either runs the HIP kernels or returns an error code.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/advntr_hip.h"
+#include "device_model.h"
+#include "column_program.h"
+#include "viterbi_generic.h"
+#include "viterbi_columns.h"
+#include "forward_generic.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ADVNTR_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+extern "C" const char *advntr_last_error(void) { return g_err.c_str(); }
+extern "C" const char *advntr_version(void) { return "advntr_hip 0.1 (gfx950)"; }
+
+extern "C" int advntr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int advntr_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return ADVNTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model
+// ------------------------------------------------------------------------------------------------
+struct advntr_hmm {
+    int32_t m = 0, P = 0, start = 0, end = 0, finite = 0, n_edges = 0;
+    int32_t bp_width = 1, max_indeg = 0;
+    std::vector<int32_t> in_ptr, in_src;
+    std::vector<double> in_logp, emis;
+    std::vector<uint16_t> sclass;
+    bool has_class = false;
+    ColProgramHost colprog;       // empty when the model is not a recognised read matcher
+    void *d_blob = nullptr;
+    size_t blob_bytes = 0;
+    DevModel dev{};
+};
+
+namespace {
+
+struct BlobBuilder {
+    std::vector<uint8_t> bytes;
+    template <class T> size_t add(const std::vector<T> &v)
+    {
+        size_t off = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T) + 16, 0);
+        if (!v.empty()) memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+
+}  // namespace
+
+extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index,
+                                         int32_t end_index, int32_t n_edges, const int32_t *in_ptr,
+                                         const int32_t *in_src, const double *in_logp,
+                                         const double *emis_logp, const uint16_t *state_class)
+{
+    if (m <= 0 || silent_start < 0 || silent_start > m || start_index < 0 || start_index >= m ||
+        end_index < 0 || end_index >= m || n_edges < 0 || !in_ptr || (n_edges && (!in_src || !in_logp)) ||
+        (silent_start && !emis_logp)) {
+        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: bad argument");
+        return nullptr;
+    }
+    if (in_ptr[0] != 0 || in_ptr[m] != n_edges) {
+        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr does not span n_edges");
+        return nullptr;
+    }
+    for (int l = 0; l < m; ++l)
+        if (in_ptr[l + 1] < in_ptr[l]) {
+            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr not monotone");
+            return nullptr;
+        }
+    for (int k = 0; k < n_edges; ++k)
+        if (in_src[k] < 0 || in_src[k] >= m) {
+            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: edge source out of range");
+            return nullptr;
+        }
+    const int P = silent_start, S = m - P;
+    // 2 fp64 trellis rows must fit the 160 KiB LDS of one CU
+    if ((size_t)m * 16 > 160 * 1024) {
+        fail(ADVNTR_ERR_TOO_LARGE, "advntr_hmm_create: %d states need %zu B of LDS rows (> 160 KiB)", m,
+             (size_t)m * 16);
+        return nullptr;
+    }
+    advntr_hmm *H = new advntr_hmm();
+    H->m = m; H->P = P; H->start = start_index; H->end = end_index; H->n_edges = n_edges;
+    H->in_ptr.assign(in_ptr, in_ptr + m + 1);
+    H->in_src.assign(in_src, in_src + n_edges);
+    H->in_logp.assign(in_logp, in_logp + n_edges);
+    H->emis.assign(emis_logp, emis_logp + (size_t)P * 4);
+    H->finite = (in_ptr[end_index + 1] - in_ptr[end_index]) != 0;   // hmm.pyx:977-980
+    H->sclass.assign(m, 0);
+    if (state_class) {
+        H->sclass.assign(state_class, state_class + m);
+        H->has_class = true;
+    }
+
+    // emitting CSR = the reference's, verbatim
+    std::vector<int32_t> e_ptr(in_ptr, in_ptr + P + 1);
+    const int eE = P ? in_ptr[P] : 0;
+    std::vector<int32_t> e_src(in_src, in_src + eE);
+    std::vector<double> e_logp(in_logp, in_logp + eE);
+    int max_indeg = 0;
+    for (int l = 0; l < P; ++l) max_indeg = std::max(max_indeg, in_ptr[l + 1] - in_ptr[l]);
+
+    // silent states: reference evaluation order r = [emitting-sourced in list order (hmm.pyx:2044-2063)]
+    // ++ [silent-sourced with ki < l in list order (hmm.pyx:2065-2083)]; edges from ki >= l never fire.
+    std::vector<int32_t> r_ptr(S + 1, 0), r_src;
+    std::vector<double> r_logp;
+    std::vector<int32_t> s_ptr(S + 1, 0), s_mid(S, 0), s_src, s_ord;
+    std::vector<double> s_logp;
+    for (int l = P; l < m; ++l) {
+        const int ls = l - P;
+        const int base = P + (ls / ADV_WAVE) * ADV_WAVE;
+        const int r0 = (int)r_src.size();
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (in_src[k] < P) { r_src.push_back(in_src[k]); r_logp.push_back(in_logp[k]); }
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (in_src[k] >= P && in_src[k] < l) { r_src.push_back(in_src[k]); r_logp.push_back(in_logp[k]); }
+        const int r1 = (int)r_src.size();
+        r_ptr[ls + 1] = r1;
+        max_indeg = std::max(max_indeg, r1 - r0);
+        // A list: sources outside this state's chunk, reference order
+        s_ptr[ls] = (int)s_src.size();
+        for (int q = r0; q < r1; ++q)
+            if (r_src[q] < base) { s_src.push_back(r_src[q]); s_logp.push_back(r_logp[q]); s_ord.push_back(q - r0); }
+        s_mid[ls] = (int)s_src.size();
+        // B list: in-chunk sources, ascending source index
+        std::vector<int> idx;
+        for (int q = r0; q < r1; ++q)
+            if (r_src[q] >= base) idx.push_back(q);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return r_src[a] < r_src[b]; });
+        for (int q : idx) { s_src.push_back(r_src[q]); s_logp.push_back(r_logp[q]); s_ord.push_back(q - r0); }
+        s_ptr[ls + 1] = (int)s_src.size();
+    }
+    H->max_indeg = max_indeg;
+    H->bp_width = max_indeg > 255 ? 2 : 1;
+
+    // column program for flank-repeats-flank read matchers (optional fast path)
+    build_column_program(*H, H->colprog);
+
+    BlobBuilder B;
+    const size_t o_eptr = B.add(e_ptr), o_esrc = B.add(e_src), o_elogp = B.add(e_logp), o_emis = B.add(H->emis);
+    const size_t o_sptr = B.add(s_ptr), o_smid = B.add(s_mid), o_ssrc = B.add(s_src), o_sord = B.add(s_ord);
+    const size_t o_slogp = B.add(s_logp), o_rptr = B.add(r_ptr), o_rsrc = B.add(r_src), o_rlogp = B.add(r_logp);
+    const size_t o_cls = B.add(H->sclass);
+    size_t o_col = 0;
+    std::vector<uint8_t> colblob;
+    if (H->colprog.valid) {
+        colblob = H->colprog.serialize();
+        o_col = B.add(colblob);
+    }
+    H->blob_bytes = B.bytes.size();
+    if (hipMalloc(&H->d_blob, H->blob_bytes) != hipSuccess ||
+        hipMemcpy(H->d_blob, B.bytes.data(), H->blob_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        fail(ADVNTR_ERR_DEVICE, "advntr_hmm_create: device upload failed (%zu B)", H->blob_bytes);
+        if (H->d_blob) (void)hipFree(H->d_blob);
+        delete H;
+        return nullptr;
+    }
+    const uint8_t *d = (const uint8_t *)H->d_blob;
+    DevModel &D = H->dev;
+    D.m = m; D.P = P; D.start = start_index; D.end = end_index; D.finite = H->finite;
+    D.bp_width = H->bp_width; D.n_chunks = (S + ADV_WAVE - 1) / ADV_WAVE; D.max_indeg = max_indeg;
+    D.e_ptr = (const int32_t *)(d + o_eptr); D.e_src = (const int32_t *)(d + o_esrc);
+    D.e_logp = (const double *)(d + o_elogp); D.emis = (const double *)(d + o_emis);
+    D.s_ptr = (const int32_t *)(d + o_sptr); D.s_mid = (const int32_t *)(d + o_smid);
+    D.s_src = (const int32_t *)(d + o_ssrc); D.s_ord = (const int32_t *)(d + o_sord);
+    D.s_logp = (const double *)(d + o_slogp); D.r_ptr = (const int32_t *)(d + o_rptr);
+    D.r_src = (const int32_t *)(d + o_rsrc); D.r_logp = (const double *)(d + o_rlogp);
+    D.sclass = (const uint16_t *)(d + o_cls);
+    D.cols = H->colprog.valid ? (const ColProgram *)(d + o_col) : nullptr;
+    return H;
+}
+
+extern "C" void advntr_hmm_destroy(advntr_hmm *H)
+{
+    if (!H) return;
+    if (H->d_blob) (void)hipFree(H->d_blob);
+    delete H;
+}
+
+extern "C" int advntr_hmm_has_column_program(const advntr_hmm *H) { return H && H->colprog.valid ? 1 : 0; }
+
+extern "C" int advntr_hmm_info(const advntr_hmm *H, int32_t *m, int32_t *silent_start, int32_t *n_edges,
+                               int32_t *n_columns)
+{
+    if (!H) return fail(ADVNTR_ERR_ARG, "advntr_hmm_info: null model");
+    if (m) *m = H->m;
+    if (silent_start) *silent_start = H->P;
+    if (n_edges) *n_edges = H->n_edges;
+    if (n_columns) *n_columns = H->colprog.valid ? H->colprog.n_cols : 0;
+    return ADVNTR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch
+// ------------------------------------------------------------------------------------------------
+struct advntr_batch {
+    std::vector<advntr_hmm *> models;
+    int32_t n_reads = 0;
+    uint32_t flags = 0;
+    bool use_columns = false;
+    int n_max = 0, m_max = 0;
+    int grid = 0;
+    size_t lds_bytes = 0;
+    int64_t device_bytes = 0;
+    std::vector<int64_t> path_off;      // internal capacities (n + m + 2 per read)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevModel *d_models = nullptr;
+    uint8_t *d_bases = nullptr;
+    int64_t *d_read_off = nullptr;
+    int32_t *d_read_model = nullptr, *d_order = nullptr;
+    double *d_logp = nullptr;
+    int32_t *d_summary = nullptr, *d_path = nullptr, *d_path_len = nullptr;
+    int64_t *d_path_off = nullptr;
+    uint8_t *d_bp = nullptr;
+    int32_t *d_pathbuf = nullptr;
+    int32_t *d_counter = nullptr;
+    int64_t bp_stride = 0;
+    int32_t path_cap = 0;
+    ColumnLaunch col{};                 // anti-diagonal kernel launch state
+    std::vector<void *> allocs;
+
+    template <class T> int dmalloc(T **p, size_t count)
+    {
+        void *q = nullptr;
+        size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        HIP_TRY(hipMalloc(&q, bytes));
+        allocs.push_back(q);
+        device_bytes += (int64_t)bytes;
+        *p = (T *)q;
+        return ADVNTR_OK;
+    }
+};
+
+static int device_cus()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                       const int64_t *read_off, const int32_t *read_model, int32_t n_reads, uint32_t flags)
+{
+    if (!models || n_models <= 0 || !read_off || !read_model || n_reads < 0 || (n_reads && !bases && read_off[n_reads] > 0))
+        return fail(ADVNTR_ERR_ARG, "batch: bad argument");
+    for (int i = 0; i < n_models; ++i)
+        if (!models[i]) return fail(ADVNTR_ERR_ARG, "batch: null model %d", i);
+    B->models.assign(models, models + n_models);
+    B->n_reads = n_reads;
+    B->flags = flags;
+    if (read_off[0] != 0) return fail(ADVNTR_ERR_ARG, "batch: read_off[0] must be 0");
+    const int64_t total = read_off[n_reads];
+    for (int r = 0; r < n_reads; ++r) {
+        if (read_off[r + 1] < read_off[r]) return fail(ADVNTR_ERR_ARG, "batch: read_off not monotone at %d", r);
+        if (read_model[r] < 0 || read_model[r] >= n_models)
+            return fail(ADVNTR_ERR_ARG, "batch: read_model[%d]=%d out of range", r, read_model[r]);
+        B->n_max = std::max<int>(B->n_max, (int)(read_off[r + 1] - read_off[r]));
+    }
+    for (int64_t i = 0; i < total; ++i)
+        if (bases[i] > 3)   // the reference raises ValueError("Symbol ... not defined") (hmm.pyx:72,79)
+            return fail(ADVNTR_ERR_SYMBOL, "batch: base code %d at offset %lld is not one of A,C,G,T", (int)bases[i],
+                        (long long)i);
+    bool all_cols = true;
+    int bpw_max = 1;
+    for (auto *H : B->models) {
+        B->m_max = std::max(B->m_max, H->m);
+        bpw_max = std::max(bpw_max, H->bp_width);
+        all_cols = all_cols && H->colprog.valid;
+    }
+    B->use_columns = all_cols && !(flags & ADVNTR_FLAG_FORCE_GENERIC);
+
+    HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&B->ev0));
+    HIP_TRY(hipEventCreate(&B->ev1));
+
+    std::vector<DevModel> dm;
+    for (auto *H : B->models) dm.push_back(H->dev);
+    int rc;
+    if ((rc = B->dmalloc(&B->d_models, dm.size()))) return rc;
+    HIP_TRY(hipMemcpy(B->d_models, dm.data(), dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
+    if ((rc = B->dmalloc(&B->d_bases, (size_t)total + 16))) return rc;
+    if (total) HIP_TRY(hipMemcpy(B->d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
+    if ((rc = B->dmalloc(&B->d_read_off, (size_t)n_reads + 1))) return rc;
+    HIP_TRY(hipMemcpy(B->d_read_off, read_off, ((size_t)n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if ((rc = B->dmalloc(&B->d_read_model, (size_t)n_reads))) return rc;
+    if (n_reads) HIP_TRY(hipMemcpy(B->d_read_model, read_model, (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
+    if ((rc = B->dmalloc(&B->d_logp, (size_t)n_reads))) return rc;
+    if ((rc = B->dmalloc(&B->d_summary, (size_t)n_reads * ADVNTR_SUMMARY_INTS))) return rc;
+    if ((rc = B->dmalloc(&B->d_counter, 4))) return rc;
+
+    // processing order: heaviest (n+1)*E first, reads of one model adjacent (dynamic dequeue in-kernel)
+    std::vector<int32_t> order(n_reads);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const int64_t wa = (read_off[a + 1] - read_off[a] + 1) * (int64_t)B->models[read_model[a]]->n_edges;
+        const int64_t wb = (read_off[b + 1] - read_off[b] + 1) * (int64_t)B->models[read_model[b]]->n_edges;
+        if (wa != wb) return wa > wb;
+        return read_model[a] < read_model[b];
+    });
+    if ((rc = B->dmalloc(&B->d_order, (size_t)n_reads))) return rc;
+    if (n_reads) HIP_TRY(hipMemcpy(B->d_order, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
+
+    if (flags & ADVNTR_FLAG_PATH) {
+        B->path_off.assign((size_t)n_reads + 1, 0);
+        for (int r = 0; r < n_reads; ++r)
+            B->path_off[r + 1] = B->path_off[r] + (read_off[r + 1] - read_off[r]) + B->models[read_model[r]]->m + 2;
+        if ((rc = B->dmalloc(&B->d_path, (size_t)B->path_off[n_reads]))) return rc;
+        if ((rc = B->dmalloc(&B->d_path_off, (size_t)n_reads + 1))) return rc;
+        HIP_TRY(hipMemcpy(B->d_path_off, B->path_off.data(), ((size_t)n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        if ((rc = B->dmalloc(&B->d_path_len, (size_t)n_reads))) return rc;
+    }
+
+    const int cus = device_cus();
+    B->path_cap = B->n_max + B->m_max + 2;
+    if (B->use_columns) {
+        if ((rc = column_launch_prepare(B->col, B->models, B->n_max, cus, n_reads))) return fail(rc, "column launch: %s", g_err.c_str());
+        B->grid = B->col.grid;
+        if ((rc = B->dmalloc(&B->d_bp, (size_t)B->grid * B->col.bp_stride))) return rc;
+        B->bp_stride = B->col.bp_stride;
+        if ((rc = B->dmalloc(&B->d_pathbuf, (size_t)B->grid * B->col.waves_per_block * B->path_cap))) return rc;
+    } else {
+        B->lds_bytes = (size_t)B->m_max * 16;
+        int per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(B->lds_bytes, 1));
+        per_cu = std::max(per_cu, 1);
+        B->grid = std::max(1, std::min(n_reads, cus * per_cu));
+        B->bp_stride = (((int64_t)(B->n_max + 1) * B->m_max * bpw_max) + 255) & ~int64_t(255);
+        if ((rc = B->dmalloc(&B->d_bp, (size_t)B->grid * B->bp_stride))) return rc;
+        if ((rc = B->dmalloc(&B->d_pathbuf, (size_t)B->grid * B->path_cap))) return rc;
+        if (B->lds_bytes > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)viterbi_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)B->lds_bytes));
+    }
+    return ADVNTR_OK;
+}
+
+extern "C" advntr_batch *advntr_batch_create(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                                             const int64_t *read_off, const int32_t *read_model,
+                                             int32_t n_reads, uint32_t flags)
+{
+    advntr_batch *B = new advntr_batch();
+    if (batch_build(B, models, n_models, bases, read_off, read_model, n_reads, flags) != ADVNTR_OK) {
+        std::string keep = g_err;
+        advntr_batch_destroy(B);
+        g_err = keep;
+        return nullptr;
+    }
+    return B;
+}
+
+extern "C" void advntr_batch_destroy(advntr_batch *B)
+{
+    if (!B) return;
+    for (void *p : B->allocs) (void)hipFree(p);
+    if (B->ev0) (void)hipEventDestroy(B->ev0);
+    if (B->ev1) (void)hipEventDestroy(B->ev1);
+    if (B->stream) (void)hipStreamDestroy(B->stream);
+    delete B;
+}
+
+extern "C" int advntr_batch_result_ptrs(advntr_batch *B, void **d_logp, void **d_summary)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_result_ptrs: null batch");
+    if (d_logp) *d_logp = B->d_logp;
+    if (d_summary) *d_summary = B->d_summary;
+    return ADVNTR_OK;
+}
+
+extern "C" int64_t advntr_batch_device_bytes(const advntr_batch *B) { return B ? B->device_bytes : 0; }
+
+static BatchArgs make_args(advntr_batch *B)
+{
+    BatchArgs a{};
+    a.models = B->d_models; a.bases = B->d_bases; a.read_off = B->d_read_off; a.read_model = B->d_read_model;
+    a.n_reads = B->n_reads; a.out_logp = B->d_logp;
+    a.out_summary = (B->flags & ADVNTR_FLAG_NO_SUMMARY) ? nullptr : B->d_summary;
+    a.out_path = B->d_path; a.out_path_off = B->d_path_off; a.out_path_len = B->d_path_len;
+    a.bp_scratch = B->d_bp; a.bp_stride = B->bp_stride; a.path_scratch = B->d_pathbuf; a.path_cap = B->path_cap;
+    a.m_max = B->m_max; a.order = B->d_order; a.counter = B->d_counter;
+    return a;
+}
+
+extern "C" int advntr_batch_run(advntr_batch *B)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_run: null batch");
+    if (B->n_reads == 0) return ADVNTR_OK;
+    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 16, B->stream));
+    BatchArgs a = make_args(B);
+    if (B->use_columns) {
+        int rc = column_launch(B->col, a, B->flags, B->stream);
+        if (rc) return fail(rc, "column kernel launch failed: %s", g_err.c_str());
+    } else {
+        hipLaunchKernelGGL(viterbi_generic_kernel, dim3(B->grid), dim3(ADV_WAVE), B->lds_bytes, B->stream, a, B->flags);
+    }
+    HIP_TRY(hipGetLastError());
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_batch_sync(advntr_batch *B)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_sync: null batch");
+    HIP_TRY(hipStreamSynchronize(B->stream));
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_batch_run_timed(advntr_batch *B, int32_t iters, float *ms_per_run)
+{
+    if (!B || iters <= 0 || !ms_per_run) return fail(ADVNTR_ERR_ARG, "advntr_batch_run_timed: bad argument");
+    HIP_TRY(hipEventRecord(B->ev0, B->stream));
+    for (int i = 0; i < iters; ++i) {
+        int rc = advntr_batch_run(B);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(B->ev1, B->stream));
+    HIP_TRY(hipEventSynchronize(B->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, B->ev0, B->ev1));
+    *ms_per_run = ms / (float)iters;
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_batch_fetch(advntr_batch *B, double *out_logp, int32_t *out_summary)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_fetch: null batch");
+    HIP_TRY(hipStreamSynchronize(B->stream));
+    if (out_logp && B->n_reads)
+        HIP_TRY(hipMemcpy(out_logp, B->d_logp, (size_t)B->n_reads * sizeof(double), hipMemcpyDeviceToHost));
+    if (out_summary && B->n_reads && !(B->flags & ADVNTR_FLAG_NO_SUMMARY))
+        HIP_TRY(hipMemcpy(out_summary, B->d_summary, (size_t)B->n_reads * ADVNTR_SUMMARY_INTS * sizeof(int32_t),
+                          hipMemcpyDeviceToHost));
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_batch_fetch_paths(advntr_batch *B, int32_t *out_path, const int64_t *out_path_off,
+                                        int32_t *out_path_len)
+{
+    if (!B || !out_path || !out_path_off || !out_path_len)
+        return fail(ADVNTR_ERR_ARG, "advntr_batch_fetch_paths: bad argument");
+    if (!(B->flags & ADVNTR_FLAG_PATH)) return fail(ADVNTR_ERR_ARG, "batch was created without ADVNTR_FLAG_PATH");
+    HIP_TRY(hipStreamSynchronize(B->stream));
+    const int n = B->n_reads;
+    if (!n) return ADVNTR_OK;
+    std::vector<int32_t> lens(n), all((size_t)B->path_off[n]);
+    HIP_TRY(hipMemcpy(lens.data(), B->d_path_len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(all.data(), B->d_path, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int r = 0; r < n; ++r) {
+        const int64_t cap = out_path_off[r + 1] - out_path_off[r];
+        int len = lens[r];
+        if (len > 0 && len > cap) len = -2;
+        if (len > 0) memcpy(out_path + out_path_off[r], all.data() + B->path_off[r], (size_t)len * sizeof(int32_t));
+        out_path_len[r] = len;
+    }
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_viterbi_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                                    const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
+                                    double *out_logp, int32_t *out_summary, int32_t *out_path,
+                                    const int64_t *out_path_off, int32_t *out_path_len, uint32_t flags)
+{
+    if (!out_logp && n_reads) return fail(ADVNTR_ERR_ARG, "advntr_viterbi_batch: out_logp is null");
+    if ((flags & ADVNTR_FLAG_PATH) && (!out_path || !out_path_off || !out_path_len))
+        return fail(ADVNTR_ERR_ARG, "advntr_viterbi_batch: ADVNTR_FLAG_PATH needs out_path/out_path_off/out_path_len");
+    if (!out_summary) flags |= ADVNTR_FLAG_NO_SUMMARY;
+    advntr_batch *B = new advntr_batch();
+    int rc = batch_build(B, models, n_models, bases, read_off, read_model, n_reads, flags);
+    if (rc == ADVNTR_OK) rc = advntr_batch_run(B);
+    if (rc == ADVNTR_OK) rc = advntr_batch_fetch(B, out_logp, out_summary);
+    if (rc == ADVNTR_OK && (flags & ADVNTR_FLAG_PATH)) rc = advntr_batch_fetch_paths(B, out_path, out_path_off, out_path_len);
+    std::string keep = g_err;
+    advntr_batch_destroy(B);
+    g_err = keep;
+    return rc;
+}
+
+extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                                    const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
+                                    double *out_logp, uint32_t flags)
+{
+    if (!out_logp && n_reads) return fail(ADVNTR_ERR_ARG, "advntr_forward_batch: out_logp is null");
+    advntr_batch *B = new advntr_batch();
+    int rc = batch_build(B, models, n_models, bases, read_off, read_model, n_reads,
+                         (flags | ADVNTR_FLAG_FORCE_GENERIC | ADVNTR_FLAG_NO_SUMMARY) & ~ADVNTR_FLAG_PATH);
+    if (rc == ADVNTR_OK && n_reads) {
+        rc = [&]() -> int {
+            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 16, B->stream));
+            BatchArgs a = make_args(B);
+            hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid), dim3(ADV_WAVE), B->lds_bytes, B->stream, a);
+            HIP_TRY(hipGetLastError());
+            return ADVNTR_OK;
+        }();
+    }
+    if (rc == ADVNTR_OK) rc = advntr_batch_fetch(B, out_logp, nullptr);
+    std::string keep = g_err;
+    advntr_batch_destroy(B);
+    g_err = keep;
+    return rc;
+}

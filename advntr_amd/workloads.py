@@ -1,0 +1,69 @@
+"""Synthetic, seeded workloads of the scoring path: loci and read batches shaped like
+the ones adVNTR builds -- used by bench.py, smoke() and the size-scaled parity tests.  Nothing here reads
+/root/reference."""
+import numpy as np
+
+from . import hmm_utils, settings
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rand_seq(rng, n):
+    return _ACGT[rng.integers(0, 4, n)].tobytes().decode()
+
+
+class Locus(object):
+    def __init__(self, left, right, units, copies, error_rate, model):
+        self.left, self.right, self.units, self.copies, self.error_rate, self.model = \
+            left, right, units, copies, error_rate, model
+
+
+def make_locus(rng, flank, pattern_len, copies, error_rate=0.05, n_units=1, max_subs=2):
+    """Flanks and a repeat pattern of random ACGT; n_units equal-length repeat units that differ from the
+    pattern by <= max_subs substitutions (=> gap-free alignment, no MSA needed)."""
+    left, right = rand_seq(rng, flank), rand_seq(rng, flank)
+    pattern = rand_seq(rng, pattern_len)
+    units = [pattern]
+    for _ in range(n_units - 1):
+        u = list(pattern)
+        for _ in range(int(rng.integers(0, max_subs + 1))):
+            u[int(rng.integers(0, pattern_len))] = "ACGT"[int(rng.integers(0, 4))]
+        units.append("".join(u))
+    old = settings.MAX_ERROR_RATE
+    settings.MAX_ERROR_RATE = error_rate
+    try:
+        model = hmm_utils.get_read_matcher_model(left, right, units, copies)
+    finally:
+        settings.MAX_ERROR_RATE = old
+    return Locus(left, right, units, copies, error_rate, model)
+
+
+def make_reads(rng, locus, n_reads, read_len, locus_fraction=0.4, sub_rate=0.01):
+    """40 % locus-derived ((left[-U(0,100):] + unit*U(1,C) + right)[:read_len], padded, 1 % substitutions),
+    60 % uniform random ACGT."""
+    reads = []
+    for _ in range(n_reads):
+        if rng.random() < locus_fraction:
+            k = int(rng.integers(1, locus.copies + 1))
+            lf = int(rng.integers(0, min(len(locus.left), 100) + 1))
+            body = "".join(locus.units[int(rng.integers(0, len(locus.units)))] for _ in range(k))
+            s = (locus.left[len(locus.left) - lf:] + body + locus.right)[:read_len]
+            s = s + rand_seq(rng, read_len - len(s))
+            a = np.frombuffer(s.encode(), dtype=np.uint8).copy()
+            hit = rng.random(len(a)) < sub_rate
+            a[hit] = _ACGT[rng.integers(0, 4, int(hit.sum()))]
+            s = a.tobytes().decode()
+        else:
+            s = rand_seq(rng, read_len)
+        reads.append(s)
+    return reads
+
+
+def ref150(seed=20240601):
+    """Config C1's model: flank 150, 14-bp pattern, copies 11 -> 1413 states / 921 emitting / 4626 edges."""
+    return make_locus(np.random.default_rng(seed), 150, 14, 11, 0.05)
+
+
+def s300(seed=20240601):
+    """flank 30, 12-bp pattern, copies 3 -> 315 states / 197 emitting / 1004 edges."""
+    return make_locus(np.random.default_rng(seed), 30, 12, 3, 0.05)

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s Viterbi-scored on the BASELINE.json workload, one process per GPU.
+
+A "step" is one pass of the hot path (Viterbi DP + traceback + path summaries) over one resident batch
+of synthetic reads.  Workload at every N: config C1 of BASELINE.json / SURVEY 8d -- one REF150 locus
+(flank 150, 14-bp pattern, 11 copies: 1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp
+reads PER GPU (weak scaling: the read x locus batch shards with no data-path collective; the only RCCL
+call is the final gather of the 40-B/read result records to rank 0, inside the timed region).
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(n, m):
+    """B = n [read] + (n+1)*m [1-byte back-pointer per cell] + (n+m) [traceback reads] + 32."""
+    return n + (n + 1) * m + (n + m) + 32
+
+
+class _CudaArray(object):
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": typestr, "version": 2}
+
+
+def cpu_baseline(locus, bases, off, n_sample):
+    """The oracle (C restatement of the reference loop, full tables calloc'd per call) on a bounded sample
+    of the same reads, 1 thread -- the reference path is single-threaded (GIL held, hmm.pyx:1958)."""
+    from oracle.oracle import OracleModel
+    a = locus.model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    sub_off = off[:n_sample + 1]
+    t0 = time.perf_counter()
+    logp, _ = O.viterbi_many(bases[:sub_off[-1]], sub_off)
+    dt = time.perf_counter() - t0
+    return n_sample / dt, logp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=2000)
+    ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import __graft_entry__ as entry
+    entry.build()
+    from advntr_amd import _lib, workloads
+    _lib.check(_lib.load().advntr_set_device(local_rank))
+
+    locus = workloads.ref150()
+    a = locus.model.baked_arrays()
+    m, P, E = a["m"], a["silent_start"], len(a["in_src"])
+    n = 150
+    reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, args.reads, n)
+    bases, off = _lib.encode_reads(reads)
+    dm = locus.model.device_model()
+    flags = _lib.FLAG_FORCE_GENERIC if args.generic else 0
+    batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
+    kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
+
+    gathered = None
+    if world > 1:
+        p_logp, p_sum = batch.result_ptrs()
+        t_logp = torch.as_tensor(_CudaArray(p_logp, (args.reads,), "<f8"), device="cuda")
+        t_sum = torch.as_tensor(_CudaArray(p_sum, (args.reads, 8), "<i4"), device="cuda")
+        if rank == 0:
+            gathered = ([torch.empty_like(t_logp) for _ in range(world)],
+                        [torch.empty_like(t_sum) for _ in range(world)])
+
+    def step():
+        batch.run()
+        if world > 1:
+            batch.sync()
+            dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0)
+            dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    batch.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration, HIP events on the engine's launch stream
+    kernel_ms = batch.run_timed(max(1, min(args.steps, 3)))
+    logp, summ = batch.fetch()
+
+    if rank == 0:
+        total_reads = args.reads * world
+        value = total_reads * args.steps / elapsed
+        B = algorithmic_bytes(n, m)
+        achieved = B * args.reads / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
+                                   "150-bp reads per GPU, seed 20240601",
+                       "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
+                       "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
+                       "relaxations_per_s": value * (n + 1) * E},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_read": B,
+                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the max-plus recurrence is "
+                                 "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
+        }
+        if not args.no_cpu:
+            cps, cpu_logp = cpu_baseline(locus, bases, off, min(args.cpu_sample, args.reads))
+            assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
+            out["cpu_baseline"] = {"value": cps, "unit": "reads/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d reads of rank 0's batch, oracle/viterbi_oracle.c, 1 thread; "
+                                             "GPU logp bit-equal on the sample" % len(cpu_logp)}
+            out["config"]["speedup_vs_cpu_1thread"] = value / cps
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * advntr_hip.h -- C ABI of the MI355X-native profile-HMM scoring engine (libadvntr_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of adVNTR: the read-vs-locus-model Viterbi scoring
+ * loop that the reference runs through its vendored Cython pomegranate
+ *   HiddenMarkovModel.viterbi / _viterbi            /root/reference/pomegranate/hmm.pyx:1911-2136
+ *   HiddenMarkovModel.log_probability / _forward    /root/reference/pomegranate/hmm.pyx:1258-1313, 1371-1484
+ * as driven per read by advntr/vntr_finder.py:239,242,553,738, plus the Viterbi-path summaries that
+ * every caller derives from the returned path (advntr/hmm_utils.py:155-286).
+ *
+ * Plain C: pointers and sizes only, caller owns every buffer, status codes instead of exceptions
+ * (the reference raises ValueError / returns (-inf, None); see per-function notes).  No torch types.
+ * The reference-side binding (ctypes) is shown in INTEGRATION.md; advntr_amd/_lib.py is that binding.
+ *
+ * Symbol codes: A,C,G,T = 0,1,2,3 (the reference maps symbols through model.keymap, hmm.pyx:57-81,
+ * 1072-1080; any code > 3 is the "Symbol not defined" ValueError case -> ADVNTR_ERR_SYMBOL).
+ */
+#ifndef ADVNTR_HIP_H
+#define ADVNTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVNTR_OK               0
+#define ADVNTR_ERR_ARG         -1   /* bad argument (null pointer, negative size, index out of range)   */
+#define ADVNTR_ERR_SYMBOL      -2   /* a read holds a base code > 3  (reference: ValueError hmm.pyx:72,79) */
+#define ADVNTR_ERR_DEVICE      -3   /* HIP runtime error; text in advntr_last_error()                    */
+#define ADVNTR_ERR_TOO_LARGE   -4   /* model does not fit the on-chip trellis rows       */
+#define ADVNTR_ERR_UNSUPPORTED -5
+
+/* flags for advntr_viterbi_batch / advntr_batch_run */
+#define ADVNTR_FLAG_PATH          1u  /* also return the Viterbi paths (state indices, start..end)      */
+#define ADVNTR_FLAG_FORCE_GENERIC 2u  /* use the generic-CSR kernel even if a model has a column program */
+#define ADVNTR_FLAG_NO_SUMMARY    4u  /* skip the path summaries (out_summary untouched)                */
+
+/* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
+#define ADVNTR_SUMMARY_INTS   8
+#define ADVNTR_SUM_RU         0   /* get_number_of_repeats_in_vpath            [155-188] */
+#define ADVNTR_SUM_MATCHES    1   /* get_number_of_matches_in_vpath            [191-197] */
+#define ADVNTR_SUM_REPEAT_BP  2   /* get_number_of_repeat_bp_matches_in_vpath  [200-206] */
+#define ADVNTR_SUM_LEFT_BP    3   /* get_left_flanking_region_size_in_vpath    [271-277]; also the left denominator of [209-268] */
+#define ADVNTR_SUM_RIGHT_BP   4   /* get_right_flanking_region_size_in_vpath   [280-286]; right denominator */
+#define ADVNTR_SUM_LEFT_MATCH 5   /* left_flanking_matches of get_flanking_regions_matching_rate [209-268] */
+#define ADVNTR_SUM_RIGHT_MATCH 6  /* right_flanking_matches                                               */
+#define ADVNTR_SUM_PATH_LEN   7   /* number of states on the path incl. model start/end; 0 = impossible read */
+
+/* state_class bits (one uint16 per state; 0 for all = "no name information") */
+#define ADVNTR_SC_EMIT        0x0001  /* is_emitting_state: name starts with M or I          [122-126] */
+#define ADVNTR_SC_MATCH       0x0002  /* is_match_state: name starts with M                  [116-119] */
+#define ADVNTR_SC_SUFFIX      0x0004  /* name ends with 'suffix' (left flank block)                    */
+#define ADVNTR_SC_PREFIX      0x0008  /* name ends with 'prefix' (right flank block)                   */
+#define ADVNTR_SC_UNIT_START  0x0010  /* name starts with 'unit_start'                                 */
+#define ADVNTR_SC_UNIT_END    0x0020  /* name starts with 'unit_end'                                   */
+#define ADVNTR_SC_SKIP        0x0040  /* 'start' or 'end' occurs in the name (skipped at [227-228])    */
+#define ADVNTR_SC_FIX         0x0080  /* name ends with 'fix' ([204])                                  */
+#define ADVNTR_SC_BASE_SHIFT  8       /* bits 8-9: flank base an M*_suffix / M*_prefix state is compared
+                                         with at [236,248]; bit 10 set when that base is known         */
+#define ADVNTR_SC_BASE_VALID  0x0400
+
+typedef struct advntr_hmm advntr_hmm;       /* a baked model resident on the current device            */
+typedef struct advntr_batch advntr_batch;   /* a device-resident batch of reads bound to models        */
+
+/* ---- device ------------------------------------------------------------------------------- */
+int advntr_device_count(void);
+int advntr_set_device(int device);           /* per process: one process per GPU                        */
+const char *advntr_last_error(void);         /* thread-local message of the last failing call           */
+const char *advntr_version(void);
+
+/* ---- model (replaces the malloc'd CSR owned by a baked HiddenMarkovModel, hmm.pyx:935-1023) ---
+ * States are ordered emitting-first (index < silent_start) then silent in topological order, as bake()
+ * leaves them (hmm.pyx:850-887).  in_ptr/in_src/in_logp are bake()'s in_edge_count / in_transitions /
+ * in_transition_log_probabilities: in-edges of state l are in_src[in_ptr[l] .. in_ptr[l+1]) in
+ * graph.edges_iter() order -- that order decides ties (strict '>', hmm.pyx:2039,2060,2080).
+ * emis_logp: silent_start x 4 log-probabilities (DiscreteDistribution.bake, distributions.pyx:1366-1385).
+ * state_class: m entries of ADVNTR_SC_* bits or NULL.  Returns NULL on error.                        */
+advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index,
+                              int32_t n_edges, const int32_t *in_ptr, const int32_t *in_src,
+                              const double *in_logp, const double *emis_logp, const uint16_t *state_class);
+void advntr_hmm_destroy(advntr_hmm *model);  /* replaces free_bake_buffers, hmm.pyx:332-346             */
+/* 1 if the model was recognised as a flank-repeats-flank read matcher (hmm_utils.py:553-595) and has
+ * a column program for the anti-diagonal kernel; 0 if it runs on the generic-CSR kernel.              */
+int advntr_hmm_has_column_program(const advntr_hmm *model);
+int advntr_hmm_info(const advntr_hmm *model, int32_t *m, int32_t *silent_start, int32_t *n_edges,
+                    int32_t *n_columns);
+
+/* ---- one-shot scoring from host buffers (replaces N calls of Model.viterbi) -------------------
+ * bases: concatenated base codes; read r is bases[read_off[r] .. read_off[r+1]); read_model[r] indexes
+ * models[].  out_logp[n_reads] (fp64; -inf for an impossible read, hmm.pyx:2100-2105).
+ * out_summary[n_reads][ADVNTR_SUMMARY_INTS] or NULL.  With ADVNTR_FLAG_PATH: read r's path goes to
+ * out_path[out_path_off[r] .. out_path_off[r+1]) (capacity), its length to out_path_len[r]
+ * (0 = impossible, -2 = capacity too small).  The reference's own capacity is n+m (hmm.pyx:1953).
+ * Returns ADVNTR_OK or an error; ADVNTR_ERR_SYMBOL is raised before anything is launched.             */
+int advntr_viterbi_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                         const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
+                         double *out_logp, int32_t *out_summary, int32_t *out_path,
+                         const int64_t *out_path_off, int32_t *out_path_len, uint32_t flags);
+
+/* sum-product twin (Model.log_probability, hmm.pyx:1258-1313) */
+int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                         const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
+                         double *out_logp, uint32_t flags);
+
+/* ---- device-resident batches (what bench.py and the multi-GPU driver use) ---------------------
+ * create: uploads reads once; run: launches the kernels on the engine's stream, results stay in HBM;
+ * fetch: copies results back.  run_timed brackets `iters` runs with HIP events on the launch stream
+ * and returns the mean kernel-region milliseconds per run.                                           */
+advntr_batch *advntr_batch_create(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                                  const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
+                                  uint32_t flags);
+void advntr_batch_destroy(advntr_batch *batch);
+int advntr_batch_run(advntr_batch *batch);
+int advntr_batch_sync(advntr_batch *batch);
+int advntr_batch_run_timed(advntr_batch *batch, int32_t iters, float *ms_per_run);
+int advntr_batch_fetch(advntr_batch *batch, double *out_logp, int32_t *out_summary);
+int advntr_batch_fetch_paths(advntr_batch *batch, int32_t *out_path, const int64_t *out_path_off,
+                             int32_t *out_path_len);
+/* device addresses of the result arrays (fp64 logp[n_reads], int32 summary[n_reads][8]) so that a
+ * multi-GPU driver can hand them to RCCL without a host round trip; valid until batch_destroy.      */
+int advntr_batch_result_ptrs(advntr_batch *batch, void **d_logp, void **d_summary);
+/* scratch / trellis bytes this batch holds in HBM (for DESIGN.md's layout accounting) */
+int64_t advntr_batch_device_bytes(const advntr_batch *batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVNTR_HIP_H */

@@ -1,0 +1,45 @@
+"""The C-ABI library loads and exports every symbol include/advntr_hip.h declares (no GPU, no compute)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from advntr_amd import _lib
+    L = _lib.load()
+    header = open(os.path.join(ROOT, "include", "advntr_hip.h")).read()
+    declared = set(re.findall(r"\b(advntr_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.advntr_version()
+
+
+def test_header_constants_match_binding():
+    from advntr_amd import _lib
+    header = open(os.path.join(ROOT, "include", "advntr_hip.h")).read()
+    consts = dict(re.findall(r"#define\s+(ADVNTR_[A-Z_]+)\s+(-?(?:0x[0-9A-Fa-f]+|\d+))u?\b", header))
+    val = lambda k: int(consts[k], 0)
+    assert val("ADVNTR_SUMMARY_INTS") == _lib.SUMMARY_INTS
+    assert (val("ADVNTR_FLAG_PATH"), val("ADVNTR_FLAG_FORCE_GENERIC"), val("ADVNTR_FLAG_NO_SUMMARY")) == \
+        (_lib.FLAG_PATH, _lib.FLAG_FORCE_GENERIC, _lib.FLAG_NO_SUMMARY)
+    for k in ("EMIT", "MATCH", "SUFFIX", "PREFIX", "UNIT_START", "UNIT_END", "SKIP", "FIX", "BASE_VALID"):
+        assert val("ADVNTR_SC_" + k) == getattr(_lib, "SC_" + k)
+    assert val("ADVNTR_ERR_SYMBOL") == _lib.ERR_SYMBOL
+
+
+def test_scoring_without_gpu_fails_loudly():
+    """No CPU fallback: on a box without a HIP device the product path raises."""
+    from advntr_amd import _lib, workloads
+    import numpy as np
+    if _lib.load().advntr_device_count() > 0:
+        pytest.skip("a GPU is present")
+    locus = workloads.make_locus(np.random.default_rng(1), 8, 5, 2)
+    with pytest.raises(_lib.EngineError):
+        locus.model.viterbi("ACGTACGT")

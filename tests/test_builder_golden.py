@@ -1,0 +1,96 @@
+"""The host-side model builder (advntr_amd.hmm_utils / pomegranate mirror / profile_hmm) against the
+baked models captured from the reference: state order, CSR edge order, log-probs, emissions.
+
+Structure (names, indices, edge order) must match exactly.  Log-probs go through numpy.exp / libm log
+(dense_transition_matrix -> from_matrix, hmm.pyx:514,433); on the machine that produced the goldens they
+are bit-identical, elsewhere numpy's SIMD exp may differ in the last bit, hence the 4-ulp allowance.
+"""
+import numpy as np
+import pytest
+
+from conftest import READ_MATCHER_GOLDENS, load_golden
+from advntr_amd import hmm_utils, settings
+
+
+def build_from_golden(g):
+    settings.MAX_ERROR_RATE = g["error_rate"]
+    try:
+        return hmm_utils.get_read_matcher_model(g["left"], g["right"], g["aligned_repeats"], g["copies"])
+    finally:
+        settings.MAX_ERROR_RATE = 0.05
+
+
+@pytest.mark.parametrize("name", READ_MATCHER_GOLDENS)
+def test_read_matcher_matches_reference_bake(name):
+    g = load_golden(name)
+    gm = g["model"]
+    m = build_from_golden(g)
+    assert [s.name for s in m.states] == gm["state_names"]
+    assert (m.silent_start, m.start_index, m.end_index) == (gm["silent_start"], gm["start_index"], gm["end_index"])
+    idx = {s: i for i, s in enumerate(m.states)}
+    edges = [(idx[a], idx[b], lp) for a, b, lp in m.graph.edges()]
+    assert [(a, b) for a, b, _ in edges] == [(a, b) for a, b, _ in gm["edges"]]
+    got = np.array([e[2] for e in edges])
+    want = np.array([e[2] for e in gm["edges"]])
+    assert np.all(np.abs(got - want) <= 4 * np.spacing(np.abs(want)))
+    exact = float(np.mean(got == want))
+    assert exact > 0.999, exact
+    emis_want = np.array([e["logp"] for e in gm["emissions"]])
+    a = m.baked_arrays()
+    assert np.array_equal(a["emis_logp"], emis_want)
+    # CSR as the C ABI takes it == the oracle's CSR of the golden edge list
+    from oracle.oracle import OracleModel
+    in_ptr, in_src, in_logp, finite = OracleModel.from_golden(g).csr()
+    assert np.array_equal(a["in_ptr"], in_ptr) and np.array_equal(a["in_src"], in_src)
+    assert bool(m.finite) == finite
+
+
+def test_profile_parameters_multi_row():
+    """profile_hmm.py:13-161 on the reference fixture's 8-row alignment and on rows with insert columns,
+    compared through the emitted model (emission probabilities are part of the golden)."""
+    for name in ("msa8_f50_c4", "msa_gaps_f40_c5"):
+        g = load_golden(name)
+        m = build_from_golden(g)
+        for s, e in zip(m.states[:m.silent_start], g["model"]["emissions"]):
+            assert [s.distribution.parameters[0][c] for c in "ACGT"] == e["prob"], s.name
+
+
+def test_unaligned_repeats_are_refused():
+    with pytest.raises(NotImplementedError):
+        hmm_utils.get_read_matcher_model("ACGTACGT", "TTGACCAA", ["ACGTT", "ACGT"], 2)
+
+
+def test_bake_merge_other_than_none_is_refused():
+    from advntr_amd import HiddenMarkovModel
+    with pytest.raises(NotImplementedError):
+        HiddenMarkovModel("x").bake()
+
+
+def test_host_path_summaries_on_goldens():
+    from advntr_amd.pomegranate import State
+    for name in READ_MATCHER_GOLDENS:
+        g = load_golden(name)
+        names = g["model"]["state_names"]
+        for r in g["reads"]:
+            if r["path"] is None:
+                continue
+            vpath = [(i, State(None, names[i])) for i in r["path"]]
+            assert hmm_utils.get_number_of_repeats_in_vpath(vpath) == r["ru"]
+            assert hmm_utils.get_number_of_matches_in_vpath(vpath) == r["matches"]
+            assert hmm_utils.get_number_of_repeat_bp_matches_in_vpath(vpath) == r["repeat_bp"]
+            assert hmm_utils.get_left_flanking_region_size_in_vpath(vpath) == r["left_bp"]
+            assert hmm_utils.get_right_flanking_region_size_in_vpath(vpath) == r["right_bp"]
+            if "flank_rate" in r:
+                assert hmm_utils.get_flanking_regions_matching_rate(vpath, r["seq"], g["left"], g["right"]) == r["flank_rate"]
+
+
+def test_reference_fixture_known_answers_host():
+    from advntr_amd.pomegranate import State
+    g = load_golden("reference_fixture_hmm_utils")
+    vpath = [(0, State(None, "s"))] + [(0, State(None, n)) for n in g["visited_states"]] + [(0, State(None, "e"))]
+    a = g["answers"]
+    assert hmm_utils.get_number_of_repeats_in_vpath(vpath) == a["ru"]
+    assert hmm_utils.get_number_of_matches_in_vpath(vpath) == a["matches"]
+    assert hmm_utils.get_number_of_repeat_bp_matches_in_vpath(vpath) == a["repeat_bp"]
+    assert hmm_utils.get_left_flanking_region_size_in_vpath(vpath) == a["left_bp"]
+    assert hmm_utils.get_right_flanking_region_size_in_vpath(vpath) == a["right_bp"]

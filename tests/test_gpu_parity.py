@@ -1,0 +1,192 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(1) the golden vectors captured from the reference and (2) the CPU oracle on seeded synthetic batches.
+
+Bars: log-probabilities bit-exact (==; the north star allows 1e-4, asserted as well), Viterbi paths
+identical, RU counts and the other integer summaries exact, recruit verdicts exact.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import ALL_MODEL_GOLDENS, READ_MATCHER_GOLDENS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def device_model_from_golden(g):
+    from advntr_amd import _lib
+    from advntr_amd.pomegranate import state_class_from_name
+    from oracle.oracle import OracleModel
+    gm = g["model"]
+    O = OracleModel.from_golden(g)
+    in_ptr, in_src, in_logp, _ = O.csr()
+    bases = {}
+    if g.get("kind") == "read_matcher":
+        F = len([n for n in gm["state_names"] if n.startswith("M") and n.endswith("_suffix")])
+        for i, ch in enumerate(g["left"][-F:]):
+            bases["M%d_suffix" % (i + 1)] = "ACGT".index(ch)
+        for i, ch in enumerate(g["right"][:F]):
+            bases["M%d_prefix" % (i + 1)] = "ACGT".index(ch)
+    cls = np.array([state_class_from_name(n, bases.get(n)) for n in gm["state_names"]], np.uint16)
+    dm = _lib.DeviceModel(len(gm["state_names"]), gm["silent_start"], gm["start_index"], gm["end_index"],
+                          in_ptr, in_src, in_logp, O.emis, cls)
+    return dm, O
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("name", ALL_MODEL_GOLDENS)
+def test_golden_logp_paths_summaries(name, force_generic):
+    from advntr_amd import _lib
+    from advntr_amd.hmm_utils import flanking_rate_from_counts
+    g = load_golden(name)
+    dm, _ = device_model_from_golden(g)
+    if not force_generic and not dm.has_column_program():
+        pytest.skip("model has no column program; generic kernel covered by the other parametrisation")
+    reads = [r["seq"] for r in g["reads"]]
+    bases, off = _lib.encode_reads(reads)
+    flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
+                                           want_paths=True)
+    for i, r in enumerate(g["reads"]):
+        want = r["logp"]
+        assert logp[i] == want or (math.isinf(want) and math.isinf(logp[i])), (name, i, logp[i], want)
+        assert math.isinf(want) or abs(logp[i] - want) <= 1e-4
+        assert paths[i] == r["path"], (name, i)
+        if r["path"] is None or g.get("kind") != "read_matcher":
+            continue
+        s = summ[i]
+        assert s[_lib.SUM_PATH_LEN] == len(r["path"])
+        assert s[_lib.SUM_RU] == r["ru"], (name, i)
+        assert s[_lib.SUM_MATCHES] == r["matches"]
+        assert s[_lib.SUM_REPEAT_BP] == r["repeat_bp"]
+        assert s[_lib.SUM_LEFT_BP] == r["left_bp"]
+        assert s[_lib.SUM_RIGHT_BP] == r["right_bp"]
+        if "flank_rate" in r:
+            rate = flanking_rate_from_counts(s[_lib.SUM_LEFT_MATCH], s[_lib.SUM_LEFT_BP],
+                                             s[_lib.SUM_RIGHT_MATCH], s[_lib.SUM_RIGHT_BP])
+            assert rate == r["flank_rate"], (name, i)
+            rate_acc = flanking_rate_from_counts(s[_lib.SUM_LEFT_MATCH], s[_lib.SUM_LEFT_BP],
+                                                 s[_lib.SUM_RIGHT_MATCH], s[_lib.SUM_RIGHT_BP], True)
+            assert rate_acc == r["flank_rate_acc"]
+
+
+@pytest.mark.parametrize("name", ALL_MODEL_GOLDENS)
+def test_golden_forward(name):
+    """log_probability: device libm + chunked fold order => rounding-level agreement (1e-9 relative;
+    the north star asks for 1e-4 absolute)."""
+    from advntr_amd import _lib
+    g = load_golden(name)
+    rs = [r for r in g["reads"] if "forward_logp" in r]
+    if not rs:
+        pytest.skip("no forward values in this golden")
+    dm, _ = device_model_from_golden(g)
+    bases, off = _lib.encode_reads([r["seq"] for r in rs])
+    got = _lib.forward_batch([dm], bases, off, np.zeros(len(rs), np.int32))
+    for v, r in zip(got, rs):
+        want = r["forward_logp"]
+        if math.isinf(want):
+            assert math.isinf(v)
+        else:
+            assert abs(v - want) <= 1e-9 * max(1.0, abs(want)), (name, v, want)
+            assert abs(v - want) <= 1e-4
+
+
+def test_mirror_model_viterbi_api():
+    """The pomegranate-shaped call: model.viterbi(seq) -> (logp, [(idx, State)...]); errors as the reference."""
+    from advntr_amd import hmm_utils, settings
+    g = load_golden("s300_f30_l12_c3")
+    settings.MAX_ERROR_RATE = g["error_rate"]
+    m = hmm_utils.get_read_matcher_model(g["left"], g["right"], g["aligned_repeats"], g["copies"])
+    for r in g["reads"][:12]:
+        logp, vpath = m.viterbi(r["seq"])
+        assert abs(logp - r["logp"]) <= 1e-4
+        assert [i for i, _ in vpath] == r["path"]
+        assert vpath[0][1].name == "Read Matcher-start" and vpath[-1][1].name.endswith("-end")
+        assert hmm_utils.get_number_of_repeats_in_vpath(vpath) == r["ru"]
+    with pytest.raises(ValueError):
+        m.viterbi("ACGTNACGT")                      # hmm.pyx:72,79
+    lp = m.log_probability(g["reads"][0]["seq"])
+    assert abs(lp - g["reads"][0]["forward_logp"]) <= 1e-4
+    from advntr_amd import HiddenMarkovModel
+    with pytest.raises(ValueError):
+        HiddenMarkovModel("unbaked").viterbi("ACGT")  # hmm.pyx:1944-1945
+
+
+@pytest.mark.parametrize("shape", ["s300", "ref150"])
+@pytest.mark.parametrize("force_generic", [True, False])
+def test_synthetic_batch_vs_oracle(shape, force_generic):
+    """Seeded C1-style batch at a size the oracle finishes in seconds."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    locus = getattr(workloads, shape)()
+    n_reads = 1500 if shape == "s300" else 400
+    reads = workloads.make_reads(np.random.default_rng(99), locus, n_reads, 150)
+    # ragged + edge cases: empty read, 1 base, long read
+    reads += ["", "A", workloads.rand_seq(np.random.default_rng(3), 301)]
+    m = locus.model
+    dm = m.device_model()
+    if not force_generic and not dm.has_column_program():
+        pytest.skip("no column program")
+    flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
+                                           want_paths=True)
+    a = m.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    want, _ = O.viterbi_many(bases, off)
+    assert np.array_equal(logp, want)
+    names = [s.name for s in m.states]
+    from oracle import oracle as Or
+    for i in range(0, len(reads), 7):
+        olp, opath = O.viterbi(reads[i])
+        assert paths[i] == opath
+        inner = [names[j] for j in opath][1:-1]
+        assert summ[i][_lib.SUM_RU] == Or.number_of_repeats(inner)
+        assert summ[i][_lib.SUM_MATCHES] == Or.number_of_matches(inner)
+        assert summ[i][_lib.SUM_REPEAT_BP] == Or.repeat_bp_matches(inner)
+        if len(reads[i]) > 0:
+            lm, lb, rm, rb = Or.flanking_counts(inner, reads[i], locus.left, locus.right)
+            assert tuple(summ[i][[_lib.SUM_LEFT_MATCH, _lib.SUM_LEFT_BP, _lib.SUM_RIGHT_MATCH, _lib.SUM_RIGHT_BP]]) == (lm, lb, rm, rb)
+
+
+def test_multi_model_batch_and_device_resident_api():
+    """Several loci in one batch (reads interleaved), through the device-resident batch API."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(2024)
+    loci = [workloads.make_locus(rng, 40, int(rng.integers(6, 30)), 4) for _ in range(5)]
+    reads, which = [], []
+    for k, loc in enumerate(loci):
+        rs = workloads.make_reads(rng, loc, 30, int(rng.integers(50, 120)))
+        reads += rs
+        which += [k] * len(rs)
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    which = np.array([which[i] for i in perm], np.int32)
+    dms = [loc.model.device_model() for loc in loci]
+    bases, off = _lib.encode_reads(reads)
+    B = _lib.DeviceBatch(dms, bases, off, which)
+    B.run()
+    logp, summ = B.fetch()
+    ms = B.run_timed(2)
+    assert ms > 0
+    logp2, _ = B.fetch()
+    assert np.array_equal(logp, logp2)          # idempotent re-run on resident inputs
+    for k, loc in enumerate(loci):
+        a = loc.model.baked_arrays()
+        edges = [(int(a["in_src"][q]), l, float(a["in_logp"][q]))
+                 for l in range(a["m"]) for q in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+        for i in np.flatnonzero(which == k):
+            assert logp[i] == O.viterbi(reads[i])[0]
+    B.close()
+
+
+def test_bad_symbol_is_rejected_before_launch():
+    from advntr_amd import _lib, workloads
+    loc = workloads.make_locus(np.random.default_rng(1), 8, 5, 2)
+    with pytest.raises(ValueError):
+        loc.model.viterbi_batch(["ACGT", "ACNT"])
