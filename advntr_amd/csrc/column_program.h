@@ -1,12 +1,434 @@
-// column_program.h -- placeholder until the anti-diagonal kernel lands.
+// column_program.h -- host-side compiler from a baked CSR model to the "column program" that the
+// anti-diagonal Viterbi kernel (viterbi_columns.h) executes.
+//
+// A flank-repeats-flank read matcher (/root/reference/advntr/hmm_utils.py:553-595) is, after bake(),
+// one long chain: its silent states (delete states and connectors) are in topological index order and
+// every emitting state hangs off that chain.  Column c = silent "backbone" state b_c plus at most one
+// insert-like state I_c (self loop) and one match-like state M_c, with the profile-HMM stencil
+//     I_c(t) = e + max[ I_c(t-1), M_c(t-1), b_c(t-1) ]                       (previous row, same column)
+//     M_c(t) = e + max[ I_{c-1}(t-1), M_{c-1}(t-1), X, b_{c-1}(t-1) ]        (previous row, previous column;
+//                                                   X = an entry edge from a row-0-only silent state)
+//     b_c(t) =     max[ I_{c-1}(t), M_{c-1}(t), b_{c-1}(t) ]                 (same row, previous column)
+// plus "feed/sink" pairs for silent fan-in across columns (end_repeating_pattern_match <- every
+// unit_end_k) and a short "tail" of silent states that only matter in the last row (prefix_end_prefix,
+// the model end: fan-in from every match state) which the kernel evaluates from a row-n buffer.
+// Cell (t,c) depends only on anti-diagonals t+c-1 and t+c-2, so 64 rows advance in lock step.
+//
+// Nothing here trusts names: the layout is derived from the graph, and EVERY in-edge of every state must
+// be claimed by the stencil in the reference's evaluation order (strict '>' => first maximum wins,
+// hmm.pyx:2039,2060,2080); otherwise the model simply has no column program and runs on the generic
+// kernel.  Transition/emission parameters are de-duplicated bit-exactly into small class tables so the
+// whole program of a 1413-state model is ~20 KB of LDS.
 #pragma once
 #include <stdint.h>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
 #include <vector>
-struct advntr_hmm;
-struct ColProgram { int32_t n_cols; };
+
+#define COL_FLAG_FEED 1u      // b_c feeds the running accumulator of the next sink
+#define COL_FLAG_SINK 2u      // b_c := accumulator (fan-in from earlier backbone states)
+#define COL_MAX_SINKS 4
+#define COL_MAX_READ 256      // rows handled in registers: 4 chunks of 64 lanes
+
+struct ColClass {             // 12 doubles = 96 B, read as 6 x ds_read_b128
+    double iI, iM, iD, mI;    // I_c <- I_c, M_c, b_c (prev row);   M_c <- I_{c-1}
+    double mM, mX, mD, dI;    // M_c <- M_{c-1}, X (row 0 only, value incl. source), b_{c-1};  b_c <- I_{c-1}
+    double dM, dD, erw, pad;  // b_c <- M_{c-1}, b_{c-1};  feed weight
+};
+
+struct ColInfo {              // 16 B per column (with one dummy column at either end)
+    double v0b;               // row-0 value of b_c (read independent)
+    uint16_t tclass, emM, emI, flags;   // flags: COL_FLAG_* | sink index << 4
+};
+
+struct ColState {             // 16 B per column: state indices for the traceback
+    int32_t sI, sM, sB, sX;
+};
+
+struct TailEdge {             // in-edge of a tail state, reference evaluation order
+    int32_t loc;              // >= 0: column*4 + slot (0 I, 1 M, 2 b);  < 0: -(tail index)-1
+    int32_t src_state;
+    double logp;
+};
+
+// device header; arrays follow at the byte offsets
+struct ColProgram {
+    int32_t n_cols, n_tclass, n_eclass, n_tail, n_sinks, end_tail, m, P;
+    int32_t off_class, off_emis, off_info, off_state, off_pred0, off_tail_ptr, off_tail_state, off_tail_edge;
+    int32_t off_v0, lds_bytes, pad0, pad1;
+};
+
 struct ColProgramHost {
     bool valid = false;
-    int32_t n_cols = 0;
-    std::vector<uint8_t> serialize() const { return {}; }
+    std::string why;                       // why there is no program (diagnostics)
+    int32_t n_cols = 0, n_sinks = 0, m = 0, P = 0;
+    std::vector<ColClass> classes;
+    std::vector<double> emis;              // n_eclass * 4
+    std::vector<ColInfo> info;             // n_cols + 2
+    std::vector<ColState> state;           // n_cols + 2
+    std::vector<int32_t> pred0;            // per silent state: row-0 predecessor state or -1
+    std::vector<double> v0;                // per silent state: row-0 value
+    std::vector<int32_t> tail_state, tail_ptr;
+    std::vector<TailEdge> tail_edges;
+    int32_t end_tail = -1;
+
+    size_t lds_bytes() const
+    {
+        return classes.size() * sizeof(ColClass) + emis.size() * sizeof(double) + info.size() * sizeof(ColInfo) +
+               state.size() * sizeof(ColState);
+    }
+
+    std::vector<uint8_t> serialize() const
+    {
+        std::vector<uint8_t> out(sizeof(ColProgram), 0);
+        auto add = [&](const void *p, size_t bytes) -> int32_t {
+            size_t off = (out.size() + 15) & ~size_t(15);
+            out.resize(off + bytes + 16, 0);
+            if (bytes) memcpy(out.data() + off, p, bytes);
+            return (int32_t)off;
+        };
+        ColProgram h{};
+        h.n_cols = n_cols; h.n_tclass = (int32_t)classes.size(); h.n_eclass = (int32_t)(emis.size() / 4);
+        h.n_tail = (int32_t)tail_state.size(); h.n_sinks = n_sinks; h.end_tail = end_tail; h.m = m; h.P = P;
+        // the four LDS-resident tables are contiguous and in this order
+        h.off_class = add(classes.data(), classes.size() * sizeof(ColClass));
+        h.off_emis = add(emis.data(), emis.size() * sizeof(double));
+        h.off_info = add(info.data(), info.size() * sizeof(ColInfo));
+        h.off_state = add(state.data(), state.size() * sizeof(ColState));
+        h.lds_bytes = (int32_t)(((out.size() + 15) & ~size_t(15)) - (size_t)h.off_class);
+        h.off_pred0 = add(pred0.data(), pred0.size() * sizeof(int32_t));
+        h.off_v0 = add(v0.data(), v0.size() * sizeof(double));
+        h.off_tail_ptr = add(tail_ptr.data(), tail_ptr.size() * sizeof(int32_t));
+        h.off_tail_state = add(tail_state.data(), tail_state.size() * sizeof(int32_t));
+        h.off_tail_edge = add(tail_edges.data(), tail_edges.size() * sizeof(TailEdge));
+        memcpy(out.data(), &h, sizeof h);
+        return out;
+    }
 };
-static inline void build_column_program(const advntr_hmm &, ColProgramHost &out) { out.valid = false; }
+
+namespace colprog_detail {
+
+struct Key96 {
+    uint64_t w[12];
+    bool operator<(const Key96 &o) const { return memcmp(w, o.w, sizeof w) < 0; }
+};
+struct Key32 {
+    uint64_t w[4];
+    bool operator<(const Key32 &o) const { return memcmp(w, o.w, sizeof w) < 0; }
+};
+
+}  // namespace colprog_detail
+
+// Model view the builder needs (engine.hip's advntr_hmm satisfies it; tests can pass their own).
+template <class Model>
+static inline bool build_column_program(const Model &H, ColProgramHost &out)
+{
+    using namespace colprog_detail;
+    const double NINF = -INFINITY;
+    const int m = H.m, P = H.P, S = m - P;
+    const std::vector<int32_t> &in_ptr = H.in_ptr, &in_src = H.in_src;
+    const std::vector<double> &in_logp = H.in_logp;
+    out = ColProgramHost();
+    out.m = m; out.P = P;
+    auto fail = [&](const std::string &why) { out.valid = false; out.why = why; return false; };
+    if (!H.finite) return fail("model has no end state in-edges (infinite model)");
+    if (S < 2 || P < 1) return fail("too few states");
+    if (m > 65000) return fail("too many states");
+
+    // out-degree, self loops
+    std::vector<int> outdeg(m, 0);
+    std::vector<char> selfloop(m, 0);
+    for (int l = 0; l < m; ++l)
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) {
+            outdeg[in_src[k]]++;
+            if (in_src[k] == l) selfloop[l] = 1;
+        }
+    for (int l = P; l < m; ++l)
+        if (selfloop[l]) return fail("silent self loop");
+
+    // reference evaluation order of a silent state's in-edges (emitting-sourced, then silent ki<l)
+    auto rlist = [&](int l, std::vector<int> &ks) {
+        ks.clear();
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (in_src[k] < P) ks.push_back(k);
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (in_src[k] >= P && in_src[k] < l) ks.push_back(k);
+    };
+    // silent edges from ki >= l never fire in the reference (hmm.pyx:2069); they only matter if present
+    for (int l = P; l < m; ++l)
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (in_src[k] >= l) return fail("silent edge against the topological order");
+
+    // ---- row 0 (read independent): hmm.pyx:1999-2023
+    out.v0.assign(S, NINF);
+    out.pred0.assign(S, -1);
+    out.v0[H.start - P] = 0.0;
+    for (int l = P; l < m; ++l) {
+        if (l == H.start) continue;
+        double best = NINF;
+        int bs = -1;
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) {
+            const int ki = in_src[k];
+            if (ki < P || ki >= l) continue;
+            const double cand = out.v0[ki - P] + in_logp[k];
+            if (cand > best) { best = cand; bs = ki; }
+        }
+        out.v0[l - P] = best;
+        out.pred0[l - P] = bs;
+    }
+
+    // ---- reachable from an emitting state (=> may be alive in rows >= 1)
+    std::vector<char> live(m, 0);
+    for (int l = 0; l < P; ++l) live[l] = 1;
+    for (int l = P; l < m; ++l)
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
+            if (live[in_src[k]]) live[l] = 1;
+
+    // ---- dead ends and tail: silent states whose every out-edge leads to the end through silent states only
+    std::vector<std::vector<int>> outs(m);
+    for (int l = 0; l < m; ++l)
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) outs[in_src[k]].push_back(l);
+    std::vector<char> dead(m, 0), tail(m, 0);
+    tail[H.end] = 1;
+    if (H.end < P) return fail("end state is emitting");
+    for (int l = m - 1; l >= P; --l) {
+        if (l == H.end) continue;
+        if (outdeg[l] == 0) { dead[l] = 1; continue; }
+        bool all = true;
+        for (int d : outs[l])
+            if (!(d >= P && (tail[d] || dead[d]))) all = false;
+        if (all) tail[l] = 1;
+    }
+    if (outdeg[H.end] != 0) return fail("end state has out-edges");
+
+    // ---- backbone columns
+    std::vector<int> pos(m, -1), backbone;
+    for (int l = P; l < m; ++l)
+        if (!dead[l] && !tail[l]) { pos[l] = (int)backbone.size(); backbone.push_back(l); }
+    const int NC = (int)backbone.size();
+    if (NC < 2) return fail("no backbone");
+    if (backbone[0] != H.start && out.v0[backbone[0] - P] != NINF) { /* fine: any order */ }
+    for (int l = P; l < m; ++l)
+        if (dead[l])
+            for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) (void)k;   // edges into dead ends are ignored
+
+    // ---- emitting states -> (column, slot)
+    std::vector<int> colI(NC, -1), colM(NC, -1), colOf(m, -1), slotOf(m, -1);
+    for (int u = 0; u < P; ++u) {
+        int bmax = -1;
+        for (int k = in_ptr[u]; k < in_ptr[u + 1]; ++k) {
+            const int s = in_src[k];
+            if (s >= P) {
+                if (pos[s] < 0) return fail("emitting state fed by a tail/dead silent state");
+                bmax = std::max(bmax, s);
+            }
+        }
+        if (bmax < 0) return fail("emitting state without a silent predecessor");
+        const bool isI = selfloop[u];
+        const int c = pos[bmax] + (isI ? 0 : 1);
+        if (c >= NC) return fail("match state beyond the last column");
+        if (isI) {
+            if (colI[c] >= 0) return fail("two insert-like states in one column");
+            colI[c] = u;
+        } else {
+            if (colM[c] >= 0) return fail("two match-like states in one column");
+            colM[c] = u;
+        }
+        colOf[u] = c;
+        slotOf[u] = isI ? 0 : 1;
+    }
+    for (int c = 0; c < NC; ++c) { colOf[backbone[c]] = c; slotOf[backbone[c]] = 2; }
+
+    // ---- per column parameters, validating every in-edge against the stencil order
+    std::vector<ColClass> percol(NC);
+    std::vector<ColState> st(NC);
+    std::vector<uint16_t> flags(NC, 0);
+    std::vector<int> feed_sink(NC, -1);
+    int n_sinks = 0;
+    for (int c = 0; c < NC; ++c) {
+        ColClass &T = percol[c];
+        T.iI = T.iM = T.iD = T.mI = T.mM = T.mX = T.mD = T.dI = T.dM = T.dD = T.erw = NINF;
+        T.pad = 0.0;
+        st[c].sI = colI[c]; st[c].sM = colM[c]; st[c].sB = backbone[c]; st[c].sX = -1;
+    }
+    for (int c = 0; c < NC; ++c) {
+        ColClass &T = percol[c];
+        // I slot: [I_c, M_c, b_c] at the previous row
+        if (colI[c] >= 0) {
+            const int u = colI[c];
+            int stage = -1;
+            for (int k = in_ptr[u]; k < in_ptr[u + 1]; ++k) {
+                const int s = in_src[k];
+                int w;
+                if (s == u) w = 0;
+                else if (s == colM[c]) w = 1;
+                else if (s == backbone[c]) w = 2;
+                else return fail("insert-like state has an in-edge outside the stencil");
+                if (w <= stage) return fail("insert-like state: in-edge order differs from [I,M,b]");
+                stage = w;
+                (w == 0 ? T.iI : w == 1 ? T.iM : T.iD) = in_logp[k];
+            }
+        }
+        // M slot: [I_{c-1}, M_{c-1}, X, b_{c-1}] at the previous row
+        if (colM[c] >= 0) {
+            const int u = colM[c];
+            if (c == 0) return fail("match-like state in column 0");
+            int stage = -1;
+            for (int k = in_ptr[u]; k < in_ptr[u + 1]; ++k) {
+                const int s = in_src[k];
+                int w;
+                if (s == colI[c - 1] && s >= 0) w = 0;
+                else if (s == colM[c - 1] && s >= 0) w = 1;
+                else if (s == backbone[c - 1]) w = 3;
+                else if (s >= P && pos[s] >= 0 && !live[s]) w = 2;      // entry edge from a row-0-only state
+                else return fail("match-like state has an in-edge outside the stencil");
+                if (w <= stage) return fail("match-like state: in-edge order differs from [I,M,X,b]");
+                stage = w;
+                if (w == 0) T.mI = in_logp[k];
+                else if (w == 1) T.mM = in_logp[k];
+                else if (w == 3) T.mD = in_logp[k];
+                else { T.mX = out.v0[s - P] + in_logp[k]; st[c].sX = s; }   // (v + t), e is added on device
+            }
+        }
+        // backbone state
+        {
+            const int l = backbone[c];
+            std::vector<int> ks;
+            rlist(l, ks);
+            bool stencil = true;
+            int stage = -1;
+            for (int k : ks) {
+                const int s = in_src[k];
+                int w;
+                if (c > 0 && s == colI[c - 1] && s >= 0) w = 0;
+                else if (c > 0 && s == colM[c - 1] && s >= 0) w = 1;
+                else if (c > 0 && s == backbone[c - 1]) w = 2;
+                else { stencil = false; break; }
+                if (w <= stage) { stencil = false; break; }
+                stage = w;
+            }
+            if (stencil) {
+                for (int k : ks) {
+                    const int s = in_src[k];
+                    if (s == colI[c - 1]) T.dI = in_logp[k];
+                    else if (s == colM[c - 1]) T.dM = in_logp[k];
+                    else T.dD = in_logp[k];
+                }
+            } else {
+                // sink: every source is an earlier backbone state, in increasing column order
+                if (n_sinks >= COL_MAX_SINKS) return fail("too many fan-in states");
+                int lastpos = -1;
+                for (int k : ks) {
+                    const int s = in_src[k];
+                    if (s < P || pos[s] < 0 || pos[s] >= c) return fail("silent fan-in from a non-backbone state");
+                    if (pos[s] <= lastpos) return fail("silent fan-in not in column order");
+                    lastpos = pos[s];
+                    if (flags[pos[s]] & COL_FLAG_FEED) return fail("backbone state feeds two fan-in states");
+                    flags[pos[s]] |= COL_FLAG_FEED;
+                    feed_sink[pos[s]] = n_sinks;
+                    percol[pos[s]].erw = in_logp[k];
+                }
+                flags[c] |= COL_FLAG_SINK | (uint16_t)(n_sinks << 4);
+                n_sinks++;
+            }
+        }
+    }
+    // feeds and sinks must not interleave: between a feeder and its sink there is no other sink, and no
+    // feeder of a different sink
+    {
+        int cur = -1;
+        for (int c = 0; c < NC; ++c) {
+            if (flags[c] & COL_FLAG_SINK) {
+                const int sidx = flags[c] >> 4;
+                if (cur != -1 && cur != sidx) return fail("interleaved fan-in ranges");
+                cur = -1;
+            }
+            if (flags[c] & COL_FLAG_FEED) {
+                if (cur != -1 && cur != feed_sink[c]) return fail("interleaved fan-in ranges");
+                cur = feed_sink[c];
+            }
+        }
+        if (cur != -1) return fail("feeder without a sink");
+    }
+    // a feeder that is also claimed by the next column's stencil (b_{c-1} edge) would be double counted:
+    // the sink takes ONLY the accumulator, so check sinks have no stencil edges (true by construction).
+
+    // ---- tail states (evaluated at the last row only), index order
+    std::map<int, int> tail_idx;
+    out.tail_ptr.push_back(0);
+    for (int l = P; l < m; ++l) {
+        if (!tail[l]) continue;
+        tail_idx[l] = (int)out.tail_state.size();
+        out.tail_state.push_back(l);
+        std::vector<int> ks;
+        rlist(l, ks);
+        for (int k : ks) {
+            const int s = in_src[k];
+            TailEdge e;
+            e.src_state = s;
+            e.logp = in_logp[k];
+            if (s >= P && tail[s]) e.loc = -(tail_idx[s]) - 1;
+            else if (s >= P && dead[s]) return fail("tail state fed by a dead end");
+            else e.loc = colOf[s] * 4 + slotOf[s];
+            out.tail_edges.push_back(e);
+        }
+        out.tail_ptr.push_back((int32_t)out.tail_edges.size());
+    }
+    out.end_tail = tail_idx[H.end];
+
+    // ---- class tables (bit-exact de-duplication)
+    std::map<Key96, int> cmap;
+    std::map<Key32, int> emap;
+    auto class_of = [&](const ColClass &T) {
+        Key96 key;
+        memcpy(key.w, &T, sizeof key.w);
+        auto it = cmap.find(key);
+        if (it != cmap.end()) return it->second;
+        const int id = (int)out.classes.size();
+        out.classes.push_back(T);
+        cmap[key] = id;
+        return id;
+    };
+    auto eclass_of = [&](const double *e4) {
+        Key32 key;
+        memcpy(key.w, e4, sizeof key.w);
+        auto it = emap.find(key);
+        if (it != emap.end()) return it->second;
+        const int id = (int)(out.emis.size() / 4);
+        out.emis.insert(out.emis.end(), e4, e4 + 4);
+        emap[key] = id;
+        return id;
+    };
+    ColClass none;
+    none.iI = none.iM = none.iD = none.mI = none.mM = none.mX = none.mD = none.dI = none.dM = none.dD = none.erw = NINF;
+    none.pad = 0.0;
+    const int none_class = class_of(none);
+    const double noe[4] = {NINF, NINF, NINF, NINF};
+    const int none_emis = eclass_of(noe);
+    out.info.resize(NC + 2);
+    out.state.resize(NC + 2);
+    for (int cc = 0; cc < NC + 2; ++cc) {
+        ColInfo &I = out.info[cc];
+        ColState &Sx = out.state[cc];
+        if (cc == 0 || cc == NC + 1) {
+            I.v0b = NINF; I.tclass = (uint16_t)none_class; I.emM = I.emI = (uint16_t)none_emis; I.flags = 0;
+            Sx.sI = Sx.sM = Sx.sB = Sx.sX = -1;
+            continue;
+        }
+        const int c = cc - 1;
+        I.v0b = out.v0[backbone[c] - P];
+        I.tclass = (uint16_t)class_of(percol[c]);
+        I.emM = (uint16_t)(colM[c] >= 0 ? eclass_of(&H.emis[(size_t)colM[c] * 4]) : none_emis);
+        I.emI = (uint16_t)(colI[c] >= 0 ? eclass_of(&H.emis[(size_t)colI[c] * 4]) : none_emis);
+        I.flags = flags[c];
+        Sx = st[c];
+    }
+    if (out.classes.size() > 60000 || out.emis.size() / 4 > 60000) return fail("class table overflow");
+    out.n_cols = NC;
+    out.n_sinks = n_sinks;
+    if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");
+    out.valid = true;
+    return true;
+}

@@ -67,6 +67,7 @@ struct advntr_hmm {
     std::vector<uint16_t> sclass;
     bool has_class = false;
     ColProgramHost colprog;       // empty when the model is not a recognised read matcher
+    int32_t col_lds_bytes = 0;
     void *d_blob = nullptr;
     size_t blob_bytes = 0;
     DevModel dev{};
@@ -185,6 +186,7 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
     std::vector<uint8_t> colblob;
     if (H->colprog.valid) {
         colblob = H->colprog.serialize();
+        H->col_lds_bytes = ((const ColProgram *)colblob.data())->lds_bytes;
         o_col = B.add(colblob);
     }
     H->blob_bytes = B.bytes.size();
@@ -237,10 +239,14 @@ struct advntr_batch {
     std::vector<advntr_hmm *> models;
     int32_t n_reads = 0;
     uint32_t flags = 0;
-    bool use_columns = false;
     int n_max = 0, m_max = 0;
-    int grid = 0;
-    size_t lds_bytes = 0;
+    // generic-kernel launch (reads without a column program, empty reads, reads longer than COL_MAX_READ)
+    int n_gen = 0, grid_gen = 0, m_max_gen = 0;
+    size_t lds_gen = 0;
+    int64_t bp_stride_gen = 0;
+    // anti-diagonal kernel launch
+    int n_col = 0;
+    ColumnLaunch col{};
     int64_t device_bytes = 0;
     std::vector<int64_t> path_off;      // internal capacities (n + m + 2 per read)
     hipStream_t stream = nullptr;
@@ -248,16 +254,14 @@ struct advntr_batch {
     DevModel *d_models = nullptr;
     uint8_t *d_bases = nullptr;
     int64_t *d_read_off = nullptr;
-    int32_t *d_read_model = nullptr, *d_order = nullptr;
+    int32_t *d_read_model = nullptr, *d_order = nullptr;   // d_order: [column reads | generic reads]
     double *d_logp = nullptr;
     int32_t *d_summary = nullptr, *d_path = nullptr, *d_path_len = nullptr;
     int64_t *d_path_off = nullptr;
-    uint8_t *d_bp = nullptr;
-    int32_t *d_pathbuf = nullptr;
-    int32_t *d_counter = nullptr;
-    int64_t bp_stride = 0;
+    uint8_t *d_bp_gen = nullptr;
+    int32_t *d_pathbuf_gen = nullptr, *d_pathbuf_col = nullptr;
+    int32_t *d_counter = nullptr;       // [0]: generic dequeue head, [4..7]: tile heads per chunk count
     int32_t path_cap = 0;
-    ColumnLaunch col{};                 // anti-diagonal kernel launch state
     std::vector<void *> allocs;
 
     template <class T> int dmalloc(T **p, size_t count)
@@ -302,14 +306,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (bases[i] > 3)   // the reference raises ValueError("Symbol ... not defined") (hmm.pyx:72,79)
             return fail(ADVNTR_ERR_SYMBOL, "batch: base code %d at offset %lld is not one of A,C,G,T", (int)bases[i],
                         (long long)i);
-    bool all_cols = true;
-    int bpw_max = 1;
-    for (auto *H : B->models) {
-        B->m_max = std::max(B->m_max, H->m);
-        bpw_max = std::max(bpw_max, H->bp_width);
-        all_cols = all_cols && H->colprog.valid;
-    }
-    B->use_columns = all_cols && !(flags & ADVNTR_FLAG_FORCE_GENERIC);
+    for (auto *H : B->models) B->m_max = std::max(B->m_max, H->m);
 
     HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&B->ev0));
@@ -328,17 +325,34 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     if (n_reads) HIP_TRY(hipMemcpy(B->d_read_model, read_model, (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_logp, (size_t)n_reads))) return rc;
     if ((rc = B->dmalloc(&B->d_summary, (size_t)n_reads * ADVNTR_SUMMARY_INTS))) return rc;
-    if ((rc = B->dmalloc(&B->d_counter, 4))) return rc;
+    if ((rc = B->dmalloc(&B->d_counter, 8))) return rc;
 
-    // processing order: heaviest (n+1)*E first, reads of one model adjacent (dynamic dequeue in-kernel)
-    std::vector<int32_t> order(n_reads);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    // split: reads the anti-diagonal kernel can take vs. the generic kernel
+    std::vector<int32_t> col_reads, gen_reads;
+    for (int r = 0; r < n_reads; ++r) {
+        const int64_t n = read_off[r + 1] - read_off[r];
+        const advntr_hmm *H = B->models[read_model[r]];
+        if (!(flags & ADVNTR_FLAG_FORCE_GENERIC) && H->colprog.valid && n >= 1 && n <= COL_MAX_READ) col_reads.push_back(r);
+        else gen_reads.push_back(r);
+    }
+    // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
+    auto kof = [&](int r) { return (int)((read_off[r + 1] - read_off[r] + 63) / 64); };
+    std::stable_sort(col_reads.begin(), col_reads.end(), [&](int a, int b) {
+        if (kof(a) != kof(b)) return kof(a) < kof(b);
+        if (read_model[a] != read_model[b]) return read_model[a] < read_model[b];
+        return (read_off[a + 1] - read_off[a]) > (read_off[b + 1] - read_off[b]);
+    });
+    // generic reads: heaviest (n+1)*E first (dynamic dequeue in-kernel)
+    std::stable_sort(gen_reads.begin(), gen_reads.end(), [&](int a, int b) {
         const int64_t wa = (read_off[a + 1] - read_off[a] + 1) * (int64_t)B->models[read_model[a]]->n_edges;
         const int64_t wb = (read_off[b + 1] - read_off[b] + 1) * (int64_t)B->models[read_model[b]]->n_edges;
         if (wa != wb) return wa > wb;
         return read_model[a] < read_model[b];
     });
+    B->n_col = (int)col_reads.size();
+    B->n_gen = (int)gen_reads.size();
+    std::vector<int32_t> order(col_reads);
+    order.insert(order.end(), gen_reads.begin(), gen_reads.end());
     if ((rc = B->dmalloc(&B->d_order, (size_t)n_reads))) return rc;
     if (n_reads) HIP_TRY(hipMemcpy(B->d_order, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
 
@@ -354,23 +368,66 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
 
     const int cus = device_cus();
     B->path_cap = B->n_max + B->m_max + 2;
-    if (B->use_columns) {
-        if ((rc = column_launch_prepare(B->col, B->models, B->n_max, cus, n_reads))) return fail(rc, "column launch: %s", g_err.c_str());
-        B->grid = B->col.grid;
-        if ((rc = B->dmalloc(&B->d_bp, (size_t)B->grid * B->col.bp_stride))) return rc;
-        B->bp_stride = B->col.bp_stride;
-        if ((rc = B->dmalloc(&B->d_pathbuf, (size_t)B->grid * B->col.waves_per_block * B->path_cap))) return rc;
-    } else {
-        B->lds_bytes = (size_t)B->m_max * 16;
-        int per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(B->lds_bytes, 1));
+
+    if (B->n_col) {
+        ColumnLaunch &C = B->col;
+        int n_max_col = 0;
+        for (int i = 0; i < B->n_col;) {
+            const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
+            int j = i;
+            while (j < B->n_col && j - i < COL_TILE_READS && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
+            C.tiles[K - 1].push_back(ColTile{mod, i, j - i, 0});
+            i = j;
+        }
+        for (int r : col_reads) {
+            const advntr_hmm *H = B->models[read_model[r]];
+            C.nc_max = std::max(C.nc_max, H->colprog.n_cols);
+            C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes);
+            n_max_col = std::max<int>(n_max_col, (int)(read_off[r + 1] - read_off[r]));
+        }
+        const int kmax = (n_max_col + 63) / 64;
+        int per_cu = (int)std::min<size_t>(4, (150 * 1024) / (C.lds_bytes + 16));
         per_cu = std::max(per_cu, 1);
-        B->grid = std::max(1, std::min(n_reads, cus * per_cu));
-        B->bp_stride = (((int64_t)(B->n_max + 1) * B->m_max * bpw_max) + 255) & ~int64_t(255);
-        if ((rc = B->dmalloc(&B->d_bp, (size_t)B->grid * B->bp_stride))) return rc;
-        if ((rc = B->dmalloc(&B->d_pathbuf, (size_t)B->grid * B->path_cap))) return rc;
-        if (B->lds_bytes > 64 * 1024)
+        size_t n_tiles = 0;
+        for (int k = 0; k < 4; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
+        C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
+        C.bp_stride = (((int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
+        C.rown_stride = 3 * (int64_t)C.nc_max + COL_MAX_TAIL;
+        C.aux_stride = COL_MAX_TAIL + COL_MAX_SINKS * (COL_MAX_READ + 1);
+        const size_t waves = (size_t)C.grid * COL_WAVES;
+        if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
+        if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
+        if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
+        if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
+        for (int k = 0; k < 4; ++k) {
+            if (C.tiles[k].empty()) continue;
+            if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
+            HIP_TRY(hipMemcpy(C.d_tiles[k], C.tiles[k].data(), C.tiles[k].size() * sizeof(ColTile), hipMemcpyHostToDevice));
+        }
+        C.d_tile_counters = B->d_counter + 4;
+    }
+    if (B->n_gen) {
+        int bpw_max = 1;
+        for (int r : gen_reads) {
+            const advntr_hmm *H = B->models[read_model[r]];
+            B->m_max_gen = std::max(B->m_max_gen, H->m);
+            bpw_max = std::max(bpw_max, H->bp_width);
+        }
+        int n_max_gen = 0;
+        for (int r : gen_reads) n_max_gen = std::max<int>(n_max_gen, (int)(read_off[r + 1] - read_off[r]));
+        B->lds_gen = (size_t)B->m_max_gen * 16;
+        int per_cu = (int)std::min<size_t>(16, (160 * 1024) / std::max<size_t>(B->lds_gen, 1));
+        per_cu = std::max(per_cu, 1);
+        B->grid_gen = std::max(1, std::min(B->n_gen, cus * per_cu));
+        B->bp_stride_gen = (((int64_t)(n_max_gen + 1) * B->m_max_gen * bpw_max) + 255) & ~int64_t(255);
+        if ((rc = B->dmalloc(&B->d_bp_gen, (size_t)B->grid_gen * B->bp_stride_gen))) return rc;
+        if ((rc = B->dmalloc(&B->d_pathbuf_gen, (size_t)B->grid_gen * B->path_cap))) return rc;
+        if (B->lds_gen > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void *)viterbi_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)B->lds_bytes));
+                                        (int)B->lds_gen));
+            HIP_TRY(hipFuncSetAttribute((const void *)forward_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)B->lds_gen));
+        }
     }
     return ADVNTR_OK;
 }
@@ -413,11 +470,22 @@ static BatchArgs make_args(advntr_batch *B)
 {
     BatchArgs a{};
     a.models = B->d_models; a.bases = B->d_bases; a.read_off = B->d_read_off; a.read_model = B->d_read_model;
-    a.n_reads = B->n_reads; a.out_logp = B->d_logp;
+    a.out_logp = B->d_logp;
     a.out_summary = (B->flags & ADVNTR_FLAG_NO_SUMMARY) ? nullptr : B->d_summary;
     a.out_path = B->d_path; a.out_path_off = B->d_path_off; a.out_path_len = B->d_path_len;
-    a.bp_scratch = B->d_bp; a.bp_stride = B->bp_stride; a.path_scratch = B->d_pathbuf; a.path_cap = B->path_cap;
-    a.m_max = B->m_max; a.order = B->d_order; a.counter = B->d_counter;
+    a.path_cap = B->path_cap;
+    return a;
+}
+
+static BatchArgs generic_args(advntr_batch *B)
+{
+    BatchArgs a = make_args(B);
+    a.n_reads = B->n_gen;
+    a.order = B->d_order + B->n_col;
+    a.counter = B->d_counter;
+    a.bp_scratch = B->d_bp_gen; a.bp_stride = B->bp_stride_gen;
+    a.path_scratch = B->d_pathbuf_gen;
+    a.m_max = B->m_max_gen;
     return a;
 }
 
@@ -425,13 +493,20 @@ extern "C" int advntr_batch_run(advntr_batch *B)
 {
     if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_run: null batch");
     if (B->n_reads == 0) return ADVNTR_OK;
-    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 16, B->stream));
-    BatchArgs a = make_args(B);
-    if (B->use_columns) {
-        int rc = column_launch(B->col, a, B->flags, B->stream);
-        if (rc) return fail(rc, "column kernel launch failed: %s", g_err.c_str());
-    } else {
-        hipLaunchKernelGGL(viterbi_generic_kernel, dim3(B->grid), dim3(ADV_WAVE), B->lds_bytes, B->stream, a, B->flags);
+    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 8 * sizeof(int32_t), B->stream));
+    if (B->n_col) {
+        BatchArgs a = make_args(B);
+        a.n_reads = B->n_col;
+        a.order = B->d_order;
+        a.path_scratch = B->d_pathbuf_col;
+        column_launch_k<1>(B->col, a, B->flags, B->stream);
+        column_launch_k<2>(B->col, a, B->flags, B->stream);
+        column_launch_k<3>(B->col, a, B->flags, B->stream);
+        column_launch_k<4>(B->col, a, B->flags, B->stream);
+    }
+    if (B->n_gen) {
+        BatchArgs a = generic_args(B);
+        hipLaunchKernelGGL(viterbi_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a, B->flags);
     }
     HIP_TRY(hipGetLastError());
     return ADVNTR_OK;
@@ -524,9 +599,9 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                          (flags | ADVNTR_FLAG_FORCE_GENERIC | ADVNTR_FLAG_NO_SUMMARY) & ~ADVNTR_FLAG_PATH);
     if (rc == ADVNTR_OK && n_reads) {
         rc = [&]() -> int {
-            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 16, B->stream));
-            BatchArgs a = make_args(B);
-            hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid), dim3(ADV_WAVE), B->lds_bytes, B->stream, a);
+            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 8 * sizeof(int32_t), B->stream));
+            BatchArgs a = generic_args(B);
+            hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a);
             HIP_TRY(hipGetLastError());
             return ADVNTR_OK;
         }();

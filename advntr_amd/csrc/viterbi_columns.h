@@ -1,8 +1,359 @@
-// viterbi_columns.h -- placeholder until the anti-diagonal kernel lands.
+// viterbi_columns.h -- anti-diagonal Viterbi kernel for models with a column program.
+//
+// One read per wavefront, lane <-> read position (row t = 64*chunk + lane + 1), up to 4 chunks of 64 rows
+// held entirely in VGPRs.  At step s every lane advances to column c = s - t of its row, so the 64 lanes
+// of a chunk sit on one anti-diagonal of the trellis and all three data dependencies of the profile-HMM
+// stencil are either the lane's own registers (same row, previous column) or the neighbouring lane's
+// values of the previous step (previous row), fetched with a wavefront shift (DPP wave_shr:1).  There
+// is no same-row serial chain left: the delete chain that serialises a row-major sweep runs ALONG the
+// step axis here.  Model parameters are staged once per workgroup in LDS as small class tables
+// (column_program.h); per step a lane reads its column's 16-B info word, the 96-B transition class and
+// two emission log-probs.  The arithmetic is the reference's, operation for operation:
+// (v + t) + e in fp64, candidates compared in the reference's in-edge order with strict '>'
+// (/root/reference/pomegranate/hmm.pyx:2026-2083), so scores and back-pointers are bit-identical.
+//
+// Back-pointers: one byte per (row, column) cell = three 2-bit pointers (I, M, b slots), written in
+// diagonal-major order so that a chunk stores 64 consecutive bytes per step.  The last row's values are
+// also written to a small per-wave buffer from which the "tail" states (prefix_end_prefix, model end:
+// fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  Lane 0 then walks
+// the pointers back and the wave summarises the path (path_summary.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <vector>
+#include "column_program.h"
 #include "viterbi_generic.h"
-struct ColumnLaunch { int grid = 0; int64_t bp_stride = 0; int waves_per_block = 1; };
-static inline int column_launch_prepare(ColumnLaunch &, const std::vector<advntr_hmm *> &, int, int, int) { return -5; }
-static inline int column_launch(ColumnLaunch &, const BatchArgs &, uint32_t, hipStream_t) { return -5; }
+
+#define COL_WAVES 4                 // wavefronts per workgroup (all on one model at a time)
+#define COL_MAX_TAIL 16
+#define COL_TILE_READS 16
+
+struct ColTile {
+    int32_t model, first, count, pad;   // reads order[first .. first+count)
+};
+
+struct ColArgs {
+    BatchArgs a;
+    const ColTile *tiles;
+    int32_t n_tiles;
+    int32_t *tile_counter;
+    double *rown;            // per wave: rown_stride doubles  (3*NC row-n values + COL_MAX_TAIL tail values)
+    int64_t rown_stride;
+    int32_t *aux;            // per wave: aux_stride ints (tail winners + sink back-pointers)
+    int64_t aux_stride;
+    uint8_t *bp;             // per wave: bp_stride bytes
+    int64_t bp_stride;
+    int32_t lds_tables;      // bytes of LDS reserved for the tables
+};
+
+__device__ __forceinline__ int dpp_wave_shr1(int old, int src)
+{
+    // lane i <- src[i-1]; lane 0 keeps `old` (bound_ctrl = 0)
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ double shift_up1(double v, double inject)
+{
+    const int lo = dpp_wave_shr1(__double2loint(inject), __double2loint(v));
+    const int hi = dpp_wave_shr1(__double2hiint(inject), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double bcast63(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+struct LdsTables {
+    const ColClass *classes;
+    const double *emis;
+    const ColInfo *info;
+    const ColState *state;
+};
+
+template <int K>
+__device__ __forceinline__ void col_sweep(const LdsTables &L, const int NC, const uint8_t *__restrict__ seq, const int n,
+                                          uint8_t *__restrict__ bp, double *__restrict__ rown,
+                                          int32_t *__restrict__ sinkbp, const int lane)
+{
+    constexpr int TPAD = 64 * K;
+    double I[K], M[K], B[K], pI[K], pM[K], pB[K], er[K];
+    int erwin[K], x[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        I[k] = M[k] = B[k] = pI[k] = pM[k] = pB[k] = er[k] = -INFINITY;
+        erwin[k] = 0;
+        const int t = 64 * k + lane + 1;
+        x[k] = (t <= n) ? (int)seq[t - 1] : 0;
+    }
+    const int s_end = n + NC - 1;
+    for (int s = 1; s <= s_end; ++s) {
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
+            const int t = 64 * k + lane + 1;
+            const int c = s - t;
+            const int cc = min(max(c + 1, 0), NC + 1);
+            const ColInfo inf = L.info[cc];
+            const ColClass *T = L.classes + inf.tclass;
+            // previous row, same column: the neighbouring lane's values of the previous step
+            double nI, nM, nB;
+            if (k == 0) {
+                nI = shift_up1(I[0], -INFINITY);
+                nM = shift_up1(M[0], -INFINITY);
+                nB = shift_up1(B[0], inf.v0b);          // row 0 is read independent (host precomputed)
+            } else {
+                nI = shift_up1(I[k], bcast63(I[k - 1]));
+                nM = shift_up1(M[k], bcast63(M[k - 1]));
+                nB = shift_up1(B[k], bcast63(B[k - 1]));
+            }
+            const double eI = L.emis[inf.emI * 4 + x[k]];
+            const double eM = L.emis[inf.emM * 4 + x[k]];
+            // I_c(t) <- [I_c, M_c, b_c](t-1)
+            double vI = (nI + T->iI) + eI;
+            int pi = 0;
+            {
+                const double c1 = (nM + T->iM) + eI, c2 = (nB + T->iD) + eI;
+                if (c1 > vI) { vI = c1; pi = 1; }
+                if (c2 > vI) { vI = c2; pi = 2; }
+            }
+            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1)
+            double vM = (pI[k] + T->mI) + eM;
+            int pm = 0;
+            {
+                const double c1 = (pM[k] + T->mM) + eM;
+                const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
+                const double c3 = (pB[k] + T->mD) + eM;
+                if (c1 > vM) { vM = c1; pm = 1; }
+                if (c2 > vM) { vM = c2; pm = 2; }
+                if (c3 > vM) { vM = c3; pm = 3; }
+            }
+            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
+            double vB = I[k] + T->dI;
+            int pb = 0;
+            {
+                const double c1 = M[k] + T->dM, c2 = B[k] + T->dD;
+                if (c1 > vB) { vB = c1; pb = 1; }
+                if (c2 > vB) { vB = c2; pb = 2; }
+            }
+            const unsigned fl = inf.flags;
+            if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
+                if (fl & COL_FLAG_SINK) {
+                    vB = er[k];
+                    pb = 3;
+                    sinkbp[(fl >> 4) * (COL_MAX_READ + 1) + t] = erwin[k];
+                    er[k] = -INFINITY;
+                }
+                if (fl & COL_FLAG_FEED) {
+                    const double cand = vB + T->erw;
+                    if (cand > er[k]) { er[k] = cand; erwin[k] = c; }
+                }
+            }
+            pI[k] = nI; pM[k] = nM; pB[k] = nB;
+            I[k] = vI; M[k] = vM; B[k] = vB;
+            bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+            if (t == n && c >= 0 && c < NC) {
+                rown[c * 3 + 0] = vI;
+                rown[c * 3 + 1] = vM;
+                rown[c * 3 + 2] = vB;
+            }
+        }
+    }
+}
+
+// Tail states at the last row: first maximum over the reference-order in-edge list, wave-parallel.
+__device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, double *__restrict__ rown,
+                                           int32_t *__restrict__ tailwin, const int NC, const int lane)
+{
+    const uint8_t *base = (const uint8_t *)cp;
+    const int32_t *tptr = (const int32_t *)(base + cp->off_tail_ptr);
+    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
+    double *tailv = rown + 3 * NC;
+    double result = -INFINITY;
+    for (int i = 0; i < cp->n_tail; ++i) {
+        double best = -INFINITY;
+        int rank = 0x7fffffff;
+        for (int e = tptr[i] + lane; e < tptr[i + 1]; e += 64) {
+            const TailEdge ed = edges[e];
+            const double v = ed.loc >= 0 ? rown[(ed.loc >> 2) * 3 + (ed.loc & 3)] : tailv[-ed.loc - 1];
+            const double cand = v + ed.logp;
+            if (cand > best) { best = cand; rank = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64);
+            const int orank = __shfl_xor(rank, o, 64);
+            if (ov > best || (ov == best && orank < rank)) { best = ov; rank = orank; }
+        }
+        if (lane == 0) { tailv[i] = best; tailwin[i] = rank; }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        if (i == cp->end_tail) result = best;
+    }
+    return result;
+}
+
+template <int K>
+__device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
+                                             const int start_state, const int P, const uint8_t *__restrict__ bp,
+                                             const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                             int32_t *__restrict__ rev, const int cap)
+{
+    constexpr int TPAD = 64 * K;
+    const uint8_t *base = (const uint8_t *)cp;
+    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
+    const int32_t *tstate = (const int32_t *)(base + cp->off_tail_state);
+    const int32_t *pred0 = (const int32_t *)(base + cp->off_pred0);
+    int len = 0;
+    int ti = cp->end_tail, t = n, c = 0, slot = 0;
+    // tail states (all in row n)
+    for (;;) {
+        if (len >= cap - 2) return -2;
+        rev[len++] = tstate[ti];
+        const TailEdge ed = edges[tailwin[ti]];
+        if (ed.loc < 0) { ti = -ed.loc - 1; continue; }
+        c = ed.loc >> 2;
+        slot = ed.loc & 3;
+        break;
+    }
+    int s0 = -1;           // row-0 silent state to continue from
+    while (t >= 1) {
+        if (len >= cap - 2) return -2;
+        const ColState cs = L.state[c + 1];
+        rev[len++] = slot == 0 ? cs.sI : slot == 1 ? cs.sM : cs.sB;
+        const int byte = bp[(int64_t)(t + c - 1) * TPAD + (t - 1)];
+        if (slot == 0) {
+            slot = byte & 3; t -= 1;                       // (t-1, c, I/M/b)
+        } else if (slot == 1) {
+            const int p = (byte >> 2) & 3;
+            t -= 1;
+            if (p == 2) { s0 = cs.sX; break; }             // entry edge from a row-0-only state
+            c -= 1;
+            slot = p == 3 ? 2 : p;
+        } else {
+            const int p = (byte >> 4) & 3;
+            if (p == 3) c = sinkbp[(L.info[c + 1].flags >> 4) * (COL_MAX_READ + 1) + t];   // fan-in winner
+            else { c -= 1; slot = p; }
+        }
+    }
+    if (s0 < 0) s0 = L.state[c + 1].sB;                    // arrived in row 0 on the backbone
+    while (s0 != start_state) {
+        if (len >= cap - 2 || s0 < P) return -2;
+        rev[len++] = s0;
+        s0 = pred0[s0 - P];
+    }
+    rev[len++] = start_state;
+    return len;
+}
+
+template <int K>
+__global__ void __launch_bounds__(COL_WAVES * 64) viterbi_columns_kernel(ColArgs g, uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
+    int32_t *tile_slot = (int32_t *)lds;                    // first 16 B: dequeued tile index
+    uint8_t *tables = lds + 16;
+    uint8_t *bp = g.bp + gw * g.bp_stride;
+    double *rown = g.rown + gw * g.rown_stride;
+    int32_t *aux = g.aux + gw * g.aux_stride;
+    int32_t *tailwin = aux, *sinkbp = aux + COL_MAX_TAIL;
+    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
+    int cur_model = -1;
+    LdsTables L{};
+    const ColProgram *cp = nullptr;
+    DevModel M{};
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
+        __syncthreads();
+        const int ti = *tile_slot;
+        if (ti >= g.n_tiles) break;
+        const ColTile tile = g.tiles[ti];
+        if (tile.model != cur_model) {                      // (re)stage the model's class tables in LDS
+            cur_model = tile.model;
+            M = g.a.models[cur_model];
+            cp = M.cols;
+            __syncthreads();
+            const uint4 *src = (const uint4 *)((const uint8_t *)cp + cp->off_class);
+            uint4 *dst = (uint4 *)tables;
+            for (int i = tid; i < cp->lds_bytes / 16; i += COL_WAVES * 64) dst[i] = src[i];
+            L.classes = (const ColClass *)tables;
+            L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
+            L.info = (const ColInfo *)(tables + (cp->off_info - cp->off_class));
+            L.state = (const ColState *)(tables + (cp->off_state - cp->off_class));
+            __syncthreads();
+        }
+        const int NC = cp->n_cols;
+        for (int j = wave; j < tile.count; j += COL_WAVES) {
+            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
+            const uint8_t *seq = g.a.bases + g.a.read_off[r];
+            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
+            col_sweep<K>(L, NC, seq, n, bp, rown, sinkbp, lane);
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            const double logp = col_tail(cp, rown, tailwin, NC, lane);
+            if (lane == 0) g.a.out_logp[r] = logp;
+            int len = 0;
+            if (logp != -INFINITY) {
+                if (lane == 0)
+                    len = col_traceback<K>(cp, L, n, M.start, M.P, bp, tailwin, sinkbp, rev, g.a.path_cap);
+                len = __shfl(len, 0, 64);
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            if (g.a.out_summary && !(flags & 4u)) {
+                int32_t *out = g.a.out_summary + (int64_t)r * 8;
+                if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);
+                else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
+            }
+            if (g.a.out_path && (flags & 1u)) {
+                const int64_t o0 = g.a.out_path_off[r];
+                const int cap = (int)(g.a.out_path_off[r + 1] - o0);
+                int olen = len;
+                if (len > cap) olen = -2;
+                if (olen > 0)
+                    for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
+                if (lane == 0) g.a.out_path_len[r] = olen;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the launch
+// ------------------------------------------------------------------------------------------------
+struct ColumnLaunch {
+    int grid = 0;
+    int waves_per_block = COL_WAVES;
+    int nc_max = 0;
+    size_t lds_bytes = 0;
+    int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
+    std::vector<ColTile> tiles[4];          // per chunk count K = 1..4
+    ColTile *d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_tile_counters = nullptr;     // 4 counters
+    double *d_rown = nullptr;
+    int32_t *d_aux = nullptr;
+    uint8_t *d_bp = nullptr;
+};
+
+template <int K>
+static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+{
+    if (cl.tiles[K - 1].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[K - 1];
+    g.n_tiles = (int32_t)cl.tiles[K - 1].size();
+    g.tile_counter = cl.d_tile_counters + (K - 1);
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
+    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    hipLaunchKernelGGL(viterbi_columns_kernel<K>, dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+}
