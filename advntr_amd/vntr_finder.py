@@ -1,0 +1,136 @@
+"""Batch driver for the callers of the scoring path -- host-side mirror of the pieces of
+/root/reference/advntr/vntr_finder.py that decide WHICH (read, strand, locus) calls are scored and what
+is kept:
+
+  get_copies_for_hmm                       vntr_finder.py:98-99
+  get_min_score_to_select_a_read           vntr_finder.py:174-177
+  recruit_read                             vntr_finder.py:179-190
+  process_unmapped_read (fwd + revcomp)    vntr_finder.py:235-254   -> score_reads(..., compute_reverse=True)
+  find_genotype_based_on_observed_repeats  vntr_finder.py:485-532   (+ get_conditional_likelihood :473-483)
+
+The reference loops over reads in Python and calls hmm.viterbi twice per unmapped read; here the whole
+locus batch (both strands) goes to the GPU in one advntr_viterbi_batch call and the keep/discard rule is
+applied to the 8-int summaries the kernel returns (no Viterbi path leaves the device).
+"""
+import numpy as np
+
+from . import _lib
+from .hmm_utils import flanking_rate_from_counts
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def reverse_complement(seq):
+    return seq.encode("ascii").translate(_COMP)[::-1].decode("ascii")
+
+
+def get_copies_for_hmm(read_length, pattern_length):
+    return int(round(float(read_length) / pattern_length + 0.5))
+
+
+def get_min_score_to_select_a_read(scaled_score, read_length):
+    if scaled_score is None or scaled_score == 0:
+        return None
+    return scaled_score * read_length
+
+
+def recruit_read(logp, summary, min_score_to_count_read, read_length):
+    """summary = the 8 int32 of ADVNTR_SUM_* for this read."""
+    rate = flanking_rate_from_counts(int(summary[_lib.SUM_LEFT_MATCH]), int(summary[_lib.SUM_LEFT_BP]),
+                                     int(summary[_lib.SUM_RIGHT_MATCH]), int(summary[_lib.SUM_RIGHT_BP]))
+    if rate < 0.90:
+        return False
+    if min_score_to_count_read is not None and logp > min_score_to_count_read:
+        return True
+    matches = int(summary[_lib.SUM_MATCHES])
+    if min_score_to_count_read is None and matches >= 0.9 * read_length and logp > -read_length:
+        return True
+    return False
+
+
+class ScoredRead(object):
+    __slots__ = ("sequence", "logp", "summary", "reversed", "recruited")
+
+    def __init__(self, sequence, logp, summary, reversed_, recruited):
+        self.sequence, self.logp, self.summary, self.reversed, self.recruited = \
+            sequence, logp, summary, reversed_, recruited
+
+    @property
+    def repeats(self):
+        return int(self.summary[_lib.SUM_RU])
+
+    @property
+    def repeat_bp(self):
+        return int(self.summary[_lib.SUM_REPEAT_BP])
+
+
+def score_reads(model, sequences, scaled_score=None, compute_reverse=True):
+    """Score reads against one locus model; with compute_reverse both strands are scored and the reverse
+    strand replaces the forward one iff logp < rev_logp (vntr_finder.py:242-246).  Reads holding 'N' are
+    skipped before scoring, as the reference does (vntr_finder.py:237).  Returns a list of ScoredRead
+    (None for skipped reads)."""
+    keep = [i for i, s in enumerate(sequences) if s.count('N') <= 0]
+    fwd = [sequences[i].upper() for i in keep]
+    batch = list(fwd)
+    if compute_reverse:
+        batch += [reverse_complement(s) for s in fwd]
+    out = [None] * len(sequences)
+    if not batch:
+        return out
+    logp, summ, _ = model.viterbi_batch(batch, want_paths=False, want_summary=True)
+    nf = len(fwd)
+    for j, i in enumerate(keep):
+        seq, lp, sm, rev = fwd[j], float(logp[j]), summ[j], False
+        if compute_reverse and lp < float(logp[nf + j]):
+            seq, lp, sm, rev = batch[nf + j], float(logp[nf + j]), summ[nf + j], True
+        ok = False
+        if sm[_lib.SUM_PATH_LEN] > 2:
+            ok = recruit_read(lp, sm, get_min_score_to_select_a_read(scaled_score, len(seq)), len(seq))
+        out[i] = ScoredRead(seq, lp, sm, rev, ok)
+    return out
+
+
+def get_conditional_likelihood(ck, ci, cj, r, r_e):
+    if ck == ci == cj:
+        return 1 - r
+    if cj == 0:
+        return 0.5 * (1 - r)
+    if ck == ci:
+        return 0.5 * ((1 - r) + r_e ** abs(ck - cj))
+    if ck == cj:
+        return 0.5 * ((1 - r) + r_e ** abs(ck - ci))
+    return 0.5 * (r_e ** abs(ck - ci) + r_e ** abs(ck - cj))
+
+
+def find_genotype_based_on_observed_repeats(observed_copy_numbers, is_haploid=False):
+    """Maximum-likelihood diploid (or haploid) RU genotype from the per-read RU counts; returns
+    (genotype tuple | None, max_prob) like vntr_finder.py:532."""
+    counts = {}
+    for cn in observed_copy_numbers:
+        counts[cn] = counts.get(cn, 0) + 1
+    if len(counts) < 2:
+        priors = 0.5
+        counts[0] = 1
+    else:
+        priors = 1.0 / (len(counts) * (len(counts) - 1) / 2)
+    ranked = sorted(counts.items(), key=lambda kv: kv[1], reverse=True)
+    r = 0.03
+    r_e = r / (2 + r)
+    terms = {}
+    for ck, occ in ranked:
+        if ck == 0:
+            continue
+        for i, (ci, _) in enumerate(ranked):
+            for j in range(i, len(ranked)):
+                if is_haploid and i != j:
+                    continue
+                cj = ranked[j][0]
+                terms.setdefault((ci, cj), []).append(get_conditional_likelihood(ck, ci, cj, r, r_e) ** occ)
+    posteriors = {key: np.prod(np.array(vals)) * priors for key, vals in terms.items()}
+    total = sum(posteriors.values())
+    max_prob, result = 1e-20, None
+    for key, value in posteriors.items():
+        if value / total > max_prob:
+            max_prob = value / total
+            result = key
+    return result, max_prob

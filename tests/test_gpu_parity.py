@@ -190,3 +190,32 @@ def test_bad_symbol_is_rejected_before_launch():
     loc = workloads.make_locus(np.random.default_rng(1), 8, 5, 2)
     with pytest.raises(ValueError):
         loc.model.viterbi_batch(["ACGT", "ACNT"])
+
+
+def test_score_reads_strand_choice_and_recruit():
+    """The caller mirror (process_unmapped_read: forward + reverse complement, keep the better strand,
+    then recruit_read) on the GPU vs the same rule applied to oracle scores."""
+    from advntr_amd import hmm_utils, settings, vntr_finder
+    from oracle import oracle as Or
+    g = load_golden("s300_f30_l12_c3")
+    settings.MAX_ERROR_RATE = g["error_rate"]
+    m = hmm_utils.get_read_matcher_model(g["left"], g["right"], g["aligned_repeats"], g["copies"])
+    O = Or.OracleModel.from_golden(g)
+    names = g["model"]["state_names"]
+    reads = [r["seq"] for r in g["reads"] if len(r["seq"]) > 3][:30] + ["ACGTNNACGT"]
+    out = vntr_finder.score_reads(m, reads, scaled_score=g["scaled_score"], compute_reverse=True)
+    assert out[-1] is None                                  # reads with N are skipped (vntr_finder.py:237)
+    n_rev = 0
+    for s, sr in zip(reads[:-1], out[:-1]):
+        lp_f, path_f = O.viterbi(s)
+        rc = vntr_finder.reverse_complement(s)
+        lp_r, path_r = O.viterbi(rc)
+        use_rev = lp_f < lp_r
+        n_rev += use_rev
+        seq, lp, path = (rc, lp_r, path_r) if use_rev else (s, lp_f, path_f)
+        assert sr.reversed == use_rev and sr.logp == lp and sr.sequence == seq
+        inner = [names[i] for i in path][1:-1]
+        assert sr.repeats == Or.number_of_repeats(inner)
+        ms = g["scaled_score"] * len(seq)
+        assert sr.recruited == Or.recruit_read(lp, inner, ms, seq, g["left"], g["right"])
+    assert n_rev > 0

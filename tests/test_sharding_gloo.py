@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: locus->rank partition and the final gather of result records, world_size 2, gloo.
+(The HIP kernels cannot run here; ranks fill their records with a deterministic function of the global read
+id, which is exactly what rank 0 must receive back, ordered by global read id.)"""
+import os
+import socket
+
+import numpy as np
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from advntr_amd import sharding
+    rng = np.random.default_rng(5)                      # same on every rank
+    n_loci = 11
+    reads_per_locus = rng.integers(1, 9, n_loci)
+    edges = rng.integers(100, 5000, n_loci)
+    work = [sharding.locus_work(np.full(reads_per_locus[i], 150), edges[i]) for i in range(n_loci)]
+    parts = sharding.partition_loci(work, world)
+    first = np.concatenate([[0], np.cumsum(reads_per_locus)])
+    ids = np.concatenate([np.arange(first[i], first[i + 1]) for i in parts[rank]]) if len(parts[rank]) else np.zeros(0, np.int64)
+    logp = -ids.astype(np.float64) * 1.5 - 0.25
+    summ = np.stack([ids * 8 + k for k in range(8)], axis=1).astype(np.int32) if len(ids) else np.zeros((0, 8), np.int32)
+    res = sharding.gather_records(ids, logp, summ, dst=0)
+    if rank == 0:
+        all_ids, all_lp, all_sm = res
+        total = int(reads_per_locus.sum())
+        ok = (np.array_equal(all_ids, np.arange(total)) and np.array_equal(all_lp, -np.arange(total) * 1.5 - 0.25)
+              and np.array_equal(all_sm[:, 3], np.arange(total) * 8 + 3))
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partition_is_balanced_and_complete():
+    from advntr_amd import sharding
+    rng = np.random.default_rng(1)
+    work = rng.integers(1, 1000, 200)
+    for world in (1, 2, 4, 8):
+        parts = sharding.partition_loci(work, world)
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(200))
+        loads = [int(work[p].sum()) for p in parts]
+        assert max(loads) - min(loads) <= int(work.max())
+
+
+def test_gather_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -1,0 +1,39 @@
+"""Host logic of the caller mirror (advntr_amd/vntr_finder.py) against values captured from the reference."""
+import numpy as np
+
+from conftest import READ_MATCHER_GOLDENS, load_golden
+from advntr_amd import _lib, vntr_finder
+from oracle import oracle as O
+
+
+def test_genotype_cases_match_reference():
+    g = load_golden("genotype_cases")
+    for c in g["cases"]:
+        geno, prob = vntr_finder.find_genotype_based_on_observed_repeats(list(c["observed"]), c["haploid"])
+        assert (None if geno is None else list(geno)) == c["genotype"], c
+        assert prob == c["max_prob"], c
+    for c in g["copies_for_hmm"]:
+        assert vntr_finder.get_copies_for_hmm(c["read_length"], c["pattern_len"]) == c["copies"]
+
+
+def test_recruit_read_from_summaries_matches_reference_verdicts():
+    """recruit_read fed with the 8-int summary layout the kernel produces (built here from the golden path)."""
+    for name in READ_MATCHER_GOLDENS:
+        g = load_golden(name)
+        names = g["model"]["state_names"]
+        for r in g["reads"]:
+            if "recruit" not in r:
+                continue
+            inner = [names[i] for i in r["path"]][1:-1]
+            lm, lb, rm, rb = O.flanking_counts(inner, r["seq"], g["left"], g["right"])
+            s = np.zeros(8, np.int32)
+            s[_lib.SUM_RU], s[_lib.SUM_MATCHES], s[_lib.SUM_REPEAT_BP] = r["ru"], r["matches"], r["repeat_bp"]
+            s[_lib.SUM_LEFT_BP], s[_lib.SUM_RIGHT_BP], s[_lib.SUM_LEFT_MATCH], s[_lib.SUM_RIGHT_MATCH] = lb, rb, lm, rm
+            s[_lib.SUM_PATH_LEN] = len(r["path"])
+            ms = vntr_finder.get_min_score_to_select_a_read(g["scaled_score"], len(r["seq"]))
+            assert vntr_finder.recruit_read(r["logp"], s, ms, len(r["seq"])) == r["recruit"], (name, r["seq"])
+            assert vntr_finder.recruit_read(r["logp"], s, None, len(r["seq"])) == r["recruit_noscore"]
+
+
+def test_reverse_complement():
+    assert vntr_finder.reverse_complement("AACGT") == "ACGTT"
