@@ -382,7 +382,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         for (int r : col_reads) {
             const advntr_hmm *H = B->models[read_model[r]];
             C.nc_max = std::max(C.nc_max, H->colprog.n_cols);
-            C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes);
+            C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes + (size_t)(H->colprog.n_cols + 128 * 4) * sizeof(ColInfo));
             n_max_col = std::max<int>(n_max_col, (int)(read_off[r + 1] - read_off[r]));
         }
         const int kmax = (n_max_col + 63) / 64;

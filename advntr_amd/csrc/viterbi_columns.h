@@ -68,95 +68,148 @@ __device__ __forceinline__ double bcast63(double v)
 struct LdsTables {
     const ColClass *classes;
     const double *emis;
-    const ColInfo *info;
+    const ColInfo *info;      // what the sweep indexes: padded copy (c + 64K) or the original (c + 1)
+    const ColInfo *info0;     // original table, index c + 1
     const ColState *state;
 };
 
 template <int K>
-__device__ __forceinline__ void col_sweep(const LdsTables &L, const int NC, const uint8_t *__restrict__ seq, const int n,
-                                          uint8_t *__restrict__ bp, double *__restrict__ rown,
-                                          int32_t *__restrict__ sinkbp, const int lane)
-{
-    constexpr int TPAD = 64 * K;
+struct ColRegs {
     double I[K], M[K], B[K], pI[K], pM[K], pB[K], er[K];
     int erwin[K], x[K];
+};
+
+__device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
+{
+    // lane i <- v[i-1]; lane 0 <- prev_chunk[63]   (wave_ror:1 feeds the `old` operand of wave_shr:1)
+    const int rlo = __builtin_amdgcn_update_dpp(0, __double2loint(prev_chunk), 0x13C, 0xf, 0xf, false);
+    const int rhi = __builtin_amdgcn_update_dpp(0, __double2hiint(prev_chunk), 0x13C, 0xf, 0xf, false);
+    const int lo = dpp_wave_shr1(rlo, __double2loint(v));
+    const int hi = dpp_wave_shr1(rhi, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// One trellis cell per lane of chunk k.  CHECKED = clamp the column index (used when chunk ranges cannot
+// be split into branch-free phases); otherwise the info table is padded with 64*K dummy columns per side.
+template <int K, bool CHECKED>
+__device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTables &L, const int NC, const int n,
+                                         const int s, const int lane, uint8_t *__restrict__ bp,
+                                         double *__restrict__ rown, int32_t *__restrict__ sinkbp)
+{
+    constexpr int TPAD = 64 * K;
+    const int t = 64 * k + lane + 1;
+    const int c = s - t;
+    const int cc = CHECKED ? min(max(c + 1, 0), NC + 1) : c + TPAD;
+    const ColInfo inf = L.info[cc];
+    const ColClass *T = L.classes + inf.tclass;
+    // previous row, same column: the neighbouring lane's values of the previous step
+    double nI, nM, nB;
+    if (k == 0) {
+        nI = shift_up1(R.I[0], -INFINITY);
+        nM = shift_up1(R.M[0], -INFINITY);
+        nB = shift_up1(R.B[0], inf.v0b);          // row 0 is read independent (host precomputed)
+    } else {
+        nI = shift_up1_from(R.I[k], R.I[k - 1]);
+        nM = shift_up1_from(R.M[k], R.M[k - 1]);
+        nB = shift_up1_from(R.B[k], R.B[k - 1]);
+    }
+    const double eI = L.emis[inf.emI * 4 + R.x[k]];
+    const double eM = L.emis[inf.emM * 4 + R.x[k]];
+    // I_c(t) <- [I_c, M_c, b_c](t-1)
+    double vI = (nI + T->iI) + eI;
+    int pi = 0;
+    {
+        const double c1 = (nM + T->iM) + eI, c2 = (nB + T->iD) + eI;
+        if (c1 > vI) { vI = c1; pi = 1; }
+        if (c2 > vI) { vI = c2; pi = 2; }
+    }
+    // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); the entry edge X only exists for row 1 (chunk 0, lane 0)
+    double vM = (R.pI[k] + T->mI) + eM;
+    int pm = 0;
+    {
+        const double c1 = (R.pM[k] + T->mM) + eM;
+        if (c1 > vM) { vM = c1; pm = 1; }
+        if (k == 0) {
+            const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
+            if (c2 > vM) { vM = c2; pm = 2; }
+        }
+        const double c3 = (R.pB[k] + T->mD) + eM;
+        if (c3 > vM) { vM = c3; pm = 3; }
+    }
+    // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
+    double vB = R.I[k] + T->dI;
+    int pb = 0;
+    {
+        const double c1 = R.M[k] + T->dM, c2 = R.B[k] + T->dD;
+        if (c1 > vB) { vB = c1; pb = 1; }
+        if (c2 > vB) { vB = c2; pb = 2; }
+    }
+    const unsigned fl = inf.flags;
+    if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
+        if (fl & COL_FLAG_SINK) {
+            vB = R.er[k];
+            pb = 3;
+            sinkbp[(fl >> 4) * (COL_MAX_READ + 1) + t] = R.erwin[k];
+            R.er[k] = -INFINITY;
+        }
+        if (fl & COL_FLAG_FEED) {
+            const double cand = vB + T->erw;
+            if (cand > R.er[k]) { R.er[k] = cand; R.erwin[k] = c; }
+        }
+    }
+    R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
+    R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
+    bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+    if (k == K - 1) {                                                // row n lives in the last chunk
+        if (t == n && c >= 0 && c < NC) {
+            rown[c * 3 + 0] = vI;
+            rown[c * 3 + 1] = vM;
+            rown[c * 3 + 2] = vB;
+        }
+    }
+}
+
+template <int K, int KLO, int KHI>
+__device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const int NC,
+                                          const int n, const int lane, uint8_t *__restrict__ bp,
+                                          double *__restrict__ rown, int32_t *__restrict__ sinkbp)
+{
+    for (int s = s0; s <= s1; ++s) {
+#pragma unroll
+        for (int k = KHI; k >= KLO; --k) col_cell<K, false>(R, k, L, NC, n, s, lane, bp, rown, sinkbp);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded, const int NC,
+                                          const uint8_t *__restrict__ seq, const int n, uint8_t *__restrict__ bp,
+                                          double *__restrict__ rown, int32_t *__restrict__ sinkbp, const int lane)
+{
+    ColRegs<K> R;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        I[k] = M[k] = B[k] = pI[k] = pM[k] = pB[k] = er[k] = -INFINITY;
-        erwin[k] = 0;
+        R.I[k] = R.M[k] = R.B[k] = R.pI[k] = R.pM[k] = R.pB[k] = R.er[k] = -INFINITY;
+        R.erwin[k] = 0;
         const int t = 64 * k + lane + 1;
-        x[k] = (t <= n) ? (int)seq[t - 1] : 0;
+        R.x[k] = (t <= n) ? (int)seq[t - 1] : 0;
     }
     const int s_end = n + NC - 1;
-    for (int s = 1; s <= s_end; ++s) {
+    if (padded && NC + 63 >= 64 * (K - 1) + 1) {
+        // chunk k is busy for steps [64k+1, 64k+64+NC-1]: ramp-up phases, a branch-free steady state with all
+        // chunks in one basic block (independent dependency chains interleave), ramp-down phases
+        if (K >= 2) col_phase<K, 0, 0>(R, 1, 64, L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0)>(R, 65, 128, L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0)>(R, 129, 192, L, NC, n, lane, bp, rown, sinkbp);
+        col_phase<K, 0, K - 1>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1>(R, NC + 64, min(s_end, NC + 127), L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1>(R, NC + 128, min(s_end, NC + 191), L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1>(R, NC + 192, min(s_end, NC + 255), L, NC, n, lane, bp, rown, sinkbp);
+    } else {
+        for (int s = 1; s <= s_end; ++s) {
 #pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
-            const int t = 64 * k + lane + 1;
-            const int c = s - t;
-            const int cc = min(max(c + 1, 0), NC + 1);
-            const ColInfo inf = L.info[cc];
-            const ColClass *T = L.classes + inf.tclass;
-            // previous row, same column: the neighbouring lane's values of the previous step
-            double nI, nM, nB;
-            if (k == 0) {
-                nI = shift_up1(I[0], -INFINITY);
-                nM = shift_up1(M[0], -INFINITY);
-                nB = shift_up1(B[0], inf.v0b);          // row 0 is read independent (host precomputed)
-            } else {
-                nI = shift_up1(I[k], bcast63(I[k - 1]));
-                nM = shift_up1(M[k], bcast63(M[k - 1]));
-                nB = shift_up1(B[k], bcast63(B[k - 1]));
-            }
-            const double eI = L.emis[inf.emI * 4 + x[k]];
-            const double eM = L.emis[inf.emM * 4 + x[k]];
-            // I_c(t) <- [I_c, M_c, b_c](t-1)
-            double vI = (nI + T->iI) + eI;
-            int pi = 0;
-            {
-                const double c1 = (nM + T->iM) + eI, c2 = (nB + T->iD) + eI;
-                if (c1 > vI) { vI = c1; pi = 1; }
-                if (c2 > vI) { vI = c2; pi = 2; }
-            }
-            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1)
-            double vM = (pI[k] + T->mI) + eM;
-            int pm = 0;
-            {
-                const double c1 = (pM[k] + T->mM) + eM;
-                const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
-                const double c3 = (pB[k] + T->mD) + eM;
-                if (c1 > vM) { vM = c1; pm = 1; }
-                if (c2 > vM) { vM = c2; pm = 2; }
-                if (c3 > vM) { vM = c3; pm = 3; }
-            }
-            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
-            double vB = I[k] + T->dI;
-            int pb = 0;
-            {
-                const double c1 = M[k] + T->dM, c2 = B[k] + T->dD;
-                if (c1 > vB) { vB = c1; pb = 1; }
-                if (c2 > vB) { vB = c2; pb = 2; }
-            }
-            const unsigned fl = inf.flags;
-            if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
-                if (fl & COL_FLAG_SINK) {
-                    vB = er[k];
-                    pb = 3;
-                    sinkbp[(fl >> 4) * (COL_MAX_READ + 1) + t] = erwin[k];
-                    er[k] = -INFINITY;
-                }
-                if (fl & COL_FLAG_FEED) {
-                    const double cand = vB + T->erw;
-                    if (cand > er[k]) { er[k] = cand; erwin[k] = c; }
-                }
-            }
-            pI[k] = nI; pM[k] = nM; pB[k] = nB;
-            I[k] = vI; M[k] = vM; B[k] = vB;
-            bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
-            if (t == n && c >= 0 && c < NC) {
-                rown[c * 3 + 0] = vI;
-                rown[c * 3 + 1] = vM;
-                rown[c * 3 + 2] = vB;
+            for (int k = K - 1; k >= 0; --k) {
+                if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
+                col_cell<K, true>(R, k, L, NC, n, s, lane, bp, rown, sinkbp);
             }
         }
     }
@@ -233,7 +286,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             slot = p == 3 ? 2 : p;
         } else {
             const int p = (byte >> 4) & 3;
-            if (p == 3) c = sinkbp[(L.info[c + 1].flags >> 4) * (COL_MAX_READ + 1) + t];   // fan-in winner
+            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * (COL_MAX_READ + 1) + t];   // fan-in winner
             else { c -= 1; slot = p; }
         }
     }
@@ -262,6 +315,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64) viterbi_columns_kernel(ColArgs
     int32_t *tailwin = aux, *sinkbp = aux + COL_MAX_TAIL;
     int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
     int cur_model = -1;
+    bool padded = false;
     LdsTables L{};
     const ColProgram *cp = nullptr;
     DevModel M{};
@@ -284,7 +338,22 @@ __global__ void __launch_bounds__(COL_WAVES * 64) viterbi_columns_kernel(ColArgs
             L.classes = (const ColClass *)tables;
             L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
             L.info = (const ColInfo *)(tables + (cp->off_info - cp->off_class));
+            L.info0 = L.info;
             L.state = (const ColState *)(tables + (cp->off_state - cp->off_class));
+            // padded copy of the info table: 64*K dummy columns on either side, so a lane can index it with
+            // c + 64*K without clamping (c runs from 1-64K to 64K+NC-2)
+            padded = (size_t)cp->lds_bytes + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)g.lds_tables;
+            if (padded) {
+                __syncthreads();
+                uint4 *pinfo = (uint4 *)(tables + cp->lds_bytes);
+                const uint4 *sinfo = (const uint4 *)L.info0;
+                const int ncol = cp->n_cols;
+                for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
+                    const int c = i - 64 * K;
+                    pinfo[i] = sinfo[(c >= 0 && c < ncol) ? c + 1 : 0];
+                }
+                L.info = (const ColInfo *)pinfo;
+            }
             __syncthreads();
         }
         const int NC = cp->n_cols;
@@ -292,7 +361,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64) viterbi_columns_kernel(ColArgs
             const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
             const uint8_t *seq = g.a.bases + g.a.read_off[r];
             const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
-            col_sweep<K>(L, NC, seq, n, bp, rown, sinkbp, lane);
+            col_sweep<K>(L, padded, NC, seq, n, bp, rown, sinkbp, lane);
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
             const double logp = col_tail(cp, rown, tailwin, NC, lane);
