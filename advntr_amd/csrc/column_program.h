@@ -32,11 +32,13 @@
 #define COL_MAX_SINKS 4
 #define COL_MAX_READ 256      // rows handled in registers: 4 chunks of 64 lanes
 
-struct ColClass {             // 12 doubles = 96 B, read as 6 x ds_read_b128
+struct ColClass {             // 11 doubles = 88 B: an odd multiple of 8 B, so records that differ by less than 32
+                              // classes never share an LDS bank at the same field (64 banks x 4 B for ds_read_b64)
     double iI, iM, iD, mI;    // I_c <- I_c, M_c, b_c (prev row);   M_c <- I_{c-1}
     double mM, mX, mD, dI;    // M_c <- M_{c-1}, X (row 0 only, value incl. source), b_{c-1};  b_c <- I_{c-1}
-    double dM, dD, erw, pad;  // b_c <- M_{c-1}, b_{c-1};  feed weight
+    double dM, dD, erw;       // b_c <- M_{c-1}, b_{c-1};  feed weight
 };
+#define COL_EMIS_STRIDE 5     // doubles per emission class (4 used): 40-B records, bank-conflict free below 32 classes
 
 struct ColInfo {              // 16 B per column (with one dummy column at either end)
     double v0b;               // row-0 value of b_c (read independent)
@@ -65,7 +67,7 @@ struct ColProgramHost {
     std::string why;                       // why there is no program (diagnostics)
     int32_t n_cols = 0, n_sinks = 0, m = 0, P = 0;
     std::vector<ColClass> classes;
-    std::vector<double> emis;              // n_eclass * 4
+    std::vector<double> emis;              // n_eclass * COL_EMIS_STRIDE
     std::vector<ColInfo> info;             // n_cols + 2
     std::vector<ColState> state;           // n_cols + 2
     std::vector<int32_t> pred0;            // per silent state: row-0 predecessor state or -1
@@ -90,7 +92,7 @@ struct ColProgramHost {
             return (int32_t)off;
         };
         ColProgram h{};
-        h.n_cols = n_cols; h.n_tclass = (int32_t)classes.size(); h.n_eclass = (int32_t)(emis.size() / 4);
+        h.n_cols = n_cols; h.n_tclass = (int32_t)classes.size(); h.n_eclass = (int32_t)(emis.size() / COL_EMIS_STRIDE);
         h.n_tail = (int32_t)tail_state.size(); h.n_sinks = n_sinks; h.end_tail = end_tail; h.m = m; h.P = P;
         // the four LDS-resident tables are contiguous and in this order
         h.off_class = add(classes.data(), classes.size() * sizeof(ColClass));
@@ -111,7 +113,7 @@ struct ColProgramHost {
 namespace colprog_detail {
 
 struct Key96 {
-    uint64_t w[12];
+    uint64_t w[11];
     bool operator<(const Key96 &o) const { return memcmp(w, o.w, sizeof w) < 0; }
 };
 struct Key32 {
@@ -250,7 +252,6 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     for (int c = 0; c < NC; ++c) {
         ColClass &T = percol[c];
         T.iI = T.iM = T.iD = T.mI = T.mM = T.mX = T.mD = T.dI = T.dM = T.dD = T.erw = NINF;
-        T.pad = 0.0;
         st[c].sI = colI[c]; st[c].sM = colM[c]; st[c].sB = backbone[c]; st[c].sX = -1;
     }
     for (int c = 0; c < NC; ++c) {
@@ -396,14 +397,14 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         memcpy(key.w, e4, sizeof key.w);
         auto it = emap.find(key);
         if (it != emap.end()) return it->second;
-        const int id = (int)(out.emis.size() / 4);
+        const int id = (int)(out.emis.size() / COL_EMIS_STRIDE);
         out.emis.insert(out.emis.end(), e4, e4 + 4);
+        out.emis.push_back(0.0);
         emap[key] = id;
         return id;
     };
     ColClass none;
     none.iI = none.iM = none.iD = none.mI = none.mM = none.mX = none.mD = none.dI = none.dM = none.dD = none.erw = NINF;
-    none.pad = 0.0;
     const int none_class = class_of(none);
     const double noe[4] = {NINF, NINF, NINF, NINF};
     const int none_emis = eclass_of(noe);
@@ -425,7 +426,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         I.flags = flags[c];
         Sx = st[c];
     }
-    if (out.classes.size() > 60000 || out.emis.size() / 4 > 60000) return fail("class table overflow");
+    if (out.classes.size() > 60000 || out.emis.size() / COL_EMIS_STRIDE > 60000) return fail("class table overflow");
     out.n_cols = NC;
     out.n_sinks = n_sinks;
     if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");

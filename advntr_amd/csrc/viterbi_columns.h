@@ -113,8 +113,8 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         nM = shift_up1_from(R.M[k], R.M[k - 1]);
         nB = shift_up1_from(R.B[k], R.B[k - 1]);
     }
-    const double eI = L.emis[inf.emI * 4 + R.x[k]];
-    const double eM = L.emis[inf.emM * 4 + R.x[k]];
+    const double eI = L.emis[inf.emI * COL_EMIS_STRIDE + R.x[k]];
+    const double eM = L.emis[inf.emM * COL_EMIS_STRIDE + R.x[k]];
     // I_c(t) <- [I_c, M_c, b_c](t-1)
     double vI = (nI + T->iI) + eI;
     int pi = 0;

@@ -44,7 +44,7 @@ extern "C" const char *colprog_why(void *p) { return ((Handle *)p)->prog.why.c_s
 extern "C" void colprog_stats(void *p, int *out)
 {
     const ColProgramHost &g = ((Handle *)p)->prog;
-    out[0] = g.n_cols; out[1] = (int)g.classes.size(); out[2] = (int)(g.emis.size() / 4);
+    out[0] = g.n_cols; out[1] = (int)g.classes.size(); out[2] = (int)(g.emis.size() / COL_EMIS_STRIDE);
     out[3] = (int)g.tail_state.size(); out[4] = g.n_sinks; out[5] = (int)g.serialize().size();
     out[6] = ((const ColProgram *)g.serialize().data())->lds_bytes;
 }
@@ -69,7 +69,7 @@ extern "C" double colprog_viterbi(void *p, const uint8_t *seq, int n, int32_t *p
         for (int c = 0; c < NC; ++c) {
             const ColInfo &inf = g.info[c + 1];
             const ColClass &T = g.classes[inf.tclass];
-            const double eI = g.emis[inf.emI * 4 + x], eM = g.emis[inf.emM * 4 + x];
+            const double eI = g.emis[inf.emI * COL_EMIS_STRIDE + x], eM = g.emis[inf.emM * COL_EMIS_STRIDE + x];
             const double nI = pI[c], nM = pM[c], nB = pB[c];
             const double qI = c ? pI[c - 1] : NINF, qM = c ? pM[c - 1] : NINF, qB = c ? pB[c - 1] : NINF;
             const double oI = c ? cI[c - 1] : NINF, oM = c ? cM[c - 1] : NINF, oB = c ? cB[c - 1] : NINF;
