@@ -27,6 +27,9 @@
 #define COL_WAVES 4                 // wavefronts per workgroup (all on one model at a time)
 #define COL_MAX_TAIL 16
 #define COL_TILE_READS 16
+#ifndef COL_MIN_WAVES_PER_SIMD
+#define COL_MIN_WAVES_PER_SIMD 4
+#endif
 
 struct ColTile {
     int32_t model, first, count, pad;   // reads order[first .. first+count)
@@ -301,7 +304,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
 }
 
 template <int K>
-__global__ void __launch_bounds__(COL_WAVES * 64) viterbi_columns_kernel(ColArgs g, uint32_t flags)
+__global__ void __launch_bounds__(COL_WAVES * 64, COL_MIN_WAVES_PER_SIMD) viterbi_columns_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
