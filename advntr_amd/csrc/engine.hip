@@ -332,11 +332,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     for (int r = 0; r < n_reads; ++r) {
         const int64_t n = read_off[r + 1] - read_off[r];
         const advntr_hmm *H = B->models[read_model[r]];
-        if (!(flags & ADVNTR_FLAG_FORCE_GENERIC) && H->colprog.valid && n >= 1 && n <= COL_MAX_READ) col_reads.push_back(r);
+        if (!(flags & ADVNTR_FLAG_FORCE_GENERIC) && H->colprog.valid && n >= 1 && n <= COL_MAX_LONG_READ) col_reads.push_back(r);
         else gen_reads.push_back(r);
     }
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
-    auto kof = [&](int r) { return (int)((read_off[r + 1] - read_off[r] + 63) / 64); };
+    // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read
+    auto kof = [&](int r) { return (int)std::min<int64_t>(5, (read_off[r + 1] - read_off[r] + 63) / 64); };
     std::stable_sort(col_reads.begin(), col_reads.end(), [&](int a, int b) {
         if (kof(a) != kof(b)) return kof(a) < kof(b);
         if (read_model[a] != read_model[b]) return read_model[a] < read_model[b];
@@ -385,26 +386,30 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes + (size_t)(H->colprog.n_cols + 128 * 4) * sizeof(ColInfo));
             n_max_col = std::max<int>(n_max_col, (int)(read_off[r + 1] - read_off[r]));
         }
-        const int kmax = (n_max_col + 63) / 64;
+        const int kmax = std::min(4, (n_max_col + 63) / 64);
+        const int row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + COL_MAX_READ - 1) / COL_MAX_READ : 1;
         int per_cu = (int)std::min<size_t>(4, (150 * 1024) / (C.lds_bytes + 16));
         per_cu = std::max(per_cu, 1);
         size_t n_tiles = 0;
-        for (int k = 0; k < 4; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
+        for (int k = 0; k < 5; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
-        C.bp_stride = (((int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
-        C.rown_stride = 3 * (int64_t)C.nc_max + COL_MAX_TAIL;
-        C.aux_stride = COL_MAX_TAIL + COL_MAX_SINKS * (COL_MAX_READ + 1);
+        C.bp_stride = ((row_tiles * (int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
+        // keep the back-pointer scratch of all resident waves under 48 GB (long reads: fewer resident waves)
+        while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > (int64_t)48 << 30) C.grid = (C.grid + 1) / 2;
+        C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
+        C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
+        C.aux_stride = COL_MAX_TAIL + (int64_t)COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
         if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 5; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
             HIP_TRY(hipMemcpy(C.d_tiles[k], C.tiles[k].data(), C.tiles[k].size() * sizeof(ColTile), hipMemcpyHostToDevice));
         }
-        C.d_tile_counters = B->d_counter + 4;
+        C.d_tile_counters = B->d_counter + 3;
     }
     if (B->n_gen) {
         int bpw_max = 1;
@@ -499,10 +504,11 @@ extern "C" int advntr_batch_run(advntr_batch *B)
         a.n_reads = B->n_col;
         a.order = B->d_order;
         a.path_scratch = B->d_pathbuf_col;
-        column_launch_k<1>(B->col, a, B->flags, B->stream);
-        column_launch_k<2>(B->col, a, B->flags, B->stream);
-        column_launch_k<3>(B->col, a, B->flags, B->stream);
-        column_launch_k<4>(B->col, a, B->flags, B->stream);
+        column_launch_k<1, false>(B->col, a, B->flags, B->stream);
+        column_launch_k<2, false>(B->col, a, B->flags, B->stream);
+        column_launch_k<3, false>(B->col, a, B->flags, B->stream);
+        column_launch_k<4, false>(B->col, a, B->flags, B->stream);
+        column_launch_k<4, true>(B->col, a, B->flags, B->stream);
     }
     if (B->n_gen) {
         BatchArgs a = generic_args(B);

@@ -47,6 +47,7 @@ struct ColArgs {
     uint8_t *bp;             // per wave: bp_stride bytes
     int64_t bp_stride;
     int32_t lds_tables;      // bytes of LDS reserved for the tables
+    int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
 };
 
 __device__ __forceinline__ int dpp_wave_shr1(int old, int src)
@@ -80,6 +81,22 @@ template <int K>
 struct ColRegs {
     double I[K], M[K], B[K], pI[K], pM[K], pB[K], er[K];
     int erwin[K], x[K];
+    // row-tiling only: values of the previous tile's last row for 64 columns (lane i <-> column cb+i), and
+    // the next 64 (prefetched)
+    double sI, sM, sB, tI, tM, tB;
+};
+
+// Per-tile sweep context.  A read longer than 64*K rows is processed in row tiles: the last row of a tile
+// ("seam", 3 fp64 per column in HBM) is the injected previous row of the next tile.
+struct TileCtx {
+    int NC;
+    int n_tile;                // rows in this tile (1 .. 64K)
+    int row0;                  // global row offset of the tile (0 for the first tile)
+    int sink_stride;           // ints per sink in sinkbp
+    uint8_t *bp;               // this tile's back-pointer slab
+    double *cap;               // where the tile's last row goes (next seam, or the row-n buffer)
+    const double *seam;        // previous tile's last row (nullptr for the first tile)
+    int32_t *sinkbp;
 };
 
 __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
@@ -94,23 +111,30 @@ __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
 
 // One trellis cell per lane of chunk k.  CHECKED = clamp the column index (used when chunk ranges cannot
 // be split into branch-free phases); otherwise the info table is padded with 64*K dummy columns per side.
-template <int K, bool CHECKED>
-__device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTables &L, const int NC, const int n,
-                                         const int s, const int lane, uint8_t *__restrict__ bp,
-                                         double *__restrict__ rown, int32_t *__restrict__ sinkbp)
+// FIRST = first row tile (row 0 comes from the host-precomputed v0b; entry edges X are live in row 1).
+template <int K, bool CHECKED, bool FIRST>
+__device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTables &L, const TileCtx &C, const int s,
+                                         const int lane, const double injI, const double injM, const double injB)
 {
     constexpr int TPAD = 64 * K;
+    const int NC = C.NC;
     const int t = 64 * k + lane + 1;
     const int c = s - t;
     const int cc = CHECKED ? min(max(c + 1, 0), NC + 1) : c + TPAD;
-    const ColInfo inf = L.info[cc];
+    const ColInfo inf = CHECKED ? L.info0[cc] : L.info[cc];
     const ColClass *T = L.classes + inf.tclass;
     // previous row, same column: the neighbouring lane's values of the previous step
     double nI, nM, nB;
     if (k == 0) {
-        nI = shift_up1(R.I[0], -INFINITY);
-        nM = shift_up1(R.M[0], -INFINITY);
-        nB = shift_up1(R.B[0], inf.v0b);          // row 0 is read independent (host precomputed)
+        if (FIRST) {
+            nI = shift_up1(R.I[0], -INFINITY);
+            nM = shift_up1(R.M[0], -INFINITY);
+            nB = shift_up1(R.B[0], inf.v0b);      // row 0 is read independent (host precomputed)
+        } else {
+            nI = shift_up1(R.I[0], injI);
+            nM = shift_up1(R.M[0], injM);
+            nB = shift_up1(R.B[0], injB);
+        }
     } else {
         nI = shift_up1_from(R.I[k], R.I[k - 1]);
         nM = shift_up1_from(R.M[k], R.M[k - 1]);
@@ -132,7 +156,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     {
         const double c1 = (R.pM[k] + T->mM) + eM;
         if (c1 > vM) { vM = c1; pm = 1; }
-        if (k == 0) {
+        if (FIRST && k == 0) {
             const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
             if (c2 > vM) { vM = c2; pm = 2; }
         }
@@ -152,7 +176,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         if (fl & COL_FLAG_SINK) {
             vB = R.er[k];
             pb = 3;
-            sinkbp[(fl >> 4) * (COL_MAX_READ + 1) + t] = R.erwin[k];
+            C.sinkbp[(fl >> 4) * C.sink_stride + C.row0 + t] = R.erwin[k];
             R.er[k] = -INFINITY;
         }
         if (fl & COL_FLAG_FEED) {
@@ -162,57 +186,86 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     }
     R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
     R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
-    bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
-    if (k == K - 1) {                                                // row n lives in the last chunk
-        if (t == n && c >= 0 && c < NC) {
-            rown[c * 3 + 0] = vI;
-            rown[c * 3 + 1] = vM;
-            rown[c * 3 + 2] = vB;
+    C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+    if (FIRST ? (k == K - 1) : true) {                               // single tile: row n lives in the last chunk
+        if (t == C.n_tile && c >= 0 && c < NC) {
+            C.cap[c * 3 + 0] = vI;
+            C.cap[c * 3 + 1] = vM;
+            C.cap[c * 3 + 2] = vB;
         }
     }
 }
 
-template <int K, int KLO, int KHI>
-__device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const int NC,
-                                          const int n, const int lane, uint8_t *__restrict__ bp,
-                                          double *__restrict__ rown, int32_t *__restrict__ sinkbp)
+// seam values for the column lane 0 works on at step s (row-tiled reads only): registers hold 64 columns,
+// the next 64 are prefetched one block ahead
+template <int K>
+__device__ __forceinline__ void seam_fetch(ColRegs<K> &R, const TileCtx &C, const int s, const int lane, double &injI,
+                                           double &injM, double &injB)
+{
+    const int j = (s - 1) & 63;
+    if (j == 0) {
+        R.sI = R.tI; R.sM = R.tM; R.sB = R.tB;
+        const int cn = min(s - 1 + 64 + lane, C.NC - 1);
+        R.tI = C.seam[cn * 3 + 0];
+        R.tM = C.seam[cn * 3 + 1];
+        R.tB = C.seam[cn * 3 + 2];
+    }
+    injI = readlane_f64(R.sI, j);
+    injM = readlane_f64(R.sM, j);
+    injB = readlane_f64(R.sB, j);
+}
+
+template <int K, int KLO, int KHI, bool FIRST>
+__device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const TileCtx &C,
+                                          const int lane)
 {
     for (int s = s0; s <= s1; ++s) {
+        double injI = 0, injM = 0, injB = 0;
+        if (!FIRST) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
-        for (int k = KHI; k >= KLO; --k) col_cell<K, false>(R, k, L, NC, n, s, lane, bp, rown, sinkbp);
+        for (int k = KHI; k >= KLO; --k) col_cell<K, false, FIRST>(R, k, L, C, s, lane, injI, injM, injB);
     }
 }
 
-template <int K>
-__device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded, const int NC,
-                                          const uint8_t *__restrict__ seq, const int n, uint8_t *__restrict__ bp,
-                                          double *__restrict__ rown, int32_t *__restrict__ sinkbp, const int lane)
+template <int K, bool FIRST>
+__device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded, const TileCtx &C,
+                                          const uint8_t *__restrict__ seq_tile, const int lane)
 {
+    const int NC = C.NC, n = C.n_tile;
     ColRegs<K> R;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         R.I[k] = R.M[k] = R.B[k] = R.pI[k] = R.pM[k] = R.pB[k] = R.er[k] = -INFINITY;
         R.erwin[k] = 0;
         const int t = 64 * k + lane + 1;
-        R.x[k] = (t <= n) ? (int)seq[t - 1] : 0;
+        R.x[k] = (t <= n) ? (int)seq_tile[t - 1] : 0;
+    }
+    R.sI = R.sM = R.sB = R.tI = R.tM = R.tB = -INFINITY;
+    if (!FIRST) {                                   // columns 0..63 of the seam; seam_fetch rotates at s = 1
+        const int cn = min(lane, NC - 1);
+        R.tI = C.seam[cn * 3 + 0];
+        R.tM = C.seam[cn * 3 + 1];
+        R.tB = C.seam[cn * 3 + 2];
     }
     const int s_end = n + NC - 1;
     if (padded && NC + 63 >= 64 * (K - 1) + 1) {
         // chunk k is busy for steps [64k+1, 64k+64+NC-1]: ramp-up phases, a branch-free steady state with all
         // chunks in one basic block (independent dependency chains interleave), ramp-down phases
-        if (K >= 2) col_phase<K, 0, 0>(R, 1, 64, L, NC, n, lane, bp, rown, sinkbp);
-        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0)>(R, 65, 128, L, NC, n, lane, bp, rown, sinkbp);
-        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0)>(R, 129, 192, L, NC, n, lane, bp, rown, sinkbp);
-        col_phase<K, 0, K - 1>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, NC, n, lane, bp, rown, sinkbp);
-        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1>(R, NC + 64, min(s_end, NC + 127), L, NC, n, lane, bp, rown, sinkbp);
-        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1>(R, NC + 128, min(s_end, NC + 191), L, NC, n, lane, bp, rown, sinkbp);
-        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1>(R, NC + 192, min(s_end, NC + 255), L, NC, n, lane, bp, rown, sinkbp);
+        if (K >= 2) col_phase<K, 0, 0, FIRST>(R, 1, min(s_end, 64), L, C, lane);
+        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0), FIRST>(R, 65, min(s_end, 128), L, C, lane);
+        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0), FIRST>(R, 129, min(s_end, 192), L, C, lane);
+        col_phase<K, 0, K - 1, FIRST>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, C, lane);
+        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1, FIRST>(R, NC + 64, min(s_end, NC + 127), L, C, lane);
+        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1, FIRST>(R, NC + 128, min(s_end, NC + 191), L, C, lane);
+        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1, FIRST>(R, NC + 192, min(s_end, NC + 255), L, C, lane);
     } else {
         for (int s = 1; s <= s_end; ++s) {
+            double injI = 0, injM = 0, injB = 0;
+            if (!FIRST) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
-                col_cell<K, true>(R, k, L, NC, n, s, lane, bp, rown, sinkbp);
+                col_cell<K, true, FIRST>(R, k, L, C, s, lane, injI, injM, injB);
             }
         }
     }
@@ -253,6 +306,7 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 template <int K>
 __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                              const int start_state, const int P, const uint8_t *__restrict__ bp,
+                                             const int64_t slab, const int sink_stride,
                                              const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
                                              int32_t *__restrict__ rev, const int cap)
 {
@@ -278,7 +332,8 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
         if (len >= cap - 2) return -2;
         const ColState cs = L.state[c + 1];
         rev[len++] = slot == 0 ? cs.sI : slot == 1 ? cs.sM : cs.sB;
-        const int byte = bp[(int64_t)(t + c - 1) * TPAD + (t - 1)];
+        const int tile = (t - 1) / TPAD, lt = t - tile * TPAD;           // row tile and row inside it
+        const int byte = bp[tile * slab + (int64_t)(lt + c - 1) * TPAD + (lt - 1)];
         if (slot == 0) {
             slot = byte & 3; t -= 1;                       // (t-1, c, I/M/b)
         } else if (slot == 1) {
@@ -289,7 +344,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             slot = p == 3 ? 2 : p;
         } else {
             const int p = (byte >> 4) & 3;
-            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * (COL_MAX_READ + 1) + t];   // fan-in winner
+            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + t];   // fan-in winner
             else { c -= 1; slot = p; }
         }
     }
@@ -303,10 +358,13 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
     return len;
 }
 
-template <int K>
-__global__ void __launch_bounds__(COL_WAVES * 64, COL_MIN_WAVES_PER_SIMD) viterbi_columns_kernel(ColArgs g, uint32_t flags)
+// LONG = reads longer than 64*K rows, processed in row tiles of 64*K rows (K = 4).
+template <int K, bool LONG>
+__global__ void __launch_bounds__(COL_WAVES * 64, (LONG ? 2 : (K >= 4 ? 3 : COL_MIN_WAVES_PER_SIMD)))
+viterbi_columns_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int TPAD = 64 * K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
@@ -360,19 +418,43 @@ __global__ void __launch_bounds__(COL_WAVES * 64, COL_MIN_WAVES_PER_SIMD) viterb
             __syncthreads();
         }
         const int NC = cp->n_cols;
+        const int64_t slab = (int64_t)(TPAD + NC) * TPAD;      // back-pointer bytes per row tile
         for (int j = wave; j < tile.count; j += COL_WAVES) {
             const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
             const uint8_t *seq = g.a.bases + g.a.read_off[r];
             const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
-            col_sweep<K>(L, padded, NC, seq, n, bp, rown, sinkbp, lane);
+            TileCtx C;
+            C.NC = NC; C.sink_stride = g.sink_stride; C.sinkbp = sinkbp;
+            double *final_row = rown;
+            if (!LONG) {
+                C.n_tile = n; C.row0 = 0; C.bp = bp; C.cap = rown; C.seam = nullptr;
+                col_sweep<K, true>(L, padded, C, seq, lane);
+            } else {
+                // seam ping-pong: tile i writes its last row to buffer (i+1)&1 and reads buffer i&1
+                double *buf[2] = {rown, rown + 3 * (int64_t)NC + COL_MAX_TAIL};
+                const int n_tiles = (n + TPAD - 1) / TPAD;
+                for (int i = 0; i < n_tiles; ++i) {
+                    C.row0 = i * TPAD;
+                    C.n_tile = min(TPAD, n - C.row0);
+                    C.bp = bp + i * slab;
+                    C.cap = buf[(i + 1) & 1];
+                    C.seam = buf[i & 1];
+                    if (i == 0) col_sweep<K, true>(L, padded, C, seq, lane);
+                    else col_sweep<K, false>(L, padded, C, seq + C.row0, lane);
+                    __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                }
+                final_row = buf[n_tiles & 1];
+            }
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
-            const double logp = col_tail(cp, rown, tailwin, NC, lane);
+            const double logp = col_tail(cp, final_row, tailwin, NC, lane);
             if (lane == 0) g.a.out_logp[r] = logp;
             int len = 0;
             if (logp != -INFINITY) {
                 if (lane == 0)
-                    len = col_traceback<K>(cp, L, n, M.start, M.P, bp, tailwin, sinkbp, rev, g.a.path_cap);
+                    len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev,
+                                           g.a.path_cap);
                 len = __shfl(len, 0, 64);
             }
             __threadfence_block();
@@ -403,29 +485,32 @@ struct ColumnLaunch {
     int grid = 0;
     int waves_per_block = COL_WAVES;
     int nc_max = 0;
+    int sink_stride = COL_MAX_READ + 1;
     size_t lds_bytes = 0;
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
-    std::vector<ColTile> tiles[4];          // per chunk count K = 1..4
-    ColTile *d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};
-    int32_t *d_tile_counters = nullptr;     // 4 counters
+    std::vector<ColTile> tiles[5];          // per chunk count K = 1..4, [4] = row-tiled long reads
+    ColTile *d_tiles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_tile_counters = nullptr;     // 5 counters
     double *d_rown = nullptr;
     int32_t *d_aux = nullptr;
     uint8_t *d_bp = nullptr;
 };
 
-template <int K>
+template <int K, bool LONG>
 static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
 {
-    if (cl.tiles[K - 1].empty()) return;
+    const int slot = LONG ? 4 : K - 1;
+    if (cl.tiles[slot].empty()) return;
     ColArgs g{};
     g.a = a;
-    g.tiles = cl.d_tiles[K - 1];
-    g.n_tiles = (int32_t)cl.tiles[K - 1].size();
-    g.tile_counter = cl.d_tile_counters + (K - 1);
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
     g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
+    g.sink_stride = cl.sink_stride;
     const int grid = std::min(cl.grid, g.n_tiles);
-    hipLaunchKernelGGL(viterbi_columns_kernel<K>, dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+    hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
 }

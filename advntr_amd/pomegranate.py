@@ -297,9 +297,8 @@ class HiddenMarkovModel(object):
     def dense_transition_matrix(self):
         m = len(self.states)
         t = np.zeros((m, m)) + NEGINF
-        for i in range(m):
-            for k in range(self._out_ptr[i], self._out_ptr[i + 1]):
-                t[i, self._out_dst[k]] = self._out_logp[k]
+        src = np.repeat(np.arange(m), np.diff(self._out_ptr))
+        t[src, self._out_dst] = self._out_logp
         return np.exp(t)
 
     @classmethod
@@ -314,12 +313,14 @@ class HiddenMarkovModel(object):
         for i, prob in enumerate(starts):
             if prob != 0:
                 model.add_transition(model.start, states[i], prob)
-        j = 0
-        for i in range(n):
-            row = transition_probabilities[i]
-            for j, prob in enumerate(row):
-                if prob != 0.:
-                    model.add_transition(states[i], states[j], prob)
+        # same edge insertion order as the reference's double loop (row-major over non-zero entries); after
+        # that loop the reference's inner variable j is left at the last column index
+        tp = np.asarray(transition_probabilities, dtype=np.float64)
+        rows, cols = np.nonzero(tp)
+        vals = tp[rows, cols]
+        for i, jj, prob in zip(rows.tolist(), cols.tolist(), vals.tolist()):
+            model.add_transition(states[i], states[jj], prob)
+        j = tp.shape[1] - 1 if tp.ndim == 2 and tp.shape[1] else 0
         if ends is not None:
             for i, prob in enumerate(ends):
                 if prob != 0:

@@ -67,3 +67,24 @@ def ref150(seed=20240601):
 def s300(seed=20240601):
     """flank 30, 12-bp pattern, copies 3 -> 315 states / 197 emitting / 1004 edges."""
     return make_locus(np.random.default_rng(seed), 30, 12, 3, 0.05)
+
+
+def make_c2(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40):
+    """Config C2/C3 of BASELINE.json at a chosen locus count: loci with pattern length U{6..100},
+    2-20 reference repeat units (equal length, <= 2 substitutions => gap-free alignment), flank = read length,
+    copies = round(read_len/len(pattern)+0.5) as adVNTR does (vntr_finder.py:98-99,131); per locus Poisson(80)
+    mapped-like reads (forward only) + Poisson(40) filtered-unmapped-like reads scored on both strands.
+    Returns (loci, reads, read_locus)."""
+    from .vntr_finder import get_copies_for_hmm, reverse_complement
+    rng = np.random.default_rng(seed)
+    loci, reads, which = [], [], []
+    for k in range(n_loci):
+        plen = int(rng.integers(6, 101))
+        loc = make_locus(rng, read_len, plen, get_copies_for_hmm(read_len, plen), 0.05, n_units=int(rng.integers(2, 21)))
+        loci.append(loc)
+        mapped = make_reads(rng, loc, int(rng.poisson(mapped_mean)), read_len, locus_fraction=0.9)
+        unmapped = make_reads(rng, loc, int(rng.poisson(unmapped_mean)), read_len, locus_fraction=0.5)
+        calls = mapped + unmapped + [reverse_complement(s) for s in unmapped]
+        reads += calls
+        which += [k] * len(calls)
+    return loci, reads, np.asarray(which, dtype=np.int32)

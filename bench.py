@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2"],
+                    help="c1 (default, the bench line): 1 REF150 locus x --reads; c2: --loci synthetic loci x ~160 calls")
+    ap.add_argument("--loci", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -75,15 +78,31 @@ def main():
     from advntr_amd import _lib, workloads
     _lib.check(_lib.load().advntr_set_device(local_rank))
 
-    locus = workloads.ref150()
-    a = locus.model.baked_arrays()
-    m, P, E = a["m"], a["silent_start"], len(a["in_src"])
     n = 150
-    reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, args.reads, n)
-    bases, off = _lib.encode_reads(reads)
-    dm = locus.model.device_model()
     flags = _lib.FLAG_FORCE_GENERIC if args.generic else 0
-    batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
+    if args.workload == "c2":
+        t_build = time.perf_counter()
+        loci, reads, which = workloads.make_c2(args.loci, seed=20240602 + rank)
+        t_build = time.perf_counter() - t_build
+        locus = loci[0]
+        bases, off = _lib.encode_reads(reads)
+        dms = [l.model.device_model() for l in loci]
+        args.reads = len(reads)
+        batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
+        dm = dms[0]
+        ms = np.array([d.m for d in dms])
+        m = int(round(float(np.mean(ms[which]))))
+        a = locus.model.baked_arrays()
+        P, E = a["silent_start"], int(np.mean([len(l.model.baked_arrays()["in_src"]) for l in loci]))
+        args.no_cpu = True
+    else:
+        locus = workloads.ref150()
+        a = locus.model.baked_arrays()
+        m, P, E = a["m"], a["silent_start"], len(a["in_src"])
+        reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, args.reads, n)
+        bases, off = _lib.encode_reads(reads)
+        dm = locus.model.device_model()
+        batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
     kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
 
     gathered = None
@@ -135,8 +154,10 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
-                                   "150-bp reads per GPU, seed 20240601",
+            "config": {"workload": ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
+                                    "150-bp reads per GPU, seed 20240601") if args.workload == "c1" else
+                                   ("C2-style: %d synthetic loci (pattern 6-100 bp, flank 150) x ~Poisson(80)+2*Poisson(40) "
+                                    "calls, seed 20240602; model build %.1f s on host" % (args.loci, t_build)),
                        "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
                        "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
                        "relaxations_per_s": value * (n + 1) * E},

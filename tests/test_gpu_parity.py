@@ -219,3 +219,31 @@ def test_score_reads_strand_choice_and_recruit():
         ms = g["scaled_score"] * len(seq)
         assert sr.recruited == Or.recruit_read(lp, inner, ms, seq, g["left"], g["right"])
     assert n_rev > 0
+
+
+def test_long_reads_row_tiled_vs_oracle():
+    """Reads longer than one 256-row tile go through the row-tiled column kernel (seam rows in HBM): PacBio-like
+    locus (error 0.3, flank 100), reads of 257..900 bases incl. exact tile multiples."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    from oracle import oracle as Or
+    rng = np.random.default_rng(31)
+    loc = workloads.make_locus(rng, 100, 30, 12, error_rate=0.3)
+    lens = [257, 300, 511, 512, 513, 640, 768, 900]
+    reads = [workloads.make_reads(rng, loc, 1, n, locus_fraction=1.0, sub_rate=0.08)[0] for n in lens]
+    reads += [workloads.rand_seq(rng, 700)]
+    m = loc.model
+    dm = m.device_model()
+    assert dm.has_column_program()
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), want_paths=True)
+    a = m.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    names = [s.name for s in m.states]
+    for i, r in enumerate(reads):
+        olp, opath = O.viterbi(r)
+        assert logp[i] == olp, (i, len(r))
+        assert paths[i] == opath, (i, len(r))
+        assert summ[i][_lib.SUM_RU] == Or.number_of_repeats([names[j] for j in opath][1:-1])
