@@ -66,12 +66,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    # under torch.distributed.run (RANK set) the RCCL path is exercised even with one rank, so the
+    # gather code is tested on a single-GPU box too
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("ADVNTR_BENCH_DIST", "1") == "1")
+    if use_dist:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
     entry.build()
@@ -106,7 +109,7 @@ def main():
     kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
 
     gathered = None
-    if world > 1:
+    if use_dist:
         p_logp, p_sum = batch.result_ptrs()
         t_logp = torch.as_tensor(_CudaArray(p_logp, (args.reads,), "<f8"), device="cuda")
         t_sum = torch.as_tensor(_CudaArray(p_sum, (args.reads, 8), "<i4"), device="cuda")
@@ -116,7 +119,7 @@ def main():
 
     def step():
         batch.run()
-        if world > 1:
+        if use_dist:
             batch.sync()
             dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0)
             dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0)
@@ -125,17 +128,17 @@ def main():
         step()
     batch.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     batch.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -143,6 +146,10 @@ def main():
     # kernel-only duration, HIP events on the engine's launch stream
     kernel_ms = batch.run_timed(max(1, min(args.steps, 3)))
     logp, summ = batch.fetch()
+    if use_dist and rank == 0:
+        # the gathered copy of rank 0's own records must equal what the engine holds
+        assert np.array_equal(gathered[0][0].cpu().numpy(), logp), "RCCL gather returned different log-probs"
+        assert np.array_equal(gathered[1][0].cpu().numpy(), summ), "RCCL gather returned different summaries"
 
     if rank == 0:
         total_reads = args.reads * world
@@ -176,7 +183,7 @@ def main():
             out["config"]["speedup_vs_cpu_1thread"] = value / cps
         print(json.dumps(out), flush=True)
     batch.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
