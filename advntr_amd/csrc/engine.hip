@@ -68,6 +68,7 @@ struct advntr_hmm {
     bool has_class = false;
     ColProgramHost colprog;       // empty when the model is not a recognised read matcher
     int32_t col_lds_bytes = 0;
+    bool generic_ok = true;
     void *d_blob = nullptr;
     size_t blob_bytes = 0;
     DevModel dev{};
@@ -114,12 +115,6 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
             return nullptr;
         }
     const int P = silent_start, S = m - P;
-    // 2 fp64 trellis rows must fit the 160 KiB LDS of one CU
-    if ((size_t)m * 16 > 160 * 1024) {
-        fail(ADVNTR_ERR_TOO_LARGE, "advntr_hmm_create: %d states need %zu B of LDS rows (> 160 KiB)", m,
-             (size_t)m * 16);
-        return nullptr;
-    }
     advntr_hmm *H = new advntr_hmm();
     H->m = m; H->P = P; H->start = start_index; H->end = end_index; H->n_edges = n_edges;
     H->in_ptr.assign(in_ptr, in_ptr + m + 1);
@@ -176,6 +171,15 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
 
     // column program for flank-repeats-flank read matchers (optional fast path)
     build_column_program(*H, H->colprog);
+    // the generic kernel keeps 2 fp64 trellis rows in the 160 KiB LDS of one CU; a bigger model is only
+    // usable through its column program
+    H->generic_ok = (size_t)m * 16 <= 160 * 1024;
+    if (!H->generic_ok && !H->colprog.valid) {
+        fail(ADVNTR_ERR_TOO_LARGE, "advntr_hmm_create: %d states need %zu B of LDS rows (> 160 KiB) and the model has "
+             "no column program (%s)", m, (size_t)m * 16, H->colprog.why.c_str());
+        delete H;
+        return nullptr;
+    }
 
     BlobBuilder B;
     const size_t o_eptr = B.add(e_ptr), o_esrc = B.add(e_src), o_elogp = B.add(e_logp), o_emis = B.add(H->emis);
@@ -333,7 +337,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         const int64_t n = read_off[r + 1] - read_off[r];
         const advntr_hmm *H = B->models[read_model[r]];
         if (!(flags & ADVNTR_FLAG_FORCE_GENERIC) && H->colprog.valid && n >= 1 && n <= COL_MAX_LONG_READ) col_reads.push_back(r);
-        else gen_reads.push_back(r);
+        else {
+            if (!H->generic_ok)
+                return fail(ADVNTR_ERR_TOO_LARGE, "read %d (%lld bases) needs the generic kernel but its model has %d states "
+                            "(> 10240, LDS rows)", r, (long long)n, H->m);
+            gen_reads.push_back(r);
+        }
     }
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
     // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read

@@ -247,3 +247,48 @@ def test_long_reads_row_tiled_vs_oracle():
         assert logp[i] == olp, (i, len(r))
         assert paths[i] == opath, (i, len(r))
         assert summ[i][_lib.SUM_RU] == Or.number_of_repeats([names[j] for j in opath][1:-1])
+
+
+def test_pacbio_c4_style_loci_vs_oracle():
+    """Config C4 of BASELINE.json at test scale: flank 100, error 0.3, copies = round((max_len-100)/len(pattern))
+    (vntr_finder.py:538-549), trimmed spanning reads of VNTR +-20 % + 200 bases with 12 % indel/substitution
+    noise; RU counts exact, log-probs bit-equal."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    from oracle import oracle as Or
+    rng = np.random.default_rng(20240603)
+    loci, reads, which = [], [], []
+    for k in range(3):
+        plen = int(rng.integers(10, 40))
+        vntr_len = int(rng.integers(100, 400))
+        true_copies = max(1, vntr_len // plen)
+        lens = [int(vntr_len * rng.uniform(0.8, 1.2)) + 200 for _ in range(6)]
+        max_copies = int(round((max(lens) - 100) / float(plen)))
+        loc = workloads.make_locus(rng, 100, plen, max_copies, error_rate=0.3)
+        loci.append(loc)
+        for n in lens:
+            s = loc.left + loc.units[0] * true_copies + loc.right
+            out = []
+            for ch in s:
+                u = rng.random()
+                if u < 0.04:
+                    continue
+                if u < 0.08:
+                    out.append("ACGT"[int(rng.integers(0, 4))])
+                out.append("ACGT"[int(rng.integers(0, 4))] if rng.random() < 0.04 else ch)
+            reads.append("".join(out)[:n])
+            which.append(k)
+    dms = [l.model.device_model() for l in loci]
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch(dms, bases, off, np.asarray(which, np.int32), want_paths=True)
+    for k, loc in enumerate(loci):
+        a = loc.model.baked_arrays()
+        edges = [(int(a["in_src"][q]), l, float(a["in_logp"][q]))
+                 for l in range(a["m"]) for q in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+        names = [s.name for s in loc.model.states]
+        for i in [i for i, w in enumerate(which) if w == k]:
+            olp, opath = O.viterbi(reads[i])
+            assert logp[i] == olp
+            assert paths[i] == opath
+            assert summ[i][_lib.SUM_RU] == Or.number_of_repeats([names[j] for j in opath][1:-1])
