@@ -81,6 +81,8 @@ template <int K>
 struct ColRegs {
     double I[K], M[K], B[K], pI[K], pM[K], pB[K], er[K];
     int erwin[K], x[K];
+    uint2 meta[K];             // this step's column info words (class / emission ids / flags), loaded a step ahead
+    double v0b0;               // chunk 0: row-0 value of this step's column
     // row-tiling only: values of the previous tile's last row for 64 columns (lane i <-> column cb+i), and
     // the next 64 (prefetched)
     double sI, sM, sB, tI, tM, tB;
@@ -121,15 +123,28 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     const int t = 64 * k + lane + 1;
     const int c = s - t;
     const int cc = CHECKED ? min(max(c + 1, 0), NC + 1) : c + TPAD;
-    const ColInfo inf = CHECKED ? L.info0[cc] : L.info[cc];
-    const ColClass *T = L.classes + inf.tclass;
+    uint2 meta;
+    double v0b = 0.0;
+    if (CHECKED) {
+        const ColInfo inf = L.info0[cc];
+        meta = make_uint2((unsigned)inf.tclass | ((unsigned)inf.emM << 16), (unsigned)inf.emI | ((unsigned)inf.flags << 16));
+        v0b = inf.v0b;
+    } else {
+        // the info word was loaded during the previous step (software pipelining of the dependent LDS chain
+        // info -> class record); fetch the next column's now
+        meta = R.meta[k];
+        R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc + 1) + 8);
+        if (FIRST && k == 0) { v0b = R.v0b0; R.v0b0 = L.info[cc + 1].v0b; }
+    }
+    const unsigned tclass = meta.x & 0xffffu, emM = meta.x >> 16, emI = meta.y & 0xffffu;
+    const ColClass *T = L.classes + tclass;
     // previous row, same column: the neighbouring lane's values of the previous step
     double nI, nM, nB;
     if (k == 0) {
         if (FIRST) {
             nI = shift_up1(R.I[0], -INFINITY);
             nM = shift_up1(R.M[0], -INFINITY);
-            nB = shift_up1(R.B[0], inf.v0b);      // row 0 is read independent (host precomputed)
+            nB = shift_up1(R.B[0], v0b);          // row 0 is read independent (host precomputed)
         } else {
             nI = shift_up1(R.I[0], injI);
             nM = shift_up1(R.M[0], injM);
@@ -140,8 +155,8 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         nM = shift_up1_from(R.M[k], R.M[k - 1]);
         nB = shift_up1_from(R.B[k], R.B[k - 1]);
     }
-    const double eI = L.emis[inf.emI * COL_EMIS_STRIDE + R.x[k]];
-    const double eM = L.emis[inf.emM * COL_EMIS_STRIDE + R.x[k]];
+    const double eI = L.emis[emI * COL_EMIS_STRIDE + R.x[k]];
+    const double eM = L.emis[emM * COL_EMIS_STRIDE + R.x[k]];
     // I_c(t) <- [I_c, M_c, b_c](t-1)
     double vI = (nI + T->iI) + eI;
     int pi = 0;
@@ -171,7 +186,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         if (c1 > vB) { vB = c1; pb = 1; }
         if (c2 > vB) { vB = c2; pb = 2; }
     }
-    const unsigned fl = inf.flags;
+    const unsigned fl = meta.y >> 16;
     if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
         if (fl & COL_FLAG_SINK) {
             vB = R.er[k];
@@ -186,7 +201,9 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     }
     R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
     R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
+#ifndef EXP_NO_BP
     C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+#endif
     if (FIRST ? (k == K - 1) : true) {                               // single tile: row n lives in the last chunk
         if (t == C.n_tile && c >= 0 && c < NC) {
             C.cap[c * 3 + 0] = vI;
@@ -219,6 +236,13 @@ template <int K, int KLO, int KHI, bool FIRST>
 __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const TileCtx &C,
                                           const int lane)
 {
+    constexpr int TPAD = 64 * K;
+#pragma unroll
+    for (int k = KHI; k >= KLO; --k) {              // info words of the phase's first step
+        const int cc = s0 - (64 * k + lane + 1) + TPAD;
+        R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc) + 8);
+        if (FIRST && k == 0) R.v0b0 = L.info[cc].v0b;
+    }
     for (int s = s0; s <= s1; ++s) {
         double injI = 0, injM = 0, injB = 0;
         if (!FIRST) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
@@ -303,24 +327,33 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
     return result;
 }
 
+// Wave-cooperative traceback.  The walk position (t, c, slot, len) is wave-uniform.  Viterbi paths of reads
+// are dominated by match->match moves, i.e. runs along a trellis diagonal: for those, the 64 lanes gather the
+// back-pointer bytes of (t-i, c-i), i = 0..63, in one round trip, a ballot gives the length of the M->M run
+// and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
 template <int K>
 __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                              const int start_state, const int P, const uint8_t *__restrict__ bp,
                                              const int64_t slab, const int sink_stride,
                                              const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                             int32_t *__restrict__ rev, const int cap)
+                                             int32_t *__restrict__ rev, const int cap, const int lane)
 {
     constexpr int TPAD = 64 * K;
     const uint8_t *base = (const uint8_t *)cp;
     const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
     const int32_t *tstate = (const int32_t *)(base + cp->off_tail_state);
     const int32_t *pred0 = (const int32_t *)(base + cp->off_pred0);
+    auto bp_at = [&](int tt, int cc) -> int {
+        const int tile = (tt - 1) / TPAD, lt = tt - tile * TPAD;       // row tile and row inside it
+        return bp[tile * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];
+    };
     int len = 0;
     int ti = cp->end_tail, t = n, c = 0, slot = 0;
     // tail states (all in row n)
     for (;;) {
         if (len >= cap - 2) return -2;
-        rev[len++] = tstate[ti];
+        if (lane == 0) rev[len] = tstate[ti];
+        ++len;
         const TailEdge ed = edges[tailwin[ti]];
         if (ed.loc < 0) { ti = -ed.loc - 1; continue; }
         c = ed.loc >> 2;
@@ -329,20 +362,52 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
     }
     int s0 = -1;           // row-0 silent state to continue from
     while (t >= 1) {
-        if (len >= cap - 2) return -2;
-        const ColState cs = L.state[c + 1];
-        rev[len++] = slot == 0 ? cs.sI : slot == 1 ? cs.sM : cs.sB;
-        const int tile = (t - 1) / TPAD, lt = t - tile * TPAD;           // row tile and row inside it
-        const int byte = bp[tile * slab + (int64_t)(lt + c - 1) * TPAD + (lt - 1)];
-        if (slot == 0) {
-            slot = byte & 3; t -= 1;                       // (t-1, c, I/M/b)
-        } else if (slot == 1) {
-            const int p = (byte >> 2) & 3;
-            t -= 1;
-            if (p == 2) { s0 = cs.sX; break; }             // entry edge from a row-0-only state
+        if (len >= cap - 66) return -2;
+        if (slot == 1) {
+            // diagonal gather: lane i looks at the M cell (t-i, c-i)
+            const int tt = t - lane, cc = c - lane;
+            const bool valid = tt >= 1 && cc >= 1;
+            const int byte = valid ? bp_at(tt, cc) : 0xff;
+            const unsigned long long mm = __ballot(valid && ((byte >> 2) & 3) == 1);
+            // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
+            // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
+            const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
+            const int cells = min(run + 1, 64);                       // M cells visited, lanes 0..cells-1
+            if (lane < cells) rev[len + lane] = L.state[cc + 1].sM;
+            len += cells;
+            if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
+            // leave through the pointer of the last visited cell (lane `run`)
+            const int lastbyte = __shfl(byte, run, 64);
+            const int p = (lastbyte >> 2) & 3;
+            const ColState cs = L.state[c - run + 1];
+            t -= run + 1;
+            c -= run;
+            if (p == 2) { s0 = cs.sX; break; }                        // entry edge from a row-0-only state
             c -= 1;
-            slot = p == 3 ? 2 : p;
-        } else {
+            slot = p == 3 ? 2 : p;                                     // p == 0 -> I, 3 -> b   (1 cannot occur here)
+            continue;
+        }
+        const ColState cs = L.state[c + 1];
+        if (slot == 0) {
+            // insert self-loop runs (reads that do not belong to the locus sit in one insert state for most
+            // of their length): vertical gather, lane i looks at the I cell (t-i, c)
+            const int tt = t - lane;
+            const bool valid = tt >= 1;
+            const int byte = valid ? bp_at(tt, c) : 0xff;
+            const unsigned long long ii = __ballot(valid && (byte & 3) == 0);
+            const int run = (~ii == 0ull) ? 64 : (__ffsll((long long)~ii) - 1);
+            const int cells = min(run + 1, 64);
+            if (lane < cells) rev[len + lane] = cs.sI;
+            len += cells;
+            if (run >= 64) { t -= 64; continue; }
+            slot = __shfl(byte, run, 64) & 3;                          // 1 -> M, 2 -> b of the same column
+            t -= run + 1;
+            continue;
+        }
+        if (lane == 0) rev[len] = cs.sB;
+        ++len;
+        const int byte = bp_at(t, c);
+        {
             const int p = (byte >> 4) & 3;
             if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + t];   // fan-in winner
             else { c -= 1; slot = p; }
@@ -351,10 +416,12 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
     if (s0 < 0) s0 = L.state[c + 1].sB;                    // arrived in row 0 on the backbone
     while (s0 != start_state) {
         if (len >= cap - 2 || s0 < P) return -2;
-        rev[len++] = s0;
+        if (lane == 0) rev[len] = s0;
+        ++len;
         s0 = pred0[s0 - P];
     }
-    rev[len++] = start_state;
+    if (lane == 0) rev[len] = start_state;
+    ++len;
     return len;
 }
 
@@ -451,12 +518,13 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
             const double logp = col_tail(cp, final_row, tailwin, NC, lane);
             if (lane == 0) g.a.out_logp[r] = logp;
             int len = 0;
+#ifndef EXP_NO_TB
             if (logp != -INFINITY) {
-                if (lane == 0)
-                    len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev,
-                                           g.a.path_cap);
-                len = __shfl(len, 0, 64);
+                len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev,
+                                       g.a.path_cap, lane);
+                len = __builtin_amdgcn_readfirstlane(len);
             }
+#endif
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
             if (g.a.out_summary && !(flags & 4u)) {
