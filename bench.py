@@ -143,6 +143,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
+    # the bench); None when the profile does not describe this workload/kernel
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        if args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_columns":
+            traffic = pmc["hbm_bytes_per_launch_fetch_x2"] / 1e9
+    except Exception:
+        traffic = None
+
     # kernel-only duration, HIP events on the engine's launch stream
     kernel_ms = batch.run_timed(max(1, min(args.steps, 3)))
     logp, summ = batch.fetch()
@@ -169,7 +179,9 @@ def main():
                        "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
                        "relaxations_per_s": value * (n + 1) * E},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "GB per launch (profiles/r01_pmc_summary.json: WRITE_SIZE + 2 x FETCH_SIZE)",
+                         "algorithmic_gb_per_launch": B * args.reads / 1e9,
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_read": B,
                          "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the max-plus recurrence is "
                                  "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
