@@ -381,32 +381,57 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
 
     if (B->n_col) {
         ColumnLaunch &C = B->col;
+        C.stream = (flags & ADVNTR_FLAG_STREAM) != 0;
         int n_max_col = 0;
-        for (int i = 0; i < B->n_col;) {
-            const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
-            int j = i;
-            while (j < B->n_col && j - i < COL_TILE_READS && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
-            C.tiles[K - 1].push_back(ColTile{mod, i, j - i, 0});
-            i = j;
-        }
         for (int r : col_reads) {
             const advntr_hmm *H = B->models[read_model[r]];
             C.nc_max = std::max(C.nc_max, H->colprog.n_cols);
             C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes + (size_t)(H->colprog.n_cols + 128 * 4) * sizeof(ColInfo));
             n_max_col = std::max<int>(n_max_col, (int)(read_off[r + 1] - read_off[r]));
         }
-        const int kmax = std::min(4, (n_max_col + 63) / 64);
-        const int row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + COL_MAX_READ - 1) / COL_MAX_READ : 1;
-        int per_cu = (int)std::min<size_t>(4, (150 * 1024) / (C.lds_bytes + 16));
+        int per_cu = (int)std::min<size_t>(4, (150 * 1024) / (C.lds_bytes + 16 + 1024));
         per_cu = std::max(per_cu, 1);
+        if (C.stream) {
+            // stream kernel: reads of one model, any length, packed back to back by each wavefront
+            std::stable_sort(col_reads.begin(), col_reads.end(), [&](int a, int b) { return read_model[a] < read_model[b]; });
+            std::copy(col_reads.begin(), col_reads.end(), order.begin());
+            HIP_TRY(hipMemcpy(B->d_order, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
+            const int per_tile = COL_WAVES * COL_STREAM_READS;
+            for (int i = 0; i < B->n_col;) {
+                const int mod = read_model[col_reads[i]];
+                int j = i;
+                while (j < B->n_col && j - i < per_tile && read_model[col_reads[j]] == mod) ++j;
+                C.tiles[0].push_back(ColTile{mod, i, j - i, 0});
+                i = j;
+            }
+            const int TP = 64 * COL_STREAM_K;
+            C.ring = (n_max_col + TP - 1) / TP + 1;
+            C.bp_stride = (((int64_t)C.ring * (TP + C.nc_max) * TP) + 255) & ~int64_t(255);
+            C.sink_stride = C.ring * TP + 2;
+            C.rown_stride = 6 * (int64_t)C.nc_max + (int64_t)COL_STREAM_CAPS * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
+        } else {
+            // tiles of up to 16 reads of one model and one chunk count; the last ~15 % of the reads go out in
+            // smaller tiles (8, then 4 = one read per wave) so the dynamic dequeue ends evenly across the CUs
+            for (int i = 0; i < B->n_col;) {
+                const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
+                const int left = B->n_col - i;
+                const int cap = left > B->n_col * 15 / 100 ? COL_TILE_READS : (left > B->n_col * 5 / 100 ? COL_TILE_READS / 2 : COL_WAVES);
+                int j = i;
+                while (j < B->n_col && j - i < cap && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
+                C.tiles[K - 1].push_back(ColTile{mod, i, j - i, 0});
+                i = j;
+            }
+            const int kmax = std::min(4, (n_max_col + 63) / 64);
+            const int row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + COL_MAX_READ - 1) / COL_MAX_READ : 1;
+            C.bp_stride = ((row_tiles * (int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
+            C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
+            C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
+        }
         size_t n_tiles = 0;
         for (int k = 0; k < 5; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
-        C.bp_stride = ((row_tiles * (int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
         // keep the back-pointer scratch of all resident waves under 48 GB (long reads: fewer resident waves)
         while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > (int64_t)48 << 30) C.grid = (C.grid + 1) / 2;
-        C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
-        C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
         C.aux_stride = COL_MAX_TAIL + (int64_t)COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
@@ -513,11 +538,15 @@ extern "C" int advntr_batch_run(advntr_batch *B)
         a.n_reads = B->n_col;
         a.order = B->d_order;
         a.path_scratch = B->d_pathbuf_col;
+        if (B->col.stream) column_launch_stream<COL_STREAM_K>(B->col, a, B->flags, B->stream);
+        else
         column_launch_k<1, false>(B->col, a, B->flags, B->stream);
-        column_launch_k<2, false>(B->col, a, B->flags, B->stream);
-        column_launch_k<3, false>(B->col, a, B->flags, B->stream);
-        column_launch_k<4, false>(B->col, a, B->flags, B->stream);
-        column_launch_k<4, true>(B->col, a, B->flags, B->stream);
+        if (!B->col.stream) {
+            column_launch_k<2, false>(B->col, a, B->flags, B->stream);
+            column_launch_k<3, false>(B->col, a, B->flags, B->stream);
+            column_launch_k<4, false>(B->col, a, B->flags, B->stream);
+            column_launch_k<4, true>(B->col, a, B->flags, B->stream);
+        }
     }
     if (B->n_gen) {
         BatchArgs a = generic_args(B);

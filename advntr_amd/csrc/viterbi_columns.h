@@ -48,6 +48,7 @@ struct ColArgs {
     int64_t bp_stride;
     int32_t lds_tables;      // bytes of LDS reserved for the tables
     int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
+    int32_t ring;            // stream kernel: back-pointer slabs per wave (row tiles kept for the traceback)
 };
 
 __device__ __forceinline__ int dpp_wave_shr1(int old, int src)
@@ -83,6 +84,7 @@ struct ColRegs {
     int erwin[K], x[K];
     uint2 meta[K];             // this step's column info words (class / emission ids / flags), loaded a step ahead
     double v0b0;               // chunk 0: row-0 value of this step's column
+    int sflag[K];              // stream mode: bit 0 = first row of a read, bit 1 = last row, bits 8.. = capture slot
     // row-tiling only: values of the previous tile's last row for 64 columns (lane i <-> column cb+i), and
     // the next 64 (prefetched)
     double sI, sM, sB, tI, tM, tB;
@@ -93,12 +95,16 @@ struct ColRegs {
 struct TileCtx {
     int NC;
     int n_tile;                // rows in this tile (1 .. 64K)
-    int row0;                  // global row offset of the tile (0 for the first tile)
+    int row0;                  // sink back-pointer row of the tile's first row minus one (index = row0 + t)
     int sink_stride;           // ints per sink in sinkbp
     uint8_t *bp;               // this tile's back-pointer slab
     double *cap;               // where the tile's last row goes (next seam, or the row-n buffer)
     const double *seam;        // previous tile's last row (nullptr for the first tile)
     int32_t *sinkbp;
+    // stream mode (several reads packed along the row axis)
+    double *seam_out;          // last row of a full tile -> next tile's seam
+    int64_t cap_stride;        // doubles between the capture buffers of the reads that end in this tile
+    unsigned hasfirst, haslast; // bit k: chunk k holds a first / last row of some read
 };
 
 __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
@@ -113,8 +119,11 @@ __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
 
 // One trellis cell per lane of chunk k.  CHECKED = clamp the column index (used when chunk ranges cannot
 // be split into branch-free phases); otherwise the info table is padded with 64*K dummy columns per side.
-// FIRST = first row tile (row 0 comes from the host-precomputed v0b; entry edges X are live in row 1).
-template <int K, bool CHECKED, bool FIRST>
+// MODE 0 = first (or only) row tile of one read: row 0 comes from the host-precomputed v0b, entry edges X are live
+//          in row 1 (chunk 0, lane 0);
+// MODE 1 = continuation tile of a long read: row 0 of the tile is the previous tile's last row (seam);
+// MODE 2 = stream tile: several reads packed back to back along the row axis, first/last rows flagged per lane.
+template <int K, bool CHECKED, int MODE>
 __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTables &L, const TileCtx &C, const int s,
                                          const int lane, const double injI, const double injM, const double injB)
 {
@@ -134,14 +143,14 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         // info -> class record); fetch the next column's now
         meta = R.meta[k];
         R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc + 1) + 8);
-        if (FIRST && k == 0) { v0b = R.v0b0; R.v0b0 = L.info[cc + 1].v0b; }
+        if (MODE == 0 && k == 0) { v0b = R.v0b0; R.v0b0 = L.info[cc + 1].v0b; }
     }
     const unsigned tclass = meta.x & 0xffffu, emM = meta.x >> 16, emI = meta.y & 0xffffu;
     const ColClass *T = L.classes + tclass;
     // previous row, same column: the neighbouring lane's values of the previous step
     double nI, nM, nB;
     if (k == 0) {
-        if (FIRST) {
+        if (MODE == 0) {
             nI = shift_up1(R.I[0], -INFINITY);
             nM = shift_up1(R.M[0], -INFINITY);
             nB = shift_up1(R.B[0], v0b);          // row 0 is read independent (host precomputed)
@@ -154,6 +163,14 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         nI = shift_up1_from(R.I[k], R.I[k - 1]);
         nM = shift_up1_from(R.M[k], R.M[k - 1]);
         nB = shift_up1_from(R.B[k], R.B[k - 1]);
+    }
+    const bool first_row = MODE == 2 ? (R.sflag[k] & 1) != 0 : false;
+    const bool chunk_first = MODE == 2 && ((C.hasfirst >> k) & 1u);          // wave-uniform
+    if (chunk_first) {                            // a read starts in this chunk: its row 0 is the model's
+        const double v0c = CHECKED ? v0b : L.info[cc].v0b;
+        nI = first_row ? -INFINITY : nI;
+        nM = first_row ? -INFINITY : nM;
+        nB = first_row ? v0c : nB;
     }
     const double eI = L.emis[emI * COL_EMIS_STRIDE + R.x[k]];
     const double eM = L.emis[emM * COL_EMIS_STRIDE + R.x[k]];
@@ -171,8 +188,12 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     {
         const double c1 = (R.pM[k] + T->mM) + eM;
         if (c1 > vM) { vM = c1; pm = 1; }
-        if (FIRST && k == 0) {
+        if (MODE == 0 && k == 0) {
             const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
+            if (c2 > vM) { vM = c2; pm = 2; }
+        }
+        if (chunk_first) {
+            const double c2 = (first_row ? T->mX : -INFINITY) + eM;
             if (c2 > vM) { vM = c2; pm = 2; }
         }
         const double c3 = (R.pB[k] + T->mD) + eM;
@@ -204,7 +225,23 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
 #ifndef EXP_NO_BP
     C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
 #endif
-    if (FIRST ? (k == K - 1) : true) {                               // single tile: row n lives in the last chunk
+    if (MODE == 2) {
+        if (k == K - 1) {                                            // last row of a full tile -> next tile's seam
+            if (lane == 63 && c >= 0 && c < NC) {
+                C.seam_out[c * 3 + 0] = vI;
+                C.seam_out[c * 3 + 1] = vM;
+                C.seam_out[c * 3 + 2] = vB;
+            }
+        }
+        if ((C.haslast >> k) & 1u) {                                 // wave-uniform: a read ends in this chunk
+            if ((R.sflag[k] & 2) && c >= 0 && c < NC) {
+                double *cap = C.cap + (int64_t)(R.sflag[k] >> 8) * C.cap_stride;
+                cap[c * 3 + 0] = vI;
+                cap[c * 3 + 1] = vM;
+                cap[c * 3 + 2] = vB;
+            }
+        }
+    } else if (MODE == 0 ? (k == K - 1) : true) {                    // single tile: row n lives in the last chunk
         if (t == C.n_tile && c >= 0 && c < NC) {
             C.cap[c * 3 + 0] = vI;
             C.cap[c * 3 + 1] = vM;
@@ -232,7 +269,7 @@ __device__ __forceinline__ void seam_fetch(ColRegs<K> &R, const TileCtx &C, cons
     injB = readlane_f64(R.sB, j);
 }
 
-template <int K, int KLO, int KHI, bool FIRST>
+template <int K, int KLO, int KHI, int MODE>
 __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const TileCtx &C,
                                           const int lane)
 {
@@ -241,19 +278,20 @@ __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int
     for (int k = KHI; k >= KLO; --k) {              // info words of the phase's first step
         const int cc = s0 - (64 * k + lane + 1) + TPAD;
         R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc) + 8);
-        if (FIRST && k == 0) R.v0b0 = L.info[cc].v0b;
+        if (MODE == 0 && k == 0) R.v0b0 = L.info[cc].v0b;
     }
     for (int s = s0; s <= s1; ++s) {
         double injI = 0, injM = 0, injB = 0;
-        if (!FIRST) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
+        if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
-        for (int k = KHI; k >= KLO; --k) col_cell<K, false, FIRST>(R, k, L, C, s, lane, injI, injM, injB);
+        for (int k = KHI; k >= KLO; --k) col_cell<K, false, MODE>(R, k, L, C, s, lane, injI, injM, injB);
     }
 }
 
-template <int K, bool FIRST>
+template <int K, int MODE>
 __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded, const TileCtx &C,
-                                          const uint8_t *__restrict__ seq_tile, const int lane)
+                                          const uint8_t *__restrict__ seq_tile, const int lane,
+                                          const int *slot_x = nullptr, const int *slot_flag = nullptr)
 {
     const int NC = C.NC, n = C.n_tile;
     ColRegs<K> R;
@@ -262,10 +300,16 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
         R.I[k] = R.M[k] = R.B[k] = R.pI[k] = R.pM[k] = R.pB[k] = R.er[k] = -INFINITY;
         R.erwin[k] = 0;
         const int t = 64 * k + lane + 1;
-        R.x[k] = (t <= n) ? (int)seq_tile[t - 1] : 0;
+        if (MODE == 2) {
+            R.x[k] = slot_x[k];
+            R.sflag[k] = slot_flag[k];
+        } else {
+            R.x[k] = (t <= n) ? (int)seq_tile[t - 1] : 0;
+            R.sflag[k] = 0;
+        }
     }
     R.sI = R.sM = R.sB = R.tI = R.tM = R.tB = -INFINITY;
-    if (!FIRST) {                                   // columns 0..63 of the seam; seam_fetch rotates at s = 1
+    if (MODE != 0) {                                // columns 0..63 of the seam; seam_fetch rotates at s = 1
         const int cn = min(lane, NC - 1);
         R.tI = C.seam[cn * 3 + 0];
         R.tM = C.seam[cn * 3 + 1];
@@ -275,21 +319,21 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
     if (padded && NC + 63 >= 64 * (K - 1) + 1) {
         // chunk k is busy for steps [64k+1, 64k+64+NC-1]: ramp-up phases, a branch-free steady state with all
         // chunks in one basic block (independent dependency chains interleave), ramp-down phases
-        if (K >= 2) col_phase<K, 0, 0, FIRST>(R, 1, min(s_end, 64), L, C, lane);
-        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0), FIRST>(R, 65, min(s_end, 128), L, C, lane);
-        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0), FIRST>(R, 129, min(s_end, 192), L, C, lane);
-        col_phase<K, 0, K - 1, FIRST>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, C, lane);
-        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1, FIRST>(R, NC + 64, min(s_end, NC + 127), L, C, lane);
-        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1, FIRST>(R, NC + 128, min(s_end, NC + 191), L, C, lane);
-        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1, FIRST>(R, NC + 192, min(s_end, NC + 255), L, C, lane);
+        if (K >= 2) col_phase<K, 0, 0, MODE>(R, 1, min(s_end, 64), L, C, lane);
+        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0), MODE>(R, 65, min(s_end, 128), L, C, lane);
+        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0), MODE>(R, 129, min(s_end, 192), L, C, lane);
+        col_phase<K, 0, K - 1, MODE>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, C, lane);
+        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1, MODE>(R, NC + 64, min(s_end, NC + 127), L, C, lane);
+        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1, MODE>(R, NC + 128, min(s_end, NC + 191), L, C, lane);
+        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1, MODE>(R, NC + 192, min(s_end, NC + 255), L, C, lane);
     } else {
         for (int s = 1; s <= s_end; ++s) {
             double injI = 0, injM = 0, injB = 0;
-            if (!FIRST) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
+            if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
-                col_cell<K, true, FIRST>(R, k, L, C, s, lane, injI, injM, injB);
+                col_cell<K, true, MODE>(R, k, L, C, s, lane, injI, injM, injB);
             }
         }
     }
@@ -336,16 +380,19 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
                                              const int start_state, const int P, const uint8_t *__restrict__ bp,
                                              const int64_t slab, const int sink_stride,
                                              const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                             int32_t *__restrict__ rev, const int cap, const int lane)
+                                             int32_t *__restrict__ rev, const int cap, const int lane,
+                                             const int U0 = 0, const int ring = 1 << 30, const int W = 1 << 30)
 {
     constexpr int TPAD = 64 * K;
     const uint8_t *base = (const uint8_t *)cp;
     const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
     const int32_t *tstate = (const int32_t *)(base + cp->off_tail_state);
     const int32_t *pred0 = (const int32_t *)(base + cp->off_pred0);
+    // read row tt is stream row U0+tt-1; row tiles of 64K rows, slabs reused modulo `ring`
     auto bp_at = [&](int tt, int cc) -> int {
-        const int tile = (tt - 1) / TPAD, lt = tt - tile * TPAD;       // row tile and row inside it
-        return bp[tile * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];
+        const int u = U0 + tt - 1;
+        const int tile = u / TPAD, lt = u - tile * TPAD + 1;
+        return bp[(tile % ring) * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];
     };
     int len = 0;
     int ti = cp->end_tail, t = n, c = 0, slot = 0;
@@ -409,7 +456,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
         const int byte = bp_at(t, c);
         {
             const int p = (byte >> 4) & 3;
-            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + t];   // fan-in winner
+            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
             else { c -= 1; slot = p; }
         }
     }
@@ -423,6 +470,78 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
     if (lane == 0) rev[len] = start_state;
     ++len;
     return len;
+}
+
+// Copy a model's class tables into LDS and build the padded info table (64*K dummy columns on either side, so a
+// lane can index it with c + 64*K without clamping; c runs from 1-64K to 64K+NC-2).  Returns whether the padded
+// copy fits.
+template <int K>
+__device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, uint8_t *tables, const int lds_tables,
+                                            LdsTables &L, const int tid)
+{
+    __syncthreads();
+    const uint4 *src = (const uint4 *)((const uint8_t *)cp + cp->off_class);
+    uint4 *dst = (uint4 *)tables;
+    for (int i = tid; i < cp->lds_bytes / 16; i += COL_WAVES * 64) dst[i] = src[i];
+    L.classes = (const ColClass *)tables;
+    L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
+    L.info = (const ColInfo *)(tables + (cp->off_info - cp->off_class));
+    L.info0 = L.info;
+    L.state = (const ColState *)(tables + (cp->off_state - cp->off_class));
+    const bool padded = (size_t)cp->lds_bytes + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)lds_tables;
+    if (padded) {
+        __syncthreads();
+        uint4 *pinfo = (uint4 *)(tables + cp->lds_bytes);
+        const uint4 *sinfo = (const uint4 *)L.info0;
+        const int ncol = cp->n_cols;
+        for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
+            const int c = i - 64 * K;
+            pinfo[i] = sinfo[(c >= 0 && c < ncol) ? c + 1 : 0];
+        }
+        L.info = (const ColInfo *)pinfo;
+    }
+    __syncthreads();
+    return padded;
+}
+
+// Everything after the sweep of one read: tail states, traceback, summaries, outputs.
+template <int K>
+__device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
+                                                const LdsTables &L, const DevModel &M, const int r,
+                                                const uint8_t *__restrict__ seq, const int n, double *final_row,
+                                                const uint8_t *__restrict__ bp, const int64_t slab,
+                                                int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                                int32_t *__restrict__ rev, const int lane, const int U0, const int ring,
+                                                const int W)
+{
+    const int NC = cp->n_cols;
+    const double logp = col_tail(cp, final_row, tailwin, NC, lane);
+    if (lane == 0) g.a.out_logp[r] = logp;
+    int len = 0;
+#ifndef EXP_NO_TB
+    if (logp != -INFINITY) {
+        len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane,
+                               U0, ring, W);
+        len = __builtin_amdgcn_readfirstlane(len);
+    }
+#endif
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (g.a.out_summary && !(flags & 4u)) {
+        int32_t *out = g.a.out_summary + (int64_t)r * 8;
+        if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);
+        else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
+    }
+    if (g.a.out_path && (flags & 1u)) {
+        const int64_t o0 = g.a.out_path_off[r];
+        const int cap = (int)(g.a.out_path_off[r + 1] - o0);
+        int olen = len;
+        if (len > cap) olen = -2;
+        if (olen > 0)
+            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
+        if (lane == 0) g.a.out_path_len[r] = olen;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // LONG = reads longer than 64*K rows, processed in row tiles of 64*K rows (K = 4).
@@ -459,30 +578,7 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            __syncthreads();
-            const uint4 *src = (const uint4 *)((const uint8_t *)cp + cp->off_class);
-            uint4 *dst = (uint4 *)tables;
-            for (int i = tid; i < cp->lds_bytes / 16; i += COL_WAVES * 64) dst[i] = src[i];
-            L.classes = (const ColClass *)tables;
-            L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
-            L.info = (const ColInfo *)(tables + (cp->off_info - cp->off_class));
-            L.info0 = L.info;
-            L.state = (const ColState *)(tables + (cp->off_state - cp->off_class));
-            // padded copy of the info table: 64*K dummy columns on either side, so a lane can index it with
-            // c + 64*K without clamping (c runs from 1-64K to 64K+NC-2)
-            padded = (size_t)cp->lds_bytes + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)g.lds_tables;
-            if (padded) {
-                __syncthreads();
-                uint4 *pinfo = (uint4 *)(tables + cp->lds_bytes);
-                const uint4 *sinfo = (const uint4 *)L.info0;
-                const int ncol = cp->n_cols;
-                for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
-                    const int c = i - 64 * K;
-                    pinfo[i] = sinfo[(c >= 0 && c < ncol) ? c + 1 : 0];
-                }
-                L.info = (const ColInfo *)pinfo;
-            }
-            __syncthreads();
+            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
         }
         const int NC = cp->n_cols;
         const int64_t slab = (int64_t)(TPAD + NC) * TPAD;      // back-pointer bytes per row tile
@@ -495,7 +591,7 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
             double *final_row = rown;
             if (!LONG) {
                 C.n_tile = n; C.row0 = 0; C.bp = bp; C.cap = rown; C.seam = nullptr;
-                col_sweep<K, true>(L, padded, C, seq, lane);
+                col_sweep<K, 0>(L, padded, C, seq, lane);
             } else {
                 // seam ping-pong: tile i writes its last row to buffer (i+1)&1 and reads buffer i&1
                 double *buf[2] = {rown, rown + 3 * (int64_t)NC + COL_MAX_TAIL};
@@ -506,8 +602,8 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
                     C.bp = bp + i * slab;
                     C.cap = buf[(i + 1) & 1];
                     C.seam = buf[i & 1];
-                    if (i == 0) col_sweep<K, true>(L, padded, C, seq, lane);
-                    else col_sweep<K, false>(L, padded, C, seq + C.row0, lane);
+                    if (i == 0) col_sweep<K, 0>(L, padded, C, seq, lane);
+                    else col_sweep<K, 1>(L, padded, C, seq + i * TPAD, lane);
                     __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -515,33 +611,152 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
             }
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
-            const double logp = col_tail(cp, final_row, tailwin, NC, lane);
-            if (lane == 0) g.a.out_logp[r] = logp;
-            int len = 0;
-#ifndef EXP_NO_TB
-            if (logp != -INFINITY) {
-                len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev,
-                                       g.a.path_cap, lane);
-                len = __builtin_amdgcn_readfirstlane(len);
-            }
+            col_finish_read<K>(g, flags, cp, L, M, r, seq, n, final_row, bp, slab, tailwin, sinkbp, rev, lane, 0, 1 << 30,
+                               1 << 30);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Stream kernel: a wavefront packs its reads back to back along the row axis and sweeps the stream in row
+// tiles of 64*K rows, so every lane carries a useful row (a 150-base read otherwise fills 150 of 192 lanes).
+// Read boundaries inside a tile are per-lane flags (first row: previous row := the model's row 0, entry edges
+// live; last row: captured for the tail states); a read that straddles two tiles continues through the seam
+// row exactly like a long read.  Back-pointer slabs form a ring so a straddling read can still be traced back.
+// ------------------------------------------------------------------------------------------------
+#ifndef COL_STREAM_WAVES_PER_SIMD
+#define COL_STREAM_WAVES_PER_SIMD 4
 #endif
+#define COL_STREAM_K 3           // chunks per row tile of the stream kernel (192 rows)
+#define COL_STREAM_READS 16      // reads per wavefront per tile of work
+#define COL_STREAM_CAPS 4        // reads that may END inside one row tile (capture buffers)
+
+struct StreamRead {
+    int32_t r, n, U, pad;        // read index, length, stream row of its first base
+};
+
+template <int K>
+__global__ void __launch_bounds__(COL_WAVES * 64, COL_STREAM_WAVES_PER_SIMD)
+viterbi_columns_stream_kernel(ColArgs g, uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int TPAD = 64 * K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
+    int32_t *tile_slot = (int32_t *)lds;
+    uint8_t *tables = lds + 16;
+    StreamRead *mine = (StreamRead *)(lds + 16 + g.lds_tables) + wave * COL_STREAM_READS;
+    uint8_t *bp = g.bp + gw * g.bp_stride;
+    double *rbase = g.rown + gw * g.rown_stride;
+    int32_t *aux = g.aux + gw * g.aux_stride;
+    int32_t *tailwin = aux, *sinkbp = aux + COL_MAX_TAIL;
+    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
+    const int ring = g.ring, W = g.ring * TPAD;
+    int cur_model = -1;
+    bool padded = false;
+    LdsTables L{};
+    const ColProgram *cp = nullptr;
+    DevModel M{};
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
+        __syncthreads();
+        const int ti = *tile_slot;
+        if (ti >= g.n_tiles) break;
+        const ColTile tile = g.tiles[ti];
+        if (tile.model != cur_model) {
+            cur_model = tile.model;
+            M = g.a.models[cur_model];
+            cp = M.cols;
+            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
+        }
+        const int NC = cp->n_cols;
+        const int64_t slab = (int64_t)(TPAD + NC) * TPAD;
+        const int64_t cap_stride = 3 * (int64_t)NC + COL_MAX_TAIL;
+        double *seam_buf[2] = {rbase, rbase + 3 * (int64_t)NC};
+        double *capbuf = rbase + 6 * (int64_t)NC;
+
+        // ---- lay this wave's reads out along the stream (wave-uniform arithmetic, lane 0 writes LDS)
+        int nr = 0, U = 0, last_te = -1, cnt = 0;
+        for (int j = wave; j < tile.count && nr < COL_STREAM_READS; j += COL_WAVES) {
+            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
+            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
+            int te = (U + n - 1) / TPAD;
+            if (te == last_te && cnt >= COL_STREAM_CAPS) {          // too many reads would end in that tile
+                U = (te + 1) * TPAD;
+                te = (U + n - 1) / TPAD;
+            }
+            if (te != last_te) { last_te = te; cnt = 0; }
+            ++cnt;
+            if (lane == 0) mine[nr] = StreamRead{r, n, U, 0};
+            U += n;
+            ++nr;
+        }
+        const int Utot = U;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+
+        const int n_tiles = (Utot + TPAD - 1) / TPAD;
+        for (int i = 0; i < n_tiles; ++i) {
+            const int u0 = i * TPAD;
+            int slot_x[K], slot_flag[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { slot_x[k] = 0; slot_flag[k] = 0; }
+            int ends[COL_STREAM_CAPS];
+#pragma unroll
+            for (int e = 0; e < COL_STREAM_CAPS; ++e) ends[e] = -1;
+            int ncap = 0;
+            for (int q = 0; q < nr; ++q) {
+                const StreamRead rd = mine[q];
+                const int rU = __builtin_amdgcn_readfirstlane(rd.U), rn = __builtin_amdgcn_readfirstlane(rd.n);
+                const int e = rU + rn - 1;
+                if (e < u0 || rU >= u0 + TPAD) continue;
+                const bool ends_here = e < u0 + TPAD;
+                const uint8_t *seq = g.a.bases + g.a.read_off[__builtin_amdgcn_readfirstlane(rd.r)];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int u = u0 + 64 * k + lane;
+                    if (u >= rU && u <= e) {
+                        slot_x[k] = seq[u - rU];
+                        slot_flag[k] = (u == rU ? 1 : 0) | (u == e ? 2 : 0) | (ncap << 8);
+                    }
+                }
+                if (ends_here) {
+#pragma unroll
+                    for (int c2 = 0; c2 < COL_STREAM_CAPS; ++c2)
+                        if (c2 == ncap) ends[c2] = q;
+                    ++ncap;
+                }
+            }
+            unsigned hasfirst = 0, haslast = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (__ballot(slot_flag[k] & 1)) hasfirst |= 1u << k;
+                if (__ballot(slot_flag[k] & 2)) haslast |= 1u << k;
+            }
+            TileCtx C;
+            C.NC = NC; C.sink_stride = g.sink_stride; C.sinkbp = sinkbp;
+            C.n_tile = min(TPAD, Utot - u0);
+            C.row0 = u0 % W;
+            C.bp = bp + (i % ring) * slab;
+            C.cap = capbuf; C.cap_stride = cap_stride;
+            C.seam = seam_buf[i & 1]; C.seam_out = seam_buf[(i + 1) & 1];
+            C.hasfirst = hasfirst; C.haslast = haslast;
+            col_sweep<K, 2>(L, padded, C, nullptr, lane, slot_x, slot_flag);
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
-            if (g.a.out_summary && !(flags & 4u)) {
-                int32_t *out = g.a.out_summary + (int64_t)r * 8;
-                if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);
-                else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
+#pragma unroll
+            for (int e = 0; e < COL_STREAM_CAPS; ++e) {
+                if (ends[e] < 0) continue;
+                const StreamRead rd = mine[ends[e]];
+                const int r = __builtin_amdgcn_readfirstlane(rd.r), n = __builtin_amdgcn_readfirstlane(rd.n);
+                const uint8_t *seq = g.a.bases + g.a.read_off[r];
+                col_finish_read<K>(g, flags, cp, L, M, r, seq, n, capbuf + e * cap_stride, bp, slab, tailwin, sinkbp, rev,
+                                   lane, __builtin_amdgcn_readfirstlane(rd.U), ring, W);
             }
-            if (g.a.out_path && (flags & 1u)) {
-                const int64_t o0 = g.a.out_path_off[r];
-                const int cap = (int)(g.a.out_path_off[r + 1] - o0);
-                int olen = len;
-                if (len > cap) olen = -2;
-                if (olen > 0)
-                    for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
-                if (lane == 0) g.a.out_path_len[r] = olen;
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -556,6 +771,8 @@ struct ColumnLaunch {
     int sink_stride = COL_MAX_READ + 1;
     size_t lds_bytes = 0;
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
+    bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
+    int ring = 2;
     std::vector<ColTile> tiles[5];          // per chunk count K = 1..4, [4] = row-tiled long reads
     ColTile *d_tiles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *d_tile_counters = nullptr;     // 5 counters
@@ -581,4 +798,24 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     g.sink_stride = cl.sink_stride;
     const int grid = std::min(cl.grid, g.n_tiles);
     hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+}
+
+template <int K>
+static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+{
+    if (cl.tiles[0].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[0];
+    g.n_tiles = (int32_t)cl.tiles[0].size();
+    g.tile_counter = cl.d_tile_counters;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
+    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.sink_stride = cl.sink_stride;
+    g.ring = cl.ring;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
+    hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
 }

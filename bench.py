@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
+    ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
     ap.add_argument("--workload", default="c1", choices=["c1", "c2"],
                     help="c1 (default, the bench line): 1 REF150 locus x --reads; c2: --loci synthetic loci x ~160 calls")
     ap.add_argument("--loci", type=int, default=64)
@@ -82,7 +83,7 @@ def main():
     _lib.check(_lib.load().advntr_set_device(local_rank))
 
     n = 150
-    flags = _lib.FLAG_FORCE_GENERIC if args.generic else 0
+    flags = _lib.FLAG_FORCE_GENERIC if args.generic else (_lib.FLAG_STREAM if args.stream else 0)
     if args.workload == "c2":
         t_build = time.perf_counter()
         loci, reads, which = workloads.make_c2(args.loci, seed=20240602 + rank)

@@ -35,6 +35,8 @@ extern "C" {
 #define ADVNTR_FLAG_PATH          1u  /* also return the Viterbi paths (state indices, start..end)      */
 #define ADVNTR_FLAG_FORCE_GENERIC 2u  /* use the generic-CSR kernel even if a model has a column program */
 #define ADVNTR_FLAG_NO_SUMMARY    4u  /* skip the path summaries (out_summary untouched)                */
+#define ADVNTR_FLAG_STREAM        8u  /* experimental: pack several reads per wavefront along the row axis (stream kernel)
+                                         instead of one read per wavefront bucketed by length */
 
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8

@@ -114,7 +114,7 @@ def test_mirror_model_viterbi_api():
 
 
 @pytest.mark.parametrize("shape", ["s300", "ref150"])
-@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("force_generic", [True, False, "stream"])
 def test_synthetic_batch_vs_oracle(shape, force_generic):
     """Seeded C1-style batch at a size the oracle finishes in seconds."""
     from advntr_amd import _lib, workloads
@@ -126,9 +126,9 @@ def test_synthetic_batch_vs_oracle(shape, force_generic):
     reads += ["", "A", workloads.rand_seq(np.random.default_rng(3), 301)]
     m = locus.model
     dm = m.device_model()
-    if not force_generic and not dm.has_column_program():
+    if force_generic is not True and not dm.has_column_program():
         pytest.skip("no column program")
-    flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+    flags = {True: _lib.FLAG_FORCE_GENERIC, False: 0, "stream": _lib.FLAG_STREAM}[force_generic]
     bases, off = _lib.encode_reads(reads)
     logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
                                            want_paths=True)
