@@ -415,7 +415,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             for (int i = 0; i < B->n_col;) {
                 const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
                 const int left = B->n_col - i;
-                const int cap = left > B->n_col * 15 / 100 ? COL_TILE_READS : (left > B->n_col * 5 / 100 ? COL_TILE_READS / 2 : COL_WAVES);
+                int cap = left > B->n_col * 15 / 100 ? COL_TILE_READS : (left > B->n_col * 5 / 100 ? COL_TILE_READS / 2 : COL_WAVES);
+                // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
+                const int64_t nlen = read_off[r0 + 1] - read_off[r0];
+                if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
                 int j = i;
                 while (j < B->n_col && j - i < cap && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
                 C.tiles[K - 1].push_back(ColTile{mod, i, j - i, 0});
