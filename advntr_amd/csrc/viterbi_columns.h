@@ -70,6 +70,23 @@ __device__ __forceinline__ double bcast63(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// One Viterbi relaxation: if (cand > best) { best = cand; ptr = code; }  -- strict '>' keeps the first maximum,
+// as the reference does (hmm.pyx:2039,2060,2080).  Written in assembly because of a measured gfx950 cost
+// (scripts/ubench/valu_rate.hip): hipcc's default lowering  v_cmp_gt_f64 vcc + 3 x v_cndmask_b32 ..., vcc  takes
+// ~64 cycles per wave (VCC-masked selects run at ~23 cycles each), whereas a compare into an ordinary SGPR pair
+// with e64 selects is ~4.5 cycles per instruction.  The value is taken with v_max_f64 (exactly the selected
+// operand for the non-NaN, never-negative-zero log-probabilities here), so only the pointer needs the mask.
+__device__ __forceinline__ void relax_gt(double &best, int &ptr, const double cand, const int code)
+{
+    unsigned long long m;
+    asm("v_cmp_gt_f64_e64 %0, %3, %1\n\t"
+                 "v_max_f64 %1, %1, %3\n\t"
+                 "s_nop 0\n\t"
+                 "v_cndmask_b32_e64 %2, %2, %4, %0"
+                 : "=&s"(m), "+v"(best), "+v"(ptr)
+                 : "v"(cand), "v"(code));
+}
+
 struct LdsTables {
     const ColClass *classes;
     const double *emis;
@@ -177,36 +194,20 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     // I_c(t) <- [I_c, M_c, b_c](t-1)
     double vI = (nI + T->iI) + eI;
     int pi = 0;
-    {
-        const double c1 = (nM + T->iM) + eI, c2 = (nB + T->iD) + eI;
-        if (c1 > vI) { vI = c1; pi = 1; }
-        if (c2 > vI) { vI = c2; pi = 2; }
-    }
+    relax_gt(vI, pi, (nM + T->iM) + eI, 1);
+    relax_gt(vI, pi, (nB + T->iD) + eI, 2);
     // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); the entry edge X only exists for row 1 (chunk 0, lane 0)
     double vM = (R.pI[k] + T->mI) + eM;
     int pm = 0;
-    {
-        const double c1 = (R.pM[k] + T->mM) + eM;
-        if (c1 > vM) { vM = c1; pm = 1; }
-        if (MODE == 0 && k == 0) {
-            const double c2 = ((t == 1) ? T->mX : -INFINITY) + eM;
-            if (c2 > vM) { vM = c2; pm = 2; }
-        }
-        if (chunk_first) {
-            const double c2 = (first_row ? T->mX : -INFINITY) + eM;
-            if (c2 > vM) { vM = c2; pm = 2; }
-        }
-        const double c3 = (R.pB[k] + T->mD) + eM;
-        if (c3 > vM) { vM = c3; pm = 3; }
-    }
+    relax_gt(vM, pm, (R.pM[k] + T->mM) + eM, 1);
+    if (MODE == 0 && k == 0) relax_gt(vM, pm, ((t == 1) ? T->mX : -INFINITY) + eM, 2);
+    if (chunk_first) relax_gt(vM, pm, (first_row ? T->mX : -INFINITY) + eM, 2);
+    relax_gt(vM, pm, (R.pB[k] + T->mD) + eM, 3);
     // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
     double vB = R.I[k] + T->dI;
     int pb = 0;
-    {
-        const double c1 = R.M[k] + T->dM, c2 = R.B[k] + T->dD;
-        if (c1 > vB) { vB = c1; pb = 1; }
-        if (c2 > vB) { vB = c2; pb = 2; }
-    }
+    relax_gt(vB, pb, R.M[k] + T->dM, 1);
+    relax_gt(vB, pb, R.B[k] + T->dD, 2);
     const unsigned fl = meta.y >> 16;
     if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
         if (fl & COL_FLAG_SINK) {

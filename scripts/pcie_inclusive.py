@@ -1,0 +1,21 @@
+"""PCIe-inclusive rate of the one-shot C-ABI call (host buffers in, host results out), for DESIGN.md section 7."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+e.build()
+from advntr_amd import _lib, workloads
+loc = workloads.ref150()
+reads = workloads.make_reads(np.random.default_rng(20240601), loc, 100000, 150)
+bases, off = _lib.encode_reads(reads)
+dm = loc.model.device_model()
+which = np.zeros(len(reads), np.int32)
+_lib.viterbi_batch([dm], bases[:1500], off[:11], which[:10])           # warm up (module load, first hipMalloc)
+for _ in range(3):
+    t = time.perf_counter()
+    logp, summ, _ = _lib.viterbi_batch([dm], bases, off, which)
+    dt = time.perf_counter() - t
+    print("one-shot advntr_viterbi_batch, 100k reads from host buffers: %.1f ms -> %.2f M reads/s" % (dt * 1e3, 1e-1 / dt))
+B = _lib.DeviceBatch([dm], bases, off, which)
+t = time.perf_counter(); B.run(); B.sync(); dt = time.perf_counter() - t
+print("resident batch, run+sync: %.1f ms" % (dt * 1e3))
