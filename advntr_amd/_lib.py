@@ -42,6 +42,9 @@ SYMBOLS = {
     "advntr_batch_fetch_paths": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "advntr_batch_result_ptrs": (ctypes.c_int, [_vp, _vp, _vp]),
     "advntr_batch_device_bytes": (_i64, [_vp]),
+    "advntr_kwfilter_create": (_vp, [_vp, _vp, _vp, _i32]),
+    "advntr_kwfilter_destroy": (None, [_vp]),
+    "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

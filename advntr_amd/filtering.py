@@ -1,0 +1,181 @@
+"""Keyword prefilter of unmapped reads -- host side of the stage upstream of the scoring path.
+
+Mirror of what `GenomeAnalyzer.get_filtered_read_ids` obtains from the external `adVNTR-Filtering` binary
+(/root/reference/advntr/genome_analyzer.py:173-199, /root/reference/filtering/main.cc) and of the keyword
+generator `VNTRFinder.get_keywords_for_filtering` (/root/reference/advntr/vntr_finder.py:140-153).
+
+The per-read keyword matching (main.cc:247-283) runs on the GPU through `advntr_kwfilter_*`
+(csrc/keyword_filter.h); this module keeps the order-dependent bookkeeping of main.cc:286-331 (per-VNTR read lists
+capped at 3 x 2000 in read order, descending (count, name) order, the 2000 + 1 names quirk) so that `run()` yields
+byte-for-byte the text the reference binary prints.  No CPU matching fallback: without the engine, scan() raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_CODE5 = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _CODE5[ord(_c)] = _i
+
+
+def get_keywords_for_filtering(left_flank, repeat_segments, right_flank, pattern, short_reads=True, keyword_size=21):
+    vntr = ''.join(repeat_segments)
+    if len(vntr) < keyword_size:
+        vntr = str(vntr) * (int(keyword_size / len(vntr)) + 1)
+    locus = left_flank[-15:] + vntr + right_flank[:15]
+    step_size = 5 if len(pattern) != 5 else 6
+    queries = [locus[i:i + keyword_size] for i in range(0, len(locus) - keyword_size + 1, step_size)]
+    if not short_reads:
+        queries = [left_flank[-80:], right_flank[:80]]
+    return set(queries)
+
+
+def _atoi(s):
+    n, i, sign = 0, 0, 1
+    if i < len(s) and s[i] in "+-":
+        sign = -1 if s[i] == "-" else 1
+        i += 1
+    while i < len(s) and s[i].isdigit():
+        n = n * 10 + ord(s[i]) - 48
+        i += 1
+    return sign * n
+
+
+class KeywordFilter(object):
+    """Keyword sets of many VNTRs resident on the GPU.  `lines` = [(vntr_id, iterable of keywords), ...] in the
+    order of the keywords file (main.cc:176-216: duplicate keywords on one line collapse, order within a line is
+    the sorted order of std::set)."""
+
+    def __init__(self, lines):
+        self.vntr_ids = [int(v) for v, _ in lines]
+        self.uniq_ids = sorted(set(self.vntr_ids))
+        index = {v: i for i, v in enumerate(self.uniq_ids)}
+        words, owners = [], []
+        for vid, kws in lines:
+            for tok in sorted(set(kws)):
+                words.append(tok)
+                owners.append(index[int(vid)])
+        off = np.zeros(len(words) + 1, np.int64)
+        for i, w in enumerate(words):
+            off[i + 1] = off[i] + len(w)
+        flat = "".join(words).encode("latin-1", "replace")
+        codes = _CODE5[np.frombuffer(flat, dtype=np.uint8)] if flat else np.zeros(0, np.uint8)
+        owners = np.asarray(owners, np.int32)
+        L = _lib.load()
+        _lib.require_gpu()
+        self._h = L.advntr_kwfilter_create(_lib.ptr(np.ascontiguousarray(codes)), _lib.ptr(off), _lib.ptr(owners), len(words))
+        if not self._h:
+            raise _lib.EngineError(_lib.ERR_ARG, _lib.last_error())
+        self.kernel_ms = 0.0
+
+    @classmethod
+    def from_text(cls, keywords_text):
+        lines = []
+        for line in keywords_text.split("\n"):
+            tokens = line.split()
+            if len(tokens) < 1:
+                break
+            lines.append((_atoi(tokens[0]), tokens[1:]))
+        return cls(lines)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().advntr_kwfilter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def count_matches(self, seqs):
+        """{read index: {vntr_id: occurrences}} for reads with at least one keyword hit (GPU)."""
+        L = _lib.load()
+        off = np.zeros(len(seqs) + 1, np.int64)
+        for i, s in enumerate(seqs):
+            off[i + 1] = off[i] + len(s)
+        flat = "".join(seqs).encode("latin-1", "replace")
+        bases = np.ascontiguousarray(_CODE5[np.frombuffer(flat, dtype=np.uint8)]) if flat else np.zeros(0, np.uint8)
+        cap = max(1024, 4 * len(seqs))
+        while True:
+            o_r, o_v, o_c = (np.zeros(cap, np.int32) for _ in range(3))
+            n_out = ctypes.c_int64(0)
+            ms = ctypes.c_float(0)
+            rc = L.advntr_kwfilter_scan(self._h, _lib.ptr(bases), _lib.ptr(off), len(seqs), _lib.ptr(o_r), _lib.ptr(o_v),
+                                        _lib.ptr(o_c), cap, ctypes.byref(n_out), ctypes.byref(ms))
+            if rc == _lib.ERR_TOO_LARGE and n_out.value > cap:
+                cap = int(n_out.value) + 1024
+                continue
+            _lib.check(rc)
+            break
+        self.kernel_ms = ms.value
+        n = n_out.value
+        out = {}
+        for r, v, c in zip(o_r[:n].tolist(), o_v[:n].tolist(), o_c[:n].tolist()):
+            d = out.setdefault(r, {})
+            vid = self.uniq_ids[v]
+            d[vid] = d.get(vid, 0) + c
+        return out
+
+    def select(self, names, seqs, min_matches=5, max_reads=2000):
+        """The bookkeeping of main.cc:284-331 on top of the GPU counts -> the reference's stdout text."""
+        counts = self.count_matches(seqs)
+        vntr_read_list, read_sequences = {}, {}
+        for r in sorted(counts):                                   # reads in file order
+            for vid in sorted(counts[r]):
+                lst = vntr_read_list.setdefault(vid, {})
+                if len(lst) > max_reads * 3:
+                    continue
+                if counts[r][vid] >= min_matches:
+                    lst[names[r]] = counts[r][vid]
+                    read_sequences[names[r]] = seqs[r]
+        out, filtered, acc = [], set(), {}
+        for vid in self.vntr_ids:
+            vec = acc.setdefault(vid, [])
+            for name in sorted(vntr_read_list.get(vid, {})):
+                vec.append((vntr_read_list[vid][name], name))
+            line = "%d %d" % (vid, min(len(vec), max_reads))
+            if vec:
+                vec.sort(reverse=True)
+                for j, (_, name) in enumerate(vec):
+                    filtered.add(name)
+                    line += " " + name
+                    if j >= max_reads:
+                        break
+            out.append(line)
+        for name in sorted(filtered):
+            out.append("%s %s" % (name, read_sequences[name]))
+        return "\n".join(out) + "\n"
+
+
+def run(fasta_text, keywords_text, min_matches=5):
+    """Drop-in for `adVNTR-Filtering reads.fa [--min_matches N] < keywords.txt`: returns its stdout text."""
+    lines = fasta_text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    names = [lines[k][1:] for k in range(0, len(lines) - 1, 2)]
+    seqs = [lines[k + 1] for k in range(0, len(lines) - 1, 2)]
+    f = KeywordFilter.from_text(keywords_text)
+    try:
+        return f.select(names, seqs, min_matches=min_matches)
+    finally:
+        f.close()
+
+
+def get_filtered_read_ids(fasta_text, vntr_keywords, min_matches=5):
+    """genome_analyzer.py:173-199: (reads [(name, seq)], {vid: set(read names)}) from {vid: keywords}."""
+    text = "".join("%s %s\n" % (vid, " ".join(sorted(k))) for vid, k in vntr_keywords.items())
+    vntr_read_ids = {vid: [] for vid in vntr_keywords}
+    reads = []
+    for line in run(fasta_text, text, min_matches).split("\n"):
+        parts = line.split()
+        if len(parts) < 2:
+            continue
+        if parts[0].isdigit() and parts[1].isdigit():
+            vntr_read_ids[int(parts[0])] = set(parts[2:])
+        else:
+            reads.append((parts[0], parts[1]))
+    return reads, vntr_read_ids

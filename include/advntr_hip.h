@@ -125,6 +125,22 @@ int advntr_batch_result_ptrs(advntr_batch *batch, void **d_logp, void **d_summar
 /* scratch / trellis bytes this batch holds in HBM (for DESIGN.md's layout accounting) */
 int64_t advntr_batch_device_bytes(const advntr_batch *batch);
 
+/* ---- keyword prefilter (the stage upstream of the scoring path) ------------------------------------
+ * Replaces the scan loop of the reference's adVNTR-Filtering binary (/root/reference/filtering/main.cc:
+ * automaton build :56-157, per-read matching :247-283).  Keywords: concatenated base codes 0..3 with offsets
+ * (lengths 1..29), kw_vntr[w] = caller's VNTR index of keyword w (the same string may belong to several VNTRs).
+ * scan(): reads as base codes 0..3, 4 = any other symbol (resets a match, main.cc:44-55); returns unordered
+ * (read, vntr, count) records with count >= 1 -- a read/vntr pair may be split over several records, sum them.
+ * The order-dependent selection and printing (main.cc:286-331) is host logic (advntr_amd/filtering.py).
+ * Returns ADVNTR_OK, or ADVNTR_ERR_TOO_LARGE with *n_out = records needed when capacity is too small.      */
+typedef struct advntr_kwfilter advntr_kwfilter;
+advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, const int64_t *kw_off, const int32_t *kw_vntr,
+                                        int32_t n_keywords);
+void advntr_kwfilter_destroy(advntr_kwfilter *filter);
+int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const int64_t *read_off, int32_t n_reads,
+                         int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity, int64_t *n_out,
+                         float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif
