@@ -791,9 +791,9 @@ extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, co
         KwfArgs a{};
         a.f = F->dev; a.bases = d_bases; a.read_off = d_off; a.n_reads = n_reads;
         a.out_read = d_r; a.out_vntr = d_v; a.out_count = d_c; a.n_out = d_n; a.capacity = capacity;
-        const int grid = std::max(1, std::min((n_reads + 255) / 256, device_cus() * 8));
+        const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus() * 2));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(KWF_BLOCK), 0, nullptr, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));

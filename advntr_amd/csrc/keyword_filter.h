@@ -39,10 +39,16 @@ struct KwfArgs {
     int64_t capacity;
 };
 
+// 32-bit mixing of the 64-bit packed key (two 32-bit multiplies; host and device must agree: the table and the
+// bit-set are built on the host with the same function).  Returns 64 bits: low half -> table slot, high -> bit-set.
 __host__ __device__ __forceinline__ uint64_t kwf_hash(uint64_t k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return k;
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    uint32_t x = lo ^ (hi * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    uint32_t y = (x ^ hi) * 0xC2B2AE35u;
+    y ^= y >> 16;
+    return ((uint64_t)y << 40) | x;
 }
 
 __device__ __forceinline__ void kwf_emit(const KwfArgs &a, int read, int vntr, int count)
@@ -55,12 +61,43 @@ __device__ __forceinline__ void kwf_emit(const KwfArgs &a, int read, int vntr, i
     }
 }
 
-__global__ void __launch_bounds__(256) keyword_filter_kernel(KwfArgs a)
+// tally one table hit (keyword string found): +1 for every VNTR that owns the string
+__device__ __forceinline__ void kwf_tally(const KwfArgs &a, const uint32_t v, const int r, int (&svid)[KWF_SLOTS],
+                                          int (&scnt)[KWF_SLOTS])
+{
+    const int first = (int)(v & 0xffffffu), cnt = (int)(v >> 24);
+    for (int q = 0; q < cnt; ++q) {
+        const int vid = a.f.ids[first + q];
+        bool done = false;
+#pragma unroll
+        for (int s = 0; s < KWF_SLOTS; ++s) {
+            if (!done && (svid[s] == vid || svid[s] < 0)) { svid[s] = vid; scnt[s] += 1; done = true; }
+        }
+        if (!done) kwf_emit(a, r, vid, 1);      // more than 4 VNTRs in one read: single events
+    }
+}
+
+__device__ __forceinline__ void kwf_probe(const KwfArgs &a, const uint64_t key, uint64_t slot, uint64_t k, const int r,
+                                          int (&svid)[KWF_SLOTS], int (&scnt)[KWF_SLOTS])
+{
+    for (;;) {
+        if (k == KWF_EMPTY) return;
+        if (k == key) { kwf_tally(a, a.f.vals[slot], r, svid, scnt); return; }
+        slot = (slot + 1) & a.f.table_mask;
+        k = a.f.keys[slot];
+    }
+}
+
+#define KWF_BLOCK 1024      // 16 waves share one 64 KiB bit-set: two workgroups fill a CU (32 waves)
+__global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
 {
     __shared__ uint32_t bits[KWF_BITSET_BITS / 32];
-    for (int i = threadIdx.x; i < (int)(KWF_BITSET_BITS / 32); i += 256) bits[i] = a.f.bitset[i];
+    for (int i = threadIdx.x; i < (int)(KWF_BITSET_BITS / 32); i += KWF_BLOCK) bits[i] = a.f.bitset[i];
     __syncthreads();
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < a.n_reads; r += gridDim.x * 256) {
+    const bool single = a.f.n_lengths == 1;
+    const int L0 = a.f.length[0];
+    const uint64_t mask0 = a.f.mask[0];
+    for (int r = blockIdx.x * KWF_BLOCK + threadIdx.x; r < a.n_reads; r += gridDim.x * KWF_BLOCK) {
         const uint8_t *seq = a.bases + a.read_off[r];
         const int n = (int)(a.read_off[r + 1] - a.read_off[r]);
         int svid[KWF_SLOTS], scnt[KWF_SLOTS];
@@ -68,37 +105,50 @@ __global__ void __launch_bounds__(256) keyword_filter_kernel(KwfArgs a)
         for (int s = 0; s < KWF_SLOTS; ++s) { svid[s] = -1; scnt[s] = 0; }
         uint64_t win = 0;
         int run = 0;                             // valid bases in the window
-        for (int p = 0; p < n; ++p) {
-            const unsigned c = seq[p];
-            if (c > 3u) { run = 0; win = 0; continue; }
-            win = (win << 2) | c;
-            ++run;
-            for (int li = 0; li < a.f.n_lengths; ++li) {
-                const int L = a.f.length[li];
-                if (run < L) continue;
-                const uint64_t key = (win & a.f.mask[li]) | ((uint64_t)L << 58);
-                const uint64_t h = kwf_hash(key);
-                const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
-                if (!((bits[b >> 5] >> (b & 31)) & 1u)) continue;
-                uint64_t slot = h & a.f.table_mask;
-                for (;;) {
-                    const uint64_t k = a.f.keys[slot];
-                    if (k == KWF_EMPTY) break;
-                    if (k == key) {
-                        const uint32_t v = a.f.vals[slot];
-                        const int first = (int)(v & 0xffffffu), cnt = (int)(v >> 24);
-                        for (int q = 0; q < cnt; ++q) {
-                            const int vid = a.f.ids[first + q];
-                            bool done = false;
+        for (int p0 = 0; p0 < n; p0 += 8) {      // 8 bases per (unaligned) global load
+            uint64_t word = 0;
+            if (p0 + 8 <= n) __builtin_memcpy(&word, seq + p0, 8);
+            else for (int q = 0; p0 + q < n; ++q) word |= (uint64_t)seq[p0 + q] << (8 * q);
+            if (single) {
+                // phase 1: keys + LDS bit-set test for 8 positions; phase 2: issue the table loads of the survivors
+                // together (memory-level parallelism instead of one dependent L2 round trip per base); phase 3: resolve
+                uint64_t key[8], slot[8], kk[8];
+                unsigned live = 0;
 #pragma unroll
-                            for (int s = 0; s < KWF_SLOTS; ++s) {
-                                if (!done && (svid[s] == vid || svid[s] < 0)) { svid[s] = vid; scnt[s] += 1; done = true; }
-                            }
-                            if (!done) kwf_emit(a, r, vid, 1);      // more than 4 VNTRs in one read: single events
-                        }
-                        break;
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
+                    const bool inside = p0 + q < n;
+                    if (!inside || c > 3u) { run = 0; win = 0; continue; }
+                    win = (win << 2) | c;
+                    ++run;
+                    if (run < L0) continue;
+                    key[q] = (win & mask0) | ((uint64_t)L0 << 58);
+                    const uint64_t h = kwf_hash(key[q]);
+                    const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
+                    if ((bits[b >> 5] >> (b & 31)) & 1u) { live |= 1u << q; slot[q] = h & a.f.table_mask; }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (live & (1u << q)) kk[q] = a.f.keys[slot[q]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (live & (1u << q)) kwf_probe(a, key[q], slot[q], kk[q], r, svid, scnt);
+            } else {
+                for (int q = 0; q < 8 && p0 + q < n; ++q) {
+                    const unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
+                    if (c > 3u) { run = 0; win = 0; continue; }
+                    win = (win << 2) | c;
+                    ++run;
+                    for (int li = 0; li < a.f.n_lengths; ++li) {
+                        const int L = a.f.length[li];
+                        if (run < L) continue;
+                        const uint64_t key = (win & a.f.mask[li]) | ((uint64_t)L << 58);
+                        const uint64_t h = kwf_hash(key);
+                        const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
+                        if (!((bits[b >> 5] >> (b & 31)) & 1u)) continue;
+                        const uint64_t slot = h & a.f.table_mask;
+                        kwf_probe(a, key, slot, a.f.keys[slot], r, svid, scnt);
                     }
-                    slot = (slot + 1) & a.f.table_mask;
                 }
             }
         }
