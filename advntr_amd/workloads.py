@@ -69,6 +69,52 @@ def s300(seed=20240601):
     return make_locus(np.random.default_rng(seed), 30, 12, 3, 0.05)
 
 
+def _c2_locus(args):
+    """One C2 locus (worker of make_c2's process pool): returns what the parent needs to upload the model."""
+    k, seed, read_len, mapped_mean, unmapped_mean = args
+    from .vntr_finder import get_copies_for_hmm, reverse_complement
+    rng = np.random.default_rng([seed, k])
+    plen = int(rng.integers(6, 101))
+    loc = make_locus(rng, read_len, plen, get_copies_for_hmm(read_len, plen), 0.05, n_units=int(rng.integers(2, 21)))
+    mapped = make_reads(rng, loc, int(rng.poisson(mapped_mean)), read_len, locus_fraction=0.9)
+    unmapped = make_reads(rng, loc, int(rng.poisson(unmapped_mean)), read_len, locus_fraction=0.5)
+    calls = mapped + unmapped + [reverse_complement(s) for s in unmapped]
+    return loc.model.baked_arrays(), calls
+
+
+class ArrayLocus(object):
+    """A locus known only through its baked arrays (built in a worker process)."""
+
+    def __init__(self, arrays):
+        self.arrays = arrays
+        self._dm = None
+
+    def device_model(self):
+        from . import _lib
+        if self._dm is None:
+            a = self.arrays
+            self._dm = _lib.DeviceModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], a["in_ptr"],
+                                        a["in_src"], a["in_logp"], a["emis_logp"], a["state_class"])
+        return self._dm
+
+
+def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None):
+    """make_c2 with the (Python) model construction spread over a process pool: 6719 loci take ~20 min on one core.
+    Per-locus seeds are independent of the worker count.  Returns ([ArrayLocus], reads, read_locus)."""
+    import multiprocessing as mp
+    import os
+    workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
+    jobs = [(k, seed, read_len, mapped_mean, unmapped_mean) for k in range(n_loci)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_c2_locus, jobs, chunksize=8)
+    loci, reads, which = [], [], []
+    for k, (arrays, calls) in enumerate(res):
+        loci.append(ArrayLocus(arrays))
+        reads += calls
+        which += [k] * len(calls)
+    return loci, reads, np.asarray(which, dtype=np.int32)
+
+
 def make_c2(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40):
     """Config C2/C3 of BASELINE.json at a chosen locus count: loci with pattern length U{6..100},
     2-20 reference repeat units (equal length, <= 2 substitutions => gap-free alignment), flank = read length,
