@@ -43,3 +43,16 @@ def test_scoring_without_gpu_fails_loudly():
     locus = workloads.make_locus(np.random.default_rng(1), 8, 5, 2)
     with pytest.raises(_lib.EngineError):
         locus.model.viterbi("ACGTACGT")
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is the checker: nothing under advntr_amd/ (Python or HIP sources) may import, include or load it."""
+    pkg = os.path.join(ROOT, "advntr_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|liboracle|oracle/", text, re.M):
+                    offenders.append(os.path.join(dirpath, fn))
+    assert offenders == []

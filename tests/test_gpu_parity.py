@@ -292,3 +292,17 @@ def test_pacbio_c4_style_loci_vs_oracle():
             assert logp[i] == olp
             assert paths[i] == opath
             assert summ[i][_lib.SUM_RU] == Or.number_of_repeats([names[j] for j in opath][1:-1])
+
+
+def test_empty_batch_and_argument_errors():
+    from advntr_amd import _lib, workloads
+    loc = workloads.make_locus(np.random.default_rng(1), 8, 5, 2)
+    dm = loc.model.device_model()
+    logp, summ, paths = _lib.viterbi_batch([dm], np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(0, np.int32),
+                                           want_paths=True)
+    assert len(logp) == 0 and paths == []
+    with pytest.raises(_lib.EngineError):                       # read_model out of range
+        _lib.viterbi_batch([dm], np.zeros(4, np.uint8), np.array([0, 4], np.int64), np.array([3], np.int32))
+    with pytest.raises(_lib.EngineError):                       # CSR that does not span its edges
+        _lib.DeviceModel(3, 1, 1, 2, np.array([0, 1, 1, 5], np.int32), np.array([1], np.int32), np.array([0.0]),
+                         np.zeros((1, 4)))
