@@ -715,6 +715,9 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     while (slots < groups.size() * 4) slots <<= 1;
     std::vector<uint64_t> keys(slots, KWF_EMPTY);
     std::vector<uint32_t> vals(slots, 0), bitset(KWF_BITSET_BITS / 32, 0);
+    size_t fp_slots = 4096;
+    while (fp_slots < groups.size() * 3 && fp_slots < (1u << 20)) fp_slots <<= 1;     // <= 2 MiB of uint16
+    std::vector<uint16_t> fps(fp_slots, 0);
     std::vector<int32_t> ids;
     for (auto &kv : groups) {
         if (kv.second.size() > 255 || ids.size() > 0xffffffu) {
@@ -724,7 +727,10 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
         const uint64_t h = kwf_hash(kv.first);
         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
         bitset[b >> 5] |= 1u << (b & 31);
-        size_t s = h & (slots - 1);
+        size_t fs = kwf_fp_slot(h, (uint32_t)(fp_slots - 1));
+        while (fps[fs] != 0) fs = (fs + 1) & (fp_slots - 1);
+        fps[fs] = kwf_fp(h);
+        size_t s = (h & 0xffffffffull) & (slots - 1);
         while (keys[s] != KWF_EMPTY) s = (s + 1) & (slots - 1);
         keys[s] = kv.first;
         vals[s] = (uint32_t)ids.size() | ((uint32_t)kv.second.size() << 24);
@@ -741,7 +747,8 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     };
     void *dk = up(keys.data(), keys.size() * 8), *dv = up(vals.data(), vals.size() * 4);
     void *di = up(ids.data(), ids.size() * 4), *db = up(bitset.data(), bitset.size() * 4);
-    if (!dk || !dv || !di || !db) {
+    void *df = up(fps.data(), fps.size() * 2);
+    if (!dk || !dv || !di || !db || !df) {
         fail(ADVNTR_ERR_DEVICE, "advntr_kwfilter_create: device upload failed");
         advntr_kwfilter_destroy(F);
         return nullptr;
@@ -754,6 +761,7 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     }
     D.table_mask = slots - 1;
     D.keys = (const uint64_t *)dk; D.vals = (const uint32_t *)dv; D.ids = (const int32_t *)di; D.bitset = (const uint32_t *)db;
+    D.fps = (const uint16_t *)df; D.fp_mask = (uint32_t)(fp_slots - 1);
     return F;
 }
 

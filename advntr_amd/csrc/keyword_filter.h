@@ -27,6 +27,8 @@ struct KwfDevice {
     const uint32_t *vals;                    // slots: first index into ids[] | count << 24
     const int32_t *ids;                      // vntr index per (keyword string, owner) pair
     const uint32_t *bitset;                  // KWF_BITSET_BITS / 32 words
+    const uint16_t *fps;                     // second-level filter: 16-bit fingerprints, open addressing (0 = free),
+    uint32_t fp_mask;                        // small enough (<= 2 MiB) to stay resident in every XCD's L2
 };
 
 struct KwfArgs {
@@ -49,6 +51,24 @@ __host__ __device__ __forceinline__ uint64_t kwf_hash(uint64_t k)
     uint32_t y = (x ^ hi) * 0xC2B2AE35u;
     y ^= y >> 16;
     return ((uint64_t)y << 40) | x;
+}
+
+// fingerprint of a key (never 0) and its home slot in the fingerprint table
+__host__ __device__ __forceinline__ uint16_t kwf_fp(uint64_t h) { return (uint16_t)(((h >> 24) & 0xffffu) | 1u); }
+__host__ __device__ __forceinline__ uint32_t kwf_fp_slot(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 8) & mask; }
+
+// true if the fingerprint table may hold the key (linear probing until a free slot)
+__device__ __forceinline__ bool kwf_fp_maybe(const KwfDevice &f, uint64_t h, uint16_t first)
+{
+    const uint16_t want = kwf_fp(h);
+    uint32_t s = kwf_fp_slot(h, f.fp_mask);
+    uint16_t v = first;
+    for (;;) {
+        if (v == 0) return false;
+        if (v == want) return true;
+        s = (s + 1) & f.fp_mask;
+        v = f.fps[s];
+    }
 }
 
 __device__ __forceinline__ void kwf_emit(const KwfArgs &a, int read, int vntr, int count)
@@ -105,34 +125,57 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
         for (int s = 0; s < KWF_SLOTS; ++s) { svid[s] = -1; scnt[s] = 0; }
         uint64_t win = 0;
         int run = 0;                             // valid bases in the window
-        for (int p0 = 0; p0 < n; p0 += 8) {      // 8 bases per (unaligned) global load
-            uint64_t word = 0;
-            if (p0 + 8 <= n) __builtin_memcpy(&word, seq + p0, 8);
-            else for (int q = 0; p0 + q < n; ++q) word |= (uint64_t)seq[p0 + q] << (8 * q);
-            if (single) {
-                // phase 1: keys + LDS bit-set test for 8 positions; phase 2: issue the table loads of the survivors
-                // together (memory-level parallelism instead of one dependent L2 round trip per base); phase 3: resolve
-                uint64_t key[8], slot[8], kk[8];
-                unsigned live = 0;
+        for (int pb = 0; pb < n; pb += 64) {     // one 64-byte sector of the read per outer step: every byte of the
+                                                 // read is fetched from HBM once (8-byte steps re-fetched evicted sectors)
+            uint64_t sector[8];
+            if (pb + 64 <= n) {
+                __builtin_memcpy(sector, seq + pb, 64);
+            } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
-                    const bool inside = p0 + q < n;
-                    if (!inside || c > 3u) { run = 0; win = 0; continue; }
-                    win = (win << 2) | c;
-                    ++run;
-                    if (run < L0) continue;
-                    key[q] = (win & mask0) | ((uint64_t)L0 << 58);
-                    const uint64_t h = kwf_hash(key[q]);
-                    const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
-                    if ((bits[b >> 5] >> (b & 31)) & 1u) { live |= 1u << q; slot[q] = h & a.f.table_mask; }
+                for (int w = 0; w < 8; ++w) {
+                    sector[w] = 0;
+                    if (pb + 8 * w + 8 <= n) __builtin_memcpy(&sector[w], seq + pb + 8 * w, 8);
+                    else for (int q = 0; pb + 8 * w + q < n; ++q) sector[w] |= (uint64_t)seq[pb + 8 * w + q] << (8 * q);
                 }
+            }
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (live & (1u << q)) kk[q] = a.f.keys[slot[q]];
+          for (int wi = 0; wi < 8; ++wi) {
+            const int p0 = pb + 8 * wi;
+            if (p0 >= n) break;
+            const uint64_t word = sector[wi];
+            if (single) {
+                // per half-word (4 positions): phase 1 keys + LDS bit-set test; phase 2 the fingerprint loads of the
+                // survivors issued together (memory-level parallelism instead of one dependent L2 round trip per
+                // base); phase 3 full-key probes of the (rare) fingerprint matches
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (live & (1u << q)) kwf_probe(a, key[q], slot[q], kk[q], r, svid, scnt);
+                for (int half = 0; half < 2; ++half) {
+                    uint64_t key[4], hh[4];
+                    uint16_t f0[4];
+                    unsigned live = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int qq = half * 4 + q;
+                        const unsigned c = (unsigned)(word >> (8 * qq)) & 0xffu;
+                        const bool inside = p0 + qq < n;
+                        if (!inside || c > 3u) { run = 0; win = 0; continue; }
+                        win = (win << 2) | c;
+                        ++run;
+                        if (run < L0) continue;
+                        key[q] = (win & mask0) | ((uint64_t)L0 << 58);
+                        const uint64_t h = kwf_hash(key[q]);
+                        const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
+                        if ((bits[b >> 5] >> (b & 31)) & 1u) { live |= 1u << q; hh[q] = h; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (live & (1u << q)) f0[q] = a.f.fps[kwf_fp_slot(hh[q], a.f.fp_mask)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((live & (1u << q)) && kwf_fp_maybe(a.f, hh[q], f0[q])) {
+                            const uint64_t slot = (hh[q] & 0xffffffffull) & a.f.table_mask;
+                            kwf_probe(a, key[q], slot, a.f.keys[slot], r, svid, scnt);
+                        }
+                }
             } else {
                 for (int q = 0; q < 8 && p0 + q < n; ++q) {
                     const unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
@@ -146,14 +189,34 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
                         const uint64_t h = kwf_hash(key);
                         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
                         if (!((bits[b >> 5] >> (b & 31)) & 1u)) continue;
-                        const uint64_t slot = h & a.f.table_mask;
+                        if (!kwf_fp_maybe(a.f, h, a.f.fps[kwf_fp_slot(h, a.f.fp_mask)])) continue;
+                        const uint64_t slot = (h & 0xffffffffull) & a.f.table_mask;
                         kwf_probe(a, key, slot, a.f.keys[slot], r, svid, scnt);
                     }
                 }
             }
+          }
         }
+        // wave-aggregated output: one atomic per wavefront and slot instead of one per record (a single device-wide
+        // counter saturates at ~88 atomics/us, MI355X_MICROARCH "dequeue" row)
 #pragma unroll
-        for (int s = 0; s < KWF_SLOTS; ++s)
-            if (svid[s] >= 0) kwf_emit(a, r, svid[s], scnt[s]);
+        for (int s = 0; s < KWF_SLOTS; ++s) {
+            const bool need = svid[s] >= 0;
+            const unsigned long long m = __ballot(need);
+            if (m == 0ull) continue;
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(a.n_out, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (need) {
+                const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)pos < a.capacity) {
+                    a.out_read[pos] = r;
+                    a.out_vntr[pos] = svid[s];
+                    a.out_count[pos] = scnt[s];
+                }
+            }
+        }
     }
 }
