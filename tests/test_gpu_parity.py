@@ -306,3 +306,45 @@ def test_empty_batch_and_argument_errors():
     with pytest.raises(_lib.EngineError):                       # CSR that does not span its edges
         _lib.DeviceModel(3, 1, 1, 2, np.array([0, 1, 1, 5], np.int32), np.array([1], np.int32), np.array([0.0]),
                          np.zeros((1, 4)))
+
+
+def test_full_size_c1_properties():
+    """BASELINE config C1 at full size (REF150 x 100 000 reads): size-independent properties instead of an oracle
+    replay -- run-to-run determinism, the two kernels agree on a subsample, permutation invariance (results do not
+    depend on batch order / tiling), every log-prob finite and <= 0, path length consistent with the summaries, and a
+    checksum of the RU counts that must not depend on how the batch is split."""
+    from advntr_amd import _lib, workloads
+    loc = workloads.ref150()
+    reads = workloads.make_reads(np.random.default_rng(20240601), loc, 100000, 150)
+    bases, off = _lib.encode_reads(reads)
+    dm = loc.model.device_model()
+    which = np.zeros(len(reads), np.int32)
+    B = _lib.DeviceBatch([dm], bases, off, which)
+    B.run()
+    logp, summ = B.fetch()
+    B.run()
+    logp2, summ2 = B.fetch()
+    B.close()
+    assert np.array_equal(logp, logp2) and np.array_equal(summ, summ2)              # idempotent / deterministic
+    assert np.all(np.isfinite(logp)) and np.all(logp <= 0)
+    assert np.all(summ[:, _lib.SUM_PATH_LEN] >= 150 + 2)                             # >= n emitting states + start/end
+    assert np.all(summ[:, _lib.SUM_MATCHES] <= 150) and np.all(summ[:, _lib.SUM_REPEAT_BP] <= 150)
+    assert np.all(summ[:, _lib.SUM_LEFT_BP] + summ[:, _lib.SUM_RIGHT_BP] + summ[:, _lib.SUM_REPEAT_BP] == 150)
+    # permutation + split invariance: shuffle, score in two halves, un-shuffle
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(reads))
+    halves = [perm[:37123], perm[37123:]]
+    got = np.zeros_like(logp)
+    got_ru = np.zeros(len(reads), np.int64)
+    for h in halves:
+        hb, ho = _lib.encode_reads([reads[i] for i in h])
+        lp, sm, _ = _lib.viterbi_batch([dm], hb, ho, np.zeros(len(h), np.int32))
+        got[h] = lp
+        got_ru[h] = sm[:, _lib.SUM_RU]
+    assert np.array_equal(got, logp)
+    assert int(got_ru.sum()) == int(summ[:, _lib.SUM_RU].sum())                      # checksum of checksums
+    # generic kernel == column kernel on a subsample
+    idx = rng.choice(len(reads), 3000, replace=False)
+    sb, so = _lib.encode_reads([reads[i] for i in idx])
+    lp_g, sm_g, _ = _lib.viterbi_batch([dm], sb, so, np.zeros(len(idx), np.int32), flags=_lib.FLAG_FORCE_GENERIC)
+    assert np.array_equal(lp_g, logp[idx]) and np.array_equal(sm_g, summ[idx])
