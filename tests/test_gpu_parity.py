@@ -348,3 +348,31 @@ def test_full_size_c1_properties():
     sb, so = _lib.encode_reads([reads[i] for i in idx])
     lp_g, sm_g, _ = _lib.viterbi_batch([dm], sb, so, np.zeros(len(idx), np.int32), flags=_lib.FLAG_FORCE_GENERIC)
     assert np.array_equal(lp_g, logp[idx]) and np.array_equal(sm_g, summ[idx])
+
+
+@pytest.mark.parametrize("mode", ["columns", "stream"])
+def test_random_locus_shapes_vs_oracle(mode):
+    """Shape sweep: random flank / pattern / copies (incl. a single copy: no fan-in state) / error rates / multi-row
+    profiles, ragged read lengths 1..320 (1-4 chunks, row tiles, tiny models that use the range-checked sweep)."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(4242)
+    flags = _lib.FLAG_STREAM if mode == "stream" else 0
+    for trial in range(10):
+        flank = int(rng.integers(3, 60))
+        plen = int(rng.integers(2, 30))
+        copies = int(rng.integers(1, 8))
+        loc = workloads.make_locus(rng, flank, plen, copies, float(rng.choice([0.05, 0.3])), n_units=int(rng.integers(1, 5)))
+        dm = loc.model.device_model()
+        assert dm.has_column_program()
+        reads = [workloads.make_reads(rng, loc, 1, int(n))[0] for n in rng.integers(1, 321, 24)]
+        bases, off = _lib.encode_reads(reads)
+        logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags, want_paths=True)
+        a = loc.model.baked_arrays()
+        edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+                 for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+        for i, r in enumerate(reads):
+            olp, opath = O.viterbi(r)
+            assert logp[i] == olp, (trial, flank, plen, copies, len(r))
+            assert paths[i] == opath, (trial, flank, plen, copies, len(r))
