@@ -60,7 +60,7 @@ struct TailEdge {             // in-edge of a tail state, reference evaluation o
 struct ColProgram {
     int32_t n_cols, n_tclass, n_eclass, n_tail, n_sinks, end_tail, m, P;
     int32_t off_class, off_emis, off_info, off_state, off_pred0, off_tail_ptr, off_tail_state, off_tail_edge;
-    int32_t off_v0, lds_bytes, pad0, pad1;
+    int32_t off_v0, lds_bytes, off_fwd, pad1;     // off_fwd: n_cols x {fwd row-0 value of b_c, fwd entry term of M_c}
 };
 
 struct ColProgramHost {
@@ -76,6 +76,9 @@ struct ColProgramHost {
     std::vector<int32_t> tail_state, tail_ptr;
     std::vector<TailEdge> tail_edges;
     int32_t end_tail = -1;
+    // sum-product (forward) twin of v0b / mX: row-0 forward values and the entry term v0f[x] + logp per column
+    std::vector<double> fwd;               // n_cols * 2
+    std::vector<double> fv0;               // per silent state
 
     size_t lds_bytes() const
     {
@@ -106,6 +109,7 @@ struct ColProgramHost {
         h.off_tail_ptr = add(tail_ptr.data(), tail_ptr.size() * sizeof(int32_t));
         h.off_tail_state = add(tail_state.data(), tail_state.size() * sizeof(int32_t));
         h.off_tail_edge = add(tail_edges.data(), tail_edges.size() * sizeof(TailEdge));
+        h.off_fwd = add(fwd.data(), fwd.size() * sizeof(double));
         memcpy(out.data(), &h, sizeof h);
         return out;
     }
@@ -182,6 +186,27 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         out.pred0[l - P] = bs;
     }
 
+    // ---- row 0 of the forward (sum-product) recursion: hmm.pyx:1403-1427, pair_lse utils.pyx:72-90
+    auto lse2h = [](double x, double y) {
+        if (x == INFINITY || y == INFINITY) return (double)INFINITY;
+        if (x == -INFINITY) return y;
+        if (y == -INFINITY) return x;
+        if (x > y) return x + std::log(std::exp(y - x) + 1);
+        return y + std::log(std::exp(x - y) + 1);
+    };
+    out.fv0.assign(S, NINF);
+    out.fv0[H.start - P] = 0.0;
+    for (int l = P; l < m; ++l) {
+        if (l == H.start) continue;
+        double lp = NINF;
+        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) {
+            const int ki = in_src[k];
+            if (ki < P || ki >= l) continue;
+            lp = lse2h(lp, out.fv0[ki - P] + in_logp[k]);
+        }
+        out.fv0[l - P] = lp;
+    }
+
     // ---- reachable from an emitting state (=> may be alive in rows >= 1)
     std::vector<char> live(m, 0);
     for (int l = 0; l < P; ++l) live[l] = 1;
@@ -249,6 +274,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     std::vector<ColState> st(NC);
     std::vector<uint16_t> flags(NC, 0);
     std::vector<int> feed_sink(NC, -1);
+    std::vector<double> fwd_mx(NC, NINF);
     int n_sinks = 0;
     for (int c = 0; c < NC; ++c) {
         ColClass &T = percol[c];
@@ -291,7 +317,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
                 if (w == 0) T.mI = in_logp[k];
                 else if (w == 1) T.mM = in_logp[k];
                 else if (w == 3) T.mD = in_logp[k];
-                else { T.mX = out.v0[s - P] + in_logp[k]; st[c].sX = s; }   // (v + t), e is added on device
+                else { T.mX = out.v0[s - P] + in_logp[k]; st[c].sX = s; fwd_mx[c] = out.fv0[s - P] + in_logp[k]; }   // (v + t), e is added on device
             }
         }
         // backbone state
@@ -428,6 +454,11 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         Sx = st[c];
     }
     if (out.classes.size() > 60000 || out.emis.size() / COL_EMIS_STRIDE > 60000) return fail("class table overflow");
+    out.fwd.resize((size_t)NC * 2);
+    for (int c = 0; c < NC; ++c) {
+        out.fwd[2 * c] = out.fv0[backbone[c] - P];
+        out.fwd[2 * c + 1] = fwd_mx[c];
+    }
     out.n_cols = NC;
     out.n_sinks = n_sinks;
     if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");

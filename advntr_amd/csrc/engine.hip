@@ -645,12 +645,24 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
     if (!out_logp && n_reads) return fail(ADVNTR_ERR_ARG, "advntr_forward_batch: out_logp is null");
     advntr_batch *B = new advntr_batch();
     int rc = batch_build(B, models, n_models, bases, read_off, read_model, n_reads,
-                         (flags | ADVNTR_FLAG_FORCE_GENERIC | ADVNTR_FLAG_NO_SUMMARY) & ~ADVNTR_FLAG_PATH);
+                         (flags | ADVNTR_FLAG_NO_SUMMARY) & ~(ADVNTR_FLAG_PATH | ADVNTR_FLAG_STREAM));
     if (rc == ADVNTR_OK && n_reads) {
         rc = [&]() -> int {
             HIP_TRY(hipMemsetAsync(B->d_counter, 0, 8 * sizeof(int32_t), B->stream));
-            BatchArgs a = generic_args(B);
-            hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a);
+            if (B->n_col) {               // reads of models with a column program: sum-product on the anti-diagonal sweep
+                BatchArgs a = make_args(B);
+                a.n_reads = B->n_col;
+                a.order = B->d_order;
+                column_launch_fwd<1, false>(B->col, a, B->stream);
+                column_launch_fwd<2, false>(B->col, a, B->stream);
+                column_launch_fwd<3, false>(B->col, a, B->stream);
+                column_launch_fwd<4, false>(B->col, a, B->stream);
+                column_launch_fwd<4, true>(B->col, a, B->stream);
+            }
+            if (B->n_gen) {
+                BatchArgs a = generic_args(B);
+                hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a);
+            }
             HIP_TRY(hipGetLastError());
             return ADVNTR_OK;
         }();

@@ -8,14 +8,20 @@
 #pragma once
 #include "viterbi_generic.h"
 
+#ifndef ADVNTR_LSE2_DEFINED
+#define ADVNTR_LSE2_DEFINED
 __device__ __forceinline__ double lse2(double x, double y)
 {
-    if (x == INFINITY || y == INFINITY) return INFINITY;
-    if (x == -INFINITY) return y;
-    if (y == -INFINITY) return x;
-    if (x > y) return x + log(exp(y - x) + 1.0);
-    return y + log(exp(x - y) + 1.0);
+    // branch-free form of the same expression: hi + log(exp(lo - hi) + 1) with hi/lo picked exactly as the
+    // reference's (x > y) test does; the -inf / +inf cases are selects, so a wavefront never diverges here
+    const bool xg = x > y;
+    const double hi = xg ? x : y, lo = xg ? y : x;
+    double r = hi + log(exp(lo - hi) + 1.0);
+    r = (lo == -INFINITY) ? hi : r;
+    r = (x == INFINITY || y == INFINITY) ? INFINITY : r;
+    return r;
 }
+#endif
 
 __device__ __forceinline__ void forward_silent_pass(const DevModel &M, double *cur, int t, int lane)
 {

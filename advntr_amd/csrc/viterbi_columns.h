@@ -87,6 +87,22 @@ __device__ __forceinline__ void relax_gt(double &best, int &ptr, const double ca
                  : "v"(cand), "v"(code));
 }
 
+#ifndef ADVNTR_LSE2_DEFINED
+#define ADVNTR_LSE2_DEFINED
+// pair_lse of the reference (utils.pyx:72-90)
+__device__ __forceinline__ double lse2(double x, double y)
+{
+    // branch-free form of the same expression: hi + log(exp(lo - hi) + 1) with hi/lo picked exactly as the
+    // reference's (x > y) test does; the -inf / +inf cases are selects, so a wavefront never diverges here
+    const bool xg = x > y;
+    const double hi = xg ? x : y, lo = xg ? y : x;
+    double r = hi + log(exp(lo - hi) + 1.0);
+    r = (lo == -INFINITY) ? hi : r;
+    r = (x == INFINITY || y == INFINITY) ? INFINITY : r;
+    return r;
+}
+#endif
+
 struct LdsTables {
     const ColClass *classes;
     const double *emis;
@@ -122,6 +138,7 @@ struct TileCtx {
     double *seam_out;          // last row of a full tile -> next tile's seam
     int64_t cap_stride;        // doubles between the capture buffers of the reads that end in this tile
     unsigned hasfirst, haslast; // bit k: chunk k holds a first / last row of some read
+    const double *fwd;         // sum-product kernel: per column {row-0 forward value of b_c, entry term of M_c}
 };
 
 __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
@@ -140,7 +157,7 @@ __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
 //          in row 1 (chunk 0, lane 0);
 // MODE 1 = continuation tile of a long read: row 0 of the tile is the previous tile's last row (seam);
 // MODE 2 = stream tile: several reads packed back to back along the row axis, first/last rows flagged per lane.
-template <int K, bool CHECKED, int MODE>
+template <int K, bool CHECKED, int MODE, bool FWD = false>
 __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTables &L, const TileCtx &C, const int s,
                                          const int lane, const double injI, const double injM, const double injB)
 {
@@ -164,6 +181,12 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     }
     const unsigned tclass = meta.x & 0xffffu, emM = meta.x >> 16, emI = meta.y & 0xffffu;
     const ColClass *T = L.classes + tclass;
+    double fwd_mX = -INFINITY;
+    if (FWD && MODE == 0 && k == 0) {            // row 0 / entry terms of the sum-product recursion (lane 0 only)
+        const int cq = min(max(c, 0), NC - 1);
+        v0b = C.fwd[2 * cq];
+        fwd_mX = C.fwd[2 * cq + 1];
+    }
     // previous row, same column: the neighbouring lane's values of the previous step
     double nI, nM, nB;
     if (k == 0) {
@@ -191,21 +214,33 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     }
     const double eI = L.emis[emI * COL_EMIS_STRIDE + R.x[k]];
     const double eM = L.emis[emM * COL_EMIS_STRIDE + R.x[k]];
+    double vI, vM, vB;
+    int pi = 0, pm = 0, pb = 0;
+    if (FWD) {
+        // sum-product: pair_lse folds in the reference's in-edge order (hmm.pyx:1429-1480), emission added last
+        vI = lse2(lse2(nI + T->iI, nM + T->iM), nB + T->iD) + eI;
+        double accM = lse2(R.pI[k] + T->mI, R.pM[k] + T->mM);
+        if (MODE == 0 && k == 0) accM = lse2(accM, (t == 1) ? fwd_mX : -INFINITY);
+        vM = lse2(accM, R.pB[k] + T->mD) + eM;
+        vB = lse2(lse2(R.I[k] + T->dI, R.M[k] + T->dM), R.B[k] + T->dD);
+        const unsigned flf = meta.y >> 16;
+        if (__ballot((flf & 3u) != 0)) {
+            if (flf & COL_FLAG_SINK) { vB = R.er[k]; R.er[k] = -INFINITY; }
+            if (flf & COL_FLAG_FEED) R.er[k] = lse2(R.er[k], vB + T->erw);
+        }
+    } else {
     // I_c(t) <- [I_c, M_c, b_c](t-1)
-    double vI = (nI + T->iI) + eI;
-    int pi = 0;
+    vI = (nI + T->iI) + eI;
     relax_gt(vI, pi, (nM + T->iM) + eI, 1);
     relax_gt(vI, pi, (nB + T->iD) + eI, 2);
     // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); the entry edge X only exists for row 1 (chunk 0, lane 0)
-    double vM = (R.pI[k] + T->mI) + eM;
-    int pm = 0;
+    vM = (R.pI[k] + T->mI) + eM;
     relax_gt(vM, pm, (R.pM[k] + T->mM) + eM, 1);
     if (MODE == 0 && k == 0) relax_gt(vM, pm, ((t == 1) ? T->mX : -INFINITY) + eM, 2);
     if (chunk_first) relax_gt(vM, pm, (first_row ? T->mX : -INFINITY) + eM, 2);
     relax_gt(vM, pm, (R.pB[k] + T->mD) + eM, 3);
     // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
-    double vB = R.I[k] + T->dI;
-    int pb = 0;
+    vB = R.I[k] + T->dI;
     relax_gt(vB, pb, R.M[k] + T->dM, 1);
     relax_gt(vB, pb, R.B[k] + T->dD, 2);
     const unsigned fl = meta.y >> 16;
@@ -221,10 +256,11 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
             if (cand > R.er[k]) { R.er[k] = cand; R.erwin[k] = c; }
         }
     }
+    }
     R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
     R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
 #ifndef EXP_NO_BP
-    C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+    if (!FWD) C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
 #endif
     if (MODE == 2) {
         if (k == K - 1) {                                            // last row of a full tile -> next tile's seam
@@ -270,7 +306,7 @@ __device__ __forceinline__ void seam_fetch(ColRegs<K> &R, const TileCtx &C, cons
     injB = readlane_f64(R.sB, j);
 }
 
-template <int K, int KLO, int KHI, int MODE>
+template <int K, int KLO, int KHI, int MODE, bool FWD = false>
 __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int s1, const LdsTables &L, const TileCtx &C,
                                           const int lane)
 {
@@ -285,11 +321,11 @@ __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int
         double injI = 0, injM = 0, injB = 0;
         if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
-        for (int k = KHI; k >= KLO; --k) col_cell<K, false, MODE>(R, k, L, C, s, lane, injI, injM, injB);
+        for (int k = KHI; k >= KLO; --k) col_cell<K, false, MODE, FWD>(R, k, L, C, s, lane, injI, injM, injB);
     }
 }
 
-template <int K, int MODE>
+template <int K, int MODE, bool FWD = false>
 __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded, const TileCtx &C,
                                           const uint8_t *__restrict__ seq_tile, const int lane,
                                           const int *slot_x = nullptr, const int *slot_flag = nullptr)
@@ -320,13 +356,13 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
     if (padded && NC + 63 >= 64 * (K - 1) + 1) {
         // chunk k is busy for steps [64k+1, 64k+64+NC-1]: ramp-up phases, a branch-free steady state with all
         // chunks in one basic block (independent dependency chains interleave), ramp-down phases
-        if (K >= 2) col_phase<K, 0, 0, MODE>(R, 1, min(s_end, 64), L, C, lane);
-        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0), MODE>(R, 65, min(s_end, 128), L, C, lane);
-        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0), MODE>(R, 129, min(s_end, 192), L, C, lane);
-        col_phase<K, 0, K - 1, MODE>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, C, lane);
-        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1, MODE>(R, NC + 64, min(s_end, NC + 127), L, C, lane);
-        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1, MODE>(R, NC + 128, min(s_end, NC + 191), L, C, lane);
-        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1, MODE>(R, NC + 192, min(s_end, NC + 255), L, C, lane);
+        if (K >= 2) col_phase<K, 0, 0, MODE, FWD>(R, 1, min(s_end, 64), L, C, lane);
+        if (K >= 3) col_phase<K, 0, (K >= 3 ? 1 : 0), MODE, FWD>(R, 65, min(s_end, 128), L, C, lane);
+        if (K >= 4) col_phase<K, 0, (K >= 4 ? 2 : 0), MODE, FWD>(R, 129, min(s_end, 192), L, C, lane);
+        col_phase<K, 0, K - 1, MODE, FWD>(R, 64 * (K - 1) + 1, min(s_end, NC + 63), L, C, lane);
+        if (K >= 2) col_phase<K, (K >= 2 ? 1 : 0), K - 1, MODE, FWD>(R, NC + 64, min(s_end, NC + 127), L, C, lane);
+        if (K >= 3) col_phase<K, (K >= 3 ? 2 : 0), K - 1, MODE, FWD>(R, NC + 128, min(s_end, NC + 191), L, C, lane);
+        if (K >= 4) col_phase<K, (K >= 4 ? 3 : 0), K - 1, MODE, FWD>(R, NC + 192, min(s_end, NC + 255), L, C, lane);
     } else {
         for (int s = 1; s <= s_end; ++s) {
             double injI = 0, injM = 0, injB = 0;
@@ -334,7 +370,7 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform
-                col_cell<K, true, MODE>(R, k, L, C, s, lane, injI, injM, injB);
+                col_cell<K, true, MODE, FWD>(R, k, L, C, s, lane, injI, injM, injB);
             }
         }
     }
@@ -620,6 +656,110 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
 
 
 // ------------------------------------------------------------------------------------------------
+// Sum-product (Model.log_probability) on the column program: the same sweep with pair_lse instead of max, no
+// back-pointers, no traceback.  Tail states: fold over the emitting-sourced in-edges, fold over the silent-sourced
+// ones, lse of the two (hmm.pyx:1446-1480), wave-parallel (the fold order inside each group differs from the
+// reference's, so results agree to rounding; tests allow 1e-9 relative, the north star 1e-4).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double col_tail_forward(const ColProgram *__restrict__ cp, double *__restrict__ rown, const int NC,
+                                                   const int lane)
+{
+    const uint8_t *base = (const uint8_t *)cp;
+    const int32_t *tptr = (const int32_t *)(base + cp->off_tail_ptr);
+    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
+    double *tailv = rown + 3 * NC;
+    double result = -INFINITY;
+    for (int i = 0; i < cp->n_tail; ++i) {
+        double pe = -INFINITY, ps = -INFINITY;
+        for (int e = tptr[i] + lane; e < tptr[i + 1]; e += 64) {
+            const TailEdge ed = edges[e];
+            if (ed.loc >= 0) {
+                const double v = rown[(ed.loc >> 2) * 3 + (ed.loc & 3)] + ed.logp;
+                if ((ed.loc & 3) < 2) pe = lse2(pe, v); else ps = lse2(ps, v);
+            } else {
+                ps = lse2(ps, tailv[-ed.loc - 1] + ed.logp);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pe = lse2(pe, __shfl_xor(pe, o, 64));
+            ps = lse2(ps, __shfl_xor(ps, o, 64));
+        }
+        const double v = lse2(pe, ps);
+        if (lane == 0) tailv[i] = v;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        if (i == cp->end_tail) result = v;
+    }
+    return result;
+}
+
+template <int K, bool LONG>
+__global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int TPAD = 64 * K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
+    int32_t *tile_slot = (int32_t *)lds;
+    uint8_t *tables = lds + 16;
+    double *rown = g.rown + gw * g.rown_stride;
+    int cur_model = -1;
+    bool padded = false;
+    LdsTables L{};
+    const ColProgram *cp = nullptr;
+    DevModel M{};
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
+        __syncthreads();
+        const int ti = *tile_slot;
+        if (ti >= g.n_tiles) break;
+        const ColTile tile = g.tiles[ti];
+        if (tile.model != cur_model) {
+            cur_model = tile.model;
+            M = g.a.models[cur_model];
+            cp = M.cols;
+            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
+        }
+        const int NC = cp->n_cols;
+        for (int j = wave; j < tile.count; j += COL_WAVES) {
+            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
+            const uint8_t *seq = g.a.bases + g.a.read_off[r];
+            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
+            TileCtx C;
+            C.NC = NC; C.sink_stride = 0; C.sinkbp = nullptr; C.bp = nullptr;
+            C.fwd = (const double *)((const uint8_t *)cp + cp->off_fwd);
+            double *final_row = rown;
+            if (!LONG) {
+                C.n_tile = n; C.row0 = 0; C.cap = rown; C.seam = nullptr;
+                col_sweep<K, 0, true>(L, padded, C, seq, lane);
+            } else {
+                double *buf[2] = {rown, rown + 3 * (int64_t)NC + COL_MAX_TAIL};
+                const int n_tiles = (n + TPAD - 1) / TPAD;
+                for (int i = 0; i < n_tiles; ++i) {
+                    C.row0 = i * TPAD;
+                    C.n_tile = min(TPAD, n - C.row0);
+                    C.cap = buf[(i + 1) & 1];
+                    C.seam = buf[i & 1];
+                    if (i == 0) col_sweep<K, 0, true>(L, padded, C, seq, lane);
+                    else col_sweep<K, 1, true>(L, padded, C, seq + i * TPAD, lane);
+                    __threadfence_block();
+                    __builtin_amdgcn_wave_barrier();
+                }
+                final_row = buf[n_tiles & 1];
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            const double logp = col_tail_forward(cp, final_row, NC, lane);
+            if (lane == 0) g.a.out_logp[r] = logp;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stream kernel: a wavefront packs its reads back to back along the row axis and sweeps the stream in row
 // tiles of 64*K rows, so every lane carries a useful row (a 150-base read otherwise fills 150 of 192 lanes).
 // Read boundaries inside a tile are per-lane flags (first row: previous row := the model's row 0, entry edges
@@ -819,4 +959,20 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     const int grid = std::min(cl.grid, g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
     hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
+}
+
+template <int K, bool LONG>
+static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream)
+{
+    const int slot = LONG ? 4 : K - 1;
+    if (cl.tiles[slot].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g);
 }

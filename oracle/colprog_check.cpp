@@ -142,3 +142,57 @@ extern "C" double colprog_viterbi(void *p, const uint8_t *seq, int n, int32_t *p
     *len_out = len;
     return logp;
 }
+
+// Sum-product twin: evaluates the column program with pair_lse exactly as the forward kernel does (same fold order).
+static double lse2c(double x, double y)
+{
+    if (x == INFINITY || y == INFINITY) return INFINITY;
+    if (x == -INFINITY) return y;
+    if (y == -INFINITY) return x;
+    if (x > y) return x + std::log(std::exp(y - x) + 1);
+    return y + std::log(std::exp(x - y) + 1);
+}
+
+extern "C" double colprog_forward(void *p, const uint8_t *seq, int n)
+{
+    const Handle *h = (const Handle *)p;
+    const ColProgramHost &g = h->prog;
+    const int NC = g.n_cols;
+    const double NINF = -INFINITY;
+    if (!g.valid || n < 1) return NAN;
+    std::vector<double> pI(NC, NINF), pM(NC, NINF), pB(NC), cI(NC), cM(NC), cB(NC);
+    for (int c = 0; c < NC; ++c) pB[c] = g.fwd[2 * c];
+    for (int t = 1; t <= n; ++t) {
+        const int x = seq[t - 1];
+        double er = NINF;
+        for (int c = 0; c < NC; ++c) {
+            const ColInfo &inf = g.info[c + 1];
+            const ColClass &T = g.classes[inf.tclass];
+            const double eI = g.emis[inf.emI * COL_EMIS_STRIDE + x], eM = g.emis[inf.emM * COL_EMIS_STRIDE + x];
+            const double qI = c ? pI[c - 1] : NINF, qM = c ? pM[c - 1] : NINF, qB = c ? pB[c - 1] : NINF;
+            const double oI = c ? cI[c - 1] : NINF, oM = c ? cM[c - 1] : NINF, oB = c ? cB[c - 1] : NINF;
+            double vI = lse2c(lse2c(pI[c] + T.iI, pM[c] + T.iM), pB[c] + T.iD) + eI;
+            double vM = lse2c(lse2c(lse2c(qI + T.mI, qM + T.mM), (t == 1) ? g.fwd[2 * c + 1] : NINF), qB + T.mD) + eM;
+            double vB = lse2c(lse2c(oI + T.dI, oM + T.dM), oB + T.dD);
+            const unsigned fl = inf.flags;
+            if (fl & COL_FLAG_SINK) { vB = er; er = NINF; }
+            if (fl & COL_FLAG_FEED) er = lse2c(er, vB + T.erw);
+            cI[c] = vI; cM[c] = vM; cB[c] = vB;
+        }
+        pI.swap(cI); pM.swap(cM); pB.swap(cB);
+    }
+    std::vector<double> tailv(g.tail_state.size(), NINF);
+    for (size_t i = 0; i < g.tail_state.size(); ++i) {
+        double pe = NINF, ps = NINF;                  // emitting-sourced fold, then silent-sourced fold (hmm.pyx:1446-1480)
+        for (int e = g.tail_ptr[i]; e < g.tail_ptr[i + 1]; ++e) {
+            const TailEdge &ed = g.tail_edges[e];
+            if (ed.loc >= 0) {
+                const int c = ed.loc >> 2, sl = ed.loc & 3;
+                const double v = (sl == 0 ? pI[c] : sl == 1 ? pM[c] : pB[c]) + ed.logp;
+                if (sl < 2) pe = lse2c(pe, v); else ps = lse2c(ps, v);
+            } else ps = lse2c(ps, tailv[-ed.loc - 1] + ed.logp);
+        }
+        tailv[i] = lse2c(pe, ps);
+    }
+    return tailv[g.end_tail];
+}

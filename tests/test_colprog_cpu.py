@@ -23,6 +23,8 @@ def checker():
     L.colprog_why.restype = ctypes.c_char_p
     L.colprog_why.argtypes = [ctypes.c_void_p]
     L.colprog_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.colprog_forward.restype = ctypes.c_double
+    L.colprog_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.colprog_viterbi.restype = ctypes.c_double
     L.colprog_viterbi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                   ctypes.c_void_p]
@@ -104,3 +106,24 @@ def test_random_loci_vs_oracle():
             assert logp == olp, (trial, s)
             assert path[:ln.value][::-1].tolist() == opath, (trial, s)
         L.colprog_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["toy_f8_l5_c2", "s300_f30_l12_c3", "msa8_f50_c4"])
+def test_forward_on_column_program_matches_reference(name):
+    """Sum-product evaluation of the column program (fold order of the forward kernel) vs the reference's
+    log_probability values: same libm, so agreement is at rounding level (the fold order differs only for the
+    fan-in states)."""
+    L = checker()
+    g = load_golden(name)
+    h, O = compile_golden(L, g)
+    assert L.colprog_valid(h)
+    n_checked = 0
+    for r in g["reads"]:
+        if "forward_logp" not in r or len(r["seq"]) < 1:
+            continue
+        codes = encode(r["seq"])
+        got = L.colprog_forward(h, codes.ctypes.data, len(codes))
+        assert abs(got - r["forward_logp"]) <= 1e-10 * max(1.0, abs(r["forward_logp"])), (name, r["seq"])
+        n_checked += 1
+    assert n_checked > 10
+    L.colprog_destroy(h)

@@ -376,3 +376,27 @@ def test_random_locus_shapes_vs_oracle(mode):
             olp, opath = O.viterbi(r)
             assert logp[i] == olp, (trial, flank, plen, copies, len(r))
             assert paths[i] == opath, (trial, flank, plen, copies, len(r))
+
+
+def test_forward_column_kernel_vs_generic_and_oracle():
+    """log_probability on the column program (sum-product sweep, row tiles for long reads) against the generic
+    forward kernel and the CPU oracle: rounding-level agreement (1e-9 relative; north-star bar 1e-4)."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(8)
+    loc = workloads.make_locus(rng, 60, 17, 5, n_units=3)
+    reads = workloads.make_reads(rng, loc, 200, 150) + [workloads.rand_seq(rng, n) for n in (1, 2, 63, 64, 65, 257, 400, 700)]
+    dm = loc.model.device_model()
+    bases, off = _lib.encode_reads(reads)
+    which = np.zeros(len(reads), np.int32)
+    col = _lib.forward_batch([dm], bases, off, which)
+    gen = _lib.forward_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC)
+    assert np.all(np.abs(col - gen) <= 1e-9 * np.maximum(1.0, np.abs(gen)))
+    a = loc.model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    for i in list(range(0, 200, 9)) + list(range(200, len(reads))):
+        want = O.forward(reads[i])
+        assert abs(col[i] - want) <= 1e-9 * max(1.0, abs(want)), (i, len(reads[i]))
+        assert col[i] >= _lib.viterbi_batch([dm], *_lib.encode_reads([reads[i]]), np.zeros(1, np.int32))[0][0] - 1e-9
