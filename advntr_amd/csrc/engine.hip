@@ -427,8 +427,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 i = j;
             }
             const int kmax = std::min(4, (n_max_col + 63) / 64);
-            const int row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + COL_MAX_READ - 1) / COL_MAX_READ : 1;
-            C.bp_stride = ((row_tiles * (int64_t)(64 * kmax + C.nc_max) * (64 * kmax)) + 255) & ~int64_t(255);
+            const int TL = 64 * COL_LONG_K;
+            const int64_t row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + TL - 1) / TL : 0;
+            const int64_t short_bp = (int64_t)(64 * kmax + C.nc_max) * (64 * kmax), long_bp = row_tiles * (int64_t)(TL + C.nc_max) * TL;
+            C.bp_stride = (std::max(short_bp, long_bp) + 255) & ~int64_t(255);
             C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
             C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
         }
@@ -550,7 +552,7 @@ extern "C" int advntr_batch_run(advntr_batch *B)
             column_launch_k<2, false>(B->col, a, B->flags, B->stream);
             column_launch_k<3, false>(B->col, a, B->flags, B->stream);
             column_launch_k<4, false>(B->col, a, B->flags, B->stream);
-            column_launch_k<4, true>(B->col, a, B->flags, B->stream);
+            column_launch_k<COL_LONG_K, true>(B->col, a, B->flags, B->stream);
         }
     }
     if (B->n_gen) {
@@ -657,7 +659,7 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 column_launch_fwd<2, false>(B->col, a, B->stream);
                 column_launch_fwd<3, false>(B->col, a, B->stream);
                 column_launch_fwd<4, false>(B->col, a, B->stream);
-                column_launch_fwd<4, true>(B->col, a, B->stream);
+                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream);
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

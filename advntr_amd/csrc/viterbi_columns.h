@@ -27,6 +27,11 @@
 #define COL_WAVES 4                 // wavefronts per workgroup (all on one model at a time)
 #define COL_MAX_TAIL 16
 #define COL_TILE_READS 16
+#define COL_LONG_K 4            // chunks per row tile of the long-read kernel (256-row tiles at 2 waves/SIMD measured best: 96 k
+                                // reads/s on the PacBio-size bench vs 87 k for 192-row tiles at 3 waves, 73 k at 4 waves with spills)
+#ifndef COL_LONG_WAVES
+#define COL_LONG_WAVES 3
+#endif
 #ifndef COL_MIN_WAVES_PER_SIMD
 #define COL_MIN_WAVES_PER_SIMD 4
 #endif
@@ -583,7 +588,7 @@ __device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t
 
 // LONG = reads longer than 64*K rows, processed in row tiles of 64*K rows (K = 4).
 template <int K, bool LONG>
-__global__ void __launch_bounds__(COL_WAVES * 64, (LONG ? 2 : (K >= 4 ? 3 : COL_MIN_WAVES_PER_SIMD)))
+__global__ void __launch_bounds__(COL_WAVES * 64, (K >= 4 ? (LONG ? 2 : 3) : (LONG ? COL_LONG_WAVES : COL_MIN_WAVES_PER_SIMD)))
 viterbi_columns_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
