@@ -76,20 +76,25 @@ __device__ __forceinline__ double bcast63(double v)
 }
 
 // One Viterbi relaxation: if (cand > best) { best = cand; ptr = code; }  -- strict '>' keeps the first maximum,
-// as the reference does (hmm.pyx:2039,2060,2080).  Written in assembly because of a measured gfx950 cost
-// (scripts/ubench/valu_rate.hip): hipcc's default lowering  v_cmp_gt_f64 vcc + 3 x v_cndmask_b32 ..., vcc  takes
-// ~64 cycles per wave (VCC-masked selects run at ~23 cycles each), whereas a compare into an ordinary SGPR pair
-// with e64 selects is ~4.5 cycles per instruction.  The value is taken with v_max_f64 (exactly the selected
-// operand for the non-NaN, never-negative-zero log-probabilities here), so only the pointer needs the mask.
+// as the reference does (hmm.pyx:2039,2060,2080).  hipcc lowers this to v_cmp_gt_f64 + v_cndmask_b32 x3.  A
+// micro-benchmark (scripts/ubench/valu_rate.hip, profiles/r01_valu_ubench.txt) shows VCC-masked selects at ~23 cycles
+// each when issued back to back, so an assembly form (compare into an SGPR pair, v_max_f64 for the value, one e64
+// select for the pointer) was tried: inside this kernel the two are equal on the 150-base workload (5.26 vs 5.25 M
+// reads/s) and the assembly is 7 % slower on the long-read kernel (opaque blocks cost the scheduler more than the
+// selects cost the VALU), so the plain form is the default; -DCOL_RELAX_ASM builds the other one.
 __device__ __forceinline__ void relax_gt(double &best, int &ptr, const double cand, const int code)
 {
+#ifndef COL_RELAX_ASM
+    if (cand > best) { best = cand; ptr = code; }
+#else
     unsigned long long m;
     asm("v_cmp_gt_f64_e64 %0, %3, %1\n\t"
-                 "v_max_f64 %1, %1, %3\n\t"
-                 "s_nop 0\n\t"
-                 "v_cndmask_b32_e64 %2, %2, %4, %0"
-                 : "=&s"(m), "+v"(best), "+v"(ptr)
-                 : "v"(cand), "v"(code));
+        "v_max_f64 %1, %1, %3\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %2, %2, %4, %0"
+        : "=&s"(m), "+v"(best), "+v"(ptr)
+        : "v"(cand), "v"(code));
+#endif
 }
 
 #ifndef ADVNTR_LSE2_DEFINED
