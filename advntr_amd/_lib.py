@@ -27,6 +27,7 @@ SYMBOLS = {
     "advntr_set_device": (ctypes.c_int, [ctypes.c_int]),
     "advntr_last_error": (ctypes.c_char_p, []),
     "advntr_version": (ctypes.c_char_p, []),
+    "advntr_trim": (None, []),
     "advntr_hmm_create": (_vp, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "advntr_hmm_destroy": (None, [_vp]),
     "advntr_hmm_has_column_program": (ctypes.c_int, [_vp]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -42,8 +43,105 @@ static int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                       \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------
+// Device-memory and stream caches.  A locus-sized call (a few hundred reads) is dominated by hipMalloc/hipFree and
+// stream/event creation, not by the kernel; batches therefore draw their buffers, stream and events from small
+// per-process caches (per device) and give them back on destroy.  advntr_trim() releases everything.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DeviceCaches {
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks[16];          // per device: free blocks by size
+    size_t cached[16] = {0};
+    std::vector<hipStream_t> streams[16];
+    std::vector<hipEvent_t> events[16];
+    static constexpr size_t kMaxCached = (size_t)24 << 30;
+
+    static size_t round_up(size_t b) { return b <= (1u << 20) ? ((b + 4095) & ~size_t(4095)) : ((b + (1u << 21) - 1) & ~size_t((1u << 21) - 1)); }
+
+    void *get(int dev, size_t bytes, size_t *got)
+    {
+        bytes = round_up(std::max<size_t>(bytes, 16));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = blocks[dev].lower_bound(bytes);
+            if (it != blocks[dev].end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+                void *p = it->second;
+                *got = it->first;
+                cached[dev] -= it->first;
+                blocks[dev].erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim(dev);                                  // cached blocks may be what is missing
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        *got = bytes;
+        return p;
+    }
+
+    void put(int dev, void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (cached[dev] + bytes > kMaxCached) { (void)hipFree(p); return; }
+        blocks[dev].emplace(bytes, p);
+        cached[dev] += bytes;
+    }
+
+    void trim(int dev)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : blocks[dev]) (void)hipFree(kv.second);
+        blocks[dev].clear();
+        cached[dev] = 0;
+    }
+
+    hipStream_t get_stream(int dev)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!streams[dev].empty()) { hipStream_t s = streams[dev].back(); streams[dev].pop_back(); return s; }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return s;
+    }
+    void put_stream(int dev, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); streams[dev].push_back(s); }
+
+    hipEvent_t get_event(int dev)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!events[dev].empty()) { hipEvent_t e = events[dev].back(); events[dev].pop_back(); return e; }
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void put_event(int dev, hipEvent_t e) { std::lock_guard<std::mutex> lk(mu); events[dev].push_back(e); }
+};
+
+DeviceCaches g_cache;
+
+int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
+    return d;
+}
+
+}  // namespace
+
 extern "C" const char *advntr_last_error(void) { return g_err.c_str(); }
 extern "C" const char *advntr_version(void) { return "advntr_hip 0.1 (gfx950)"; }
+
+extern "C" void advntr_trim(void)
+{
+    for (int d = 0; d < 16; ++d) g_cache.trim(d);
+}
 
 extern "C" int advntr_device_count(void)
 {
@@ -268,14 +366,15 @@ struct advntr_batch {
     int32_t *d_pathbuf_gen = nullptr, *d_pathbuf_col = nullptr;
     int32_t *d_counter = nullptr;       // [0]: generic dequeue head, [4..7]: tile heads per chunk count
     int32_t path_cap = 0;
-    std::vector<void *> allocs;
+    int device = 0;
+    std::vector<std::pair<void *, size_t>> allocs;
 
     template <class T> int dmalloc(T **p, size_t count)
     {
-        void *q = nullptr;
-        size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-        HIP_TRY(hipMalloc(&q, bytes));
-        allocs.push_back(q);
+        size_t bytes = std::max<size_t>(count, 1) * sizeof(T), got = 0;
+        void *q = g_cache.get(device, bytes, &got);
+        if (!q) return fail(ADVNTR_ERR_DEVICE, "device allocation of %zu bytes failed", bytes);
+        allocs.emplace_back(q, got);
         device_bytes += (int64_t)bytes;
         *p = (T *)q;
         return ADVNTR_OK;
@@ -314,9 +413,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                         (long long)i);
     for (auto *H : B->models) B->m_max = std::max(B->m_max, H->m);
 
-    HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&B->ev0));
-    HIP_TRY(hipEventCreate(&B->ev1));
+    B->device = current_device();
+    B->stream = g_cache.get_stream(B->device);
+    B->ev0 = g_cache.get_event(B->device);
+    B->ev1 = g_cache.get_event(B->device);
+    if (!B->stream || !B->ev0 || !B->ev1) return fail(ADVNTR_ERR_DEVICE, "stream/event creation failed");
 
     std::vector<DevModel> dm;
     for (auto *H : B->models) dm.push_back(H->dev);
@@ -417,7 +518,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             for (int i = 0; i < B->n_col;) {
                 const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
                 const int left = B->n_col - i;
-                int cap = left > B->n_col * 15 / 100 ? COL_TILE_READS : (left > B->n_col * 5 / 100 ? COL_TILE_READS / 2 : COL_WAVES);
+                // small batches (a locus-sized call): one read per wavefront so the reads spread over the CUs
+                const int full = std::max<int>(COL_WAVES, std::min<int>(COL_TILE_READS, B->n_col / std::max(1, cus * per_cu)));
+                int cap = left > B->n_col * 15 / 100 ? full : (left > B->n_col * 5 / 100 ? std::max<int>(COL_WAVES, full / 2) : COL_WAVES);
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
@@ -495,10 +598,11 @@ extern "C" advntr_batch *advntr_batch_create(advntr_hmm *const *models, int32_t 
 extern "C" void advntr_batch_destroy(advntr_batch *B)
 {
     if (!B) return;
-    for (void *p : B->allocs) (void)hipFree(p);
-    if (B->ev0) (void)hipEventDestroy(B->ev0);
-    if (B->ev1) (void)hipEventDestroy(B->ev1);
-    if (B->stream) (void)hipStreamDestroy(B->stream);
+    if (B->stream) (void)hipStreamSynchronize(B->stream);        // nothing of this batch may still be running
+    for (auto &a : B->allocs) g_cache.put(B->device, a.first, a.second);
+    if (B->ev0) g_cache.put_event(B->device, B->ev0);
+    if (B->ev1) g_cache.put_event(B->device, B->ev1);
+    if (B->stream) g_cache.put_stream(B->device, B->stream);
     delete B;
 }
 

@@ -70,6 +70,7 @@ int advntr_device_count(void);
 int advntr_set_device(int device);           /* per process: one process per GPU                        */
 const char *advntr_last_error(void);         /* thread-local message of the last failing call           */
 const char *advntr_version(void);
+void advntr_trim(void);                      /* release the cached device buffers (batches reuse them between calls) */
 
 /* ---- model (replaces the malloc'd CSR owned by a baked HiddenMarkovModel, hmm.pyx:935-1023) ---
  * States are ordered emitting-first (index < silent_start) then silent in topological order, as bake()
