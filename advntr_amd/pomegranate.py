@@ -296,10 +296,12 @@ class HiddenMarkovModel(object):
 
     def dense_transition_matrix(self):
         m = len(self.states)
-        t = np.zeros((m, m)) + NEGINF
+        # exp() only where there is an edge: exp(-inf) = 0 everywhere else (numpy's exp is an elementwise function, so
+        # the finite entries come out as they would from exponentiating the full matrix; pinned by the golden models)
+        out = np.zeros((m, m))
         src = np.repeat(np.arange(m), np.diff(self._out_ptr))
-        t[src, self._out_dst] = self._out_logp
-        return np.exp(t)
+        out[src, self._out_dst] = np.exp(self._out_logp)
+        return out
 
     @classmethod
     def from_matrix(cls, transition_probabilities, distributions, starts, ends=None, state_names=None,
