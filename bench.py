@@ -44,7 +44,20 @@ def cpu_baseline(locus, bases, off, n_sample):
     t0 = time.perf_counter()
     logp, _ = O.viterbi_many(bases[:sub_off[-1]], sub_off)
     dt = time.perf_counter() - t0
-    return n_sample / dt, logp
+    return n_sample / dt, logp, O
+
+
+def ru_concordance(O, locus, reads, summ, n_check):
+    """RU-count concordance (the second half of BASELINE.json's metric): repeat-unit counts the kernel derived on
+    the GPU vs. advntr/hmm_utils.py:155-188 applied to the oracle's Viterbi path, read by read."""
+    from oracle import oracle as Or
+    names = [s.name for s in locus.model.states]
+    same = 0
+    for i in range(n_check):
+        _, path = O.viterbi(reads[i])
+        ru = Or.number_of_repeats([names[j] for j in path][1:-1]) if path else 0
+        same += int(ru == int(summ[i][0]))
+    return same
 
 
 def main():
@@ -191,8 +204,12 @@ def main():
                                  "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
         }
         if not args.no_cpu:
-            cps, cpu_logp = cpu_baseline(locus, bases, off, min(args.cpu_sample, args.reads))
+            cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, args.reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
+            n_ru = min(500, len(cpu_logp))
+            same = ru_concordance(O, locus, reads, summ, n_ru)
+            out["ru_concordance"] = {"reads": n_ru, "identical_ru_counts": same, "fraction": same / n_ru,
+                                     "note": "GPU path summaries vs hmm_utils.get_number_of_repeats_in_vpath on the oracle path"}
             out["cpu_baseline"] = {"value": cps, "unit": "reads/s", "cores": 1, "kind": "port",
                                    "sample": "first %d reads of rank 0's batch, oracle/viterbi_oracle.c, 1 thread; "
                                              "GPU logp bit-equal on the sample" % len(cpu_logp)}
