@@ -400,3 +400,57 @@ def test_forward_column_kernel_vs_generic_and_oracle():
         want = O.forward(reads[i])
         assert abs(col[i] - want) <= 1e-9 * max(1.0, abs(want)), (i, len(reads[i]))
         assert col[i] >= _lib.viterbi_batch([dm], *_lib.encode_reads([reads[i]]), np.zeros(1, np.int32))[0][0] - 1e-9
+
+
+def test_end_to_end_genotype_concordance():
+    """prefilter -> scoring (both strands) -> recruit -> RU counts of spanning reads -> genotype, GPU pipeline vs the
+    same pipeline on oracle scores: identical recruited sets, RU lists and genotype; and the genotype is the planted
+    diploid one (3/5 copies)."""
+    from advntr_amd import filtering, hmm_utils, settings, vntr_finder, workloads, _lib
+    from oracle import oracle as Or
+    rng = np.random.default_rng(77)
+    pattern = workloads.rand_seq(rng, 14)
+    left, right = workloads.rand_seq(rng, 150), workloads.rand_seq(rng, 150)
+    reads = []
+    for copies in (3, 5):
+        allele = left + pattern * copies + right
+        for _ in range(40):
+            st = int(rng.integers(60, 120))
+            s = allele[st:st + 150]
+            s = "".join(("ACGT"[int(rng.integers(0, 4))] if rng.random() < 0.005 else ch) for ch in s)
+            reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
+    reads += [workloads.rand_seq(rng, 150) for _ in range(300)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    # stage 1: keyword prefilter (both strands of every read, as unmapped reads come in either orientation)
+    kws = filtering.get_keywords_for_filtering(left, [pattern] * 4, right, pattern, True, 15)
+    fasta = "".join(">r%d\n%s\n>r%d_rc\n%s\n" % (i, s, i, vntr_finder.reverse_complement(s)) for i, s in enumerate(reads))
+    _, ids = filtering.get_filtered_read_ids(fasta, {1: kws}, min_matches=3)
+    picked = sorted(set(int(n.split("_")[0][1:]) for n in ids[1]))
+    assert 60 <= len(picked) <= 120
+    cand = [reads[i] for i in picked]
+    # stage 2: scoring + recruit on the GPU
+    settings.MAX_ERROR_RATE = 0.05
+    model = hmm_utils.get_read_matcher_model(left, right, [pattern], vntr_finder.get_copies_for_hmm(150, 14))
+    scored = vntr_finder.score_reads(model, cand, scaled_score=None, compute_reverse=True)
+    gpu_ru = [s.repeats for s in scored if s.recruited and s.summary[_lib.SUM_LEFT_BP] >= 5 and s.summary[_lib.SUM_RIGHT_BP] >= 5]
+    # the same on oracle scores
+    a = model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = Or.OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    names = [s.name for s in model.states]
+    cpu_ru = []
+    for s in cand:
+        lf, pf = O.viterbi(s)
+        rc = vntr_finder.reverse_complement(s)
+        lr, pr = O.viterbi(rc)
+        seq, lp, path = (rc, lr, pr) if lf < lr else (s, lf, pf)
+        inner = [names[i] for i in path][1:-1]
+        if not Or.recruit_read(lp, inner, None, seq, left, right):
+            continue
+        if Or.left_flank_size(inner) >= 5 and Or.right_flank_size(inner) >= 5:
+            cpu_ru.append(Or.number_of_repeats(inner))
+    assert gpu_ru == cpu_ru and len(gpu_ru) >= 20
+    geno, prob = vntr_finder.find_genotype_based_on_observed_repeats(gpu_ru)
+    assert sorted(geno) == [3, 5]
