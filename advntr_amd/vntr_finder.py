@@ -7,6 +7,8 @@ is kept:
   recruit_read                             vntr_finder.py:179-190
   process_unmapped_read (fwd + revcomp)    vntr_finder.py:235-254   -> score_reads(..., compute_reverse=True)
   find_genotype_based_on_observed_repeats  vntr_finder.py:485-532   (+ get_conditional_likelihood :473-483)
+  read_flanks_repeats_with_confidence      vntr_finder.py:311-322
+  find_repeat_count_from_alignment_file    vntr_finder.py:807-887   -> find_repeat_count_from_selected_reads (after selection)
 
 The reference loops over reads in Python and calls hmm.viterbi twice per unmapped read; here the whole
 locus batch (both strands) goes to the GPU in one advntr_viterbi_batch call and the keep/discard rule is
@@ -134,3 +136,61 @@ def find_genotype_based_on_observed_repeats(observed_copy_numbers, is_haploid=Fa
             max_prob = value / total
             result = key
     return result, max_prob
+
+
+class GenotypeResult(object):
+    """Same fields as the reference's GenotypeResult (vntr_finder.py:28-34)."""
+
+    def __init__(self, copy_numbers, recruited_reads_count, spanning_reads_count, flanking_reads_count, max_likelihood):
+        self.copy_numbers = copy_numbers
+        self.recruited_reads_count = recruited_reads_count
+        self.spanning_reads_count = spanning_reads_count
+        self.flanking_reads_count = flanking_reads_count
+        self.maximum_likelihood = max_likelihood
+
+
+def read_flanks_repeats_with_confidence(summary, minimum_left_flanking_size=5, minimum_right_flanking_size=5):
+    """vntr_finder.py:311-322 on the kernel's summary: flank match rate >= 0.95 and more than the minimum number of
+    bases on either flank => the read spans the VNTR."""
+    rate = flanking_rate_from_counts(int(summary[_lib.SUM_LEFT_MATCH]), int(summary[_lib.SUM_LEFT_BP]),
+                                     int(summary[_lib.SUM_RIGHT_MATCH]), int(summary[_lib.SUM_RIGHT_BP]))
+    if rate < 0.95:
+        return False
+    return bool(summary[_lib.SUM_LEFT_BP] > minimum_left_flanking_size and
+                summary[_lib.SUM_RIGHT_BP] > minimum_right_flanking_size)
+
+
+def find_repeat_count_from_selected_reads(summaries, accuracy_filter=False, average_coverage=None, is_haploid=False,
+                                          minimum_left_flanking_size=5, minimum_right_flanking_size=5):
+    """The Illumina aggregation of find_repeat_count_from_alignment_file after read selection
+    (vntr_finder.py:807-887): RU counts of spanning reads, plus the largest RU count of flanking reads when at least
+    five of them agree on it and it is not below the largest spanning count; with the accuracy filter only RU counts
+    supported by >= 3 spanning reads survive and flanking reads are ignored; optional coverage-based estimate.
+    `summaries` = the 8-int records of the selected (recruited) reads."""
+    from collections import Counter
+    covered, flanking = [], []
+    for s in summaries:
+        repeats = int(s[_lib.SUM_RU])
+        if read_flanks_repeats_with_confidence(s, minimum_left_flanking_size, minimum_right_flanking_size):
+            covered.append(repeats)
+        elif not accuracy_filter:
+            flanking.append(repeats)
+    flanking = sorted(flanking)
+    min_valid_flanked = max(covered) if covered else 0
+    max_flanking = [r for r in flanking if r == max(flanking) and r >= min_valid_flanked]
+    if len(max_flanking) < 5:
+        max_flanking = []
+    if accuracy_filter:
+        modified = []
+        for key, count in Counter(covered).most_common():
+            if count >= 3:
+                modified.extend([key] * count)
+        covered = modified
+        max_flanking = []
+    genotype, max_prob = find_genotype_based_on_observed_repeats(covered + max_flanking, is_haploid)
+    if average_coverage is None or average_coverage is False or average_coverage == 0:
+        return GenotypeResult(genotype, len(summaries), len(covered), len(flanking), max_prob)
+    occurrences = sum(flanking) + sum(covered)
+    haplotypes = 1 if is_haploid else 2
+    estimate = [int(occurrences / (float(average_coverage) * haplotypes))] * 2
+    return GenotypeResult(estimate, len(summaries), len(covered), len(flanking), 0)

@@ -42,17 +42,23 @@ def _load_vntr_finder_methods():
     path = "/root/reference/advntr/vntr_finder.py"
     tree = ast.parse(open(path).read())
     wanted = {"recruit_read", "get_conditional_likelihood", "find_genotype_based_on_observed_repeats",
-              "get_copies_for_hmm", "get_min_score_to_select_a_read"}
+              "get_copies_for_hmm", "get_min_score_to_select_a_read", "find_repeat_count_from_alignment_file",
+              "read_flanks_repeats_with_confidence", "get_ru_count_with_coverage_method"}
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "VNTRFinder"][0]
     body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
     for fn in body:
         fn.decorator_list = []
-    mod = ast.Module(body=[ast.ClassDef(name="VNTRFinder", bases=[], keywords=[], body=body,
-                                        decorator_list=[])], type_ignores=[])
+    helpers = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("GenotypeResult", "ReadSource", "LoggedRead")]
+    mod = ast.Module(body=helpers + [ast.ClassDef(name="VNTRFinder", bases=[], keywords=[], body=body,
+                                                  decorator_list=[])], type_ignores=[])
     ast.fix_missing_locations(mod)
     ns = dict(vars(hmm_utils))
     import logging
+    from collections import Counter
+    from enum import Enum
     ns["logging"] = logging
+    ns["Counter"] = Counter
+    ns["Enum"] = Enum
     exec(compile(mod, path, "exec"), ns)
     return ns["VNTRFinder"]
 
@@ -63,7 +69,7 @@ RefVNTRFinder = _load_vntr_finder_methods()
 def make_finder(left, right, pattern, scaled_score, haploid=False):
     f = RefVNTRFinder.__new__(RefVNTRFinder)
     f.reference_vntr = types.SimpleNamespace(left_flanking_region=left, right_flanking_region=right,
-                                             pattern=pattern, scaled_score=scaled_score)
+                                             pattern=pattern, scaled_score=scaled_score, id=1)
     f.is_haploid = haploid
     return f
 
@@ -231,6 +237,52 @@ def generic_model(name, seed, n_emit, n_silent, finite, n_reads):
     write(name, {"kind": "generic", "finite": bool(finite), "model": dump_model(m), "reads": recs})
 
 
+def illumina_aggregation_cases():
+    """VNTRFinder.find_repeat_count_from_alignment_file (vntr_finder.py:789-887) with its read selection stubbed out:
+    select_illumina_reads needs a BAM (pysam); here it returns prepared SelectedRead-like records whose vpaths come
+    from the reference's own viterbi, so everything after the selection is the reference's code."""
+    rng = np.random.default_rng(31)
+    settings.MAX_ERROR_RATE = 0.05
+    pattern = rand_seq(rng, 14)
+    left, right = rand_seq(rng, 150), rand_seq(rng, 150)
+    m = hmm_utils.get_read_matcher_model(left, right, [pattern], 11)
+    cases, all_reads = [], {}
+    for case, (alleles, n_per, noise) in enumerate([((3, 5), 30, 0.005), ((4, 4), 25, 0.01), ((2, 9), 30, 0.005),
+                                                    ((6, 7), 12, 0.02)]):
+        finder = make_finder(left, right, pattern, None)
+        finder.minimum_left_flanking_size = 5
+        finder.minimum_right_flanking_size = 5
+        recs, selected = [], []
+        for copies in alleles:
+            allele = left + pattern * copies + right
+            for _ in range(n_per):
+                st = int(rng.integers(40, 150))
+                s = mutate(rng, allele[st:st + 150], noise)
+                logp, vpath = m.viterbi(s)
+                if vpath is None or not finder.recruit_read(logp, vpath, None, s):
+                    continue
+                if hmm_utils.get_number_of_repeat_bp_matches_in_vpath(vpath) <= 2:
+                    continue
+                mapped = bool(rng.random() < 0.5)
+                selected.append(types.SimpleNamespace(sequence=s, logp=logp, vpath=vpath, is_mapped=mapped,
+                                                      query_name="q%d" % len(selected)))
+                recs.append({"seq": s, "logp": logp, "path": [i for i, _ in vpath], "is_mapped": mapped})
+        finder.select_illumina_reads = lambda *a, **k: selected
+        for acc, cov in ((False, None), (True, None), (False, 30.0)):
+            res = finder.find_repeat_count_from_alignment_file(None, None, accuracy_filter=acc, average_coverage=cov)
+            cn = res.copy_numbers
+            cases.append({"case": case, "accuracy_filter": acc, "average_coverage": cov, "haploid": False,
+                          "copy_numbers": None if cn is None else list(cn),
+                          "recruited": res.recruited_reads_count, "spanning": res.spanning_reads_count,
+                          "flanking": res.flanking_reads_count, "max_likelihood": res.maximum_likelihood})
+        for c in cases[-3:]:
+            c["reads_ref"] = case
+        all_reads[case] = recs
+    write("illumina_aggregation", {"kind": "illumina_aggregation", "left": left, "right": right, "pattern": pattern,
+                                   "copies": 11, "error_rate": 0.05, "model": dump_model(m),
+                                   "reads_by_case": {str(k): v for k, v in all_reads.items()}, "cases": cases})
+
+
 def genotype_cases():
     f = make_finder("A", "A", "A", None)
     cases = [[2, 2, 2, 5, 5], [3], [], [4, 4, 4, 4], [1, 2, 3], [7, 7, 8, 8, 8, 9], [10, 10, 2],
@@ -298,6 +350,7 @@ def main():
     generic_model("generic_finite", 21, 9, 6, True, 40)
     generic_model("generic_infinite", 22, 7, 4, False, 40)
     genotype_cases()
+    illumina_aggregation_cases()
     reference_fixture_answers()
 
 

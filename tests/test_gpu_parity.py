@@ -454,3 +454,21 @@ def test_end_to_end_genotype_concordance():
     assert gpu_ru == cpu_ru and len(gpu_ru) >= 20
     geno, prob = vntr_finder.find_genotype_based_on_observed_repeats(gpu_ru)
     assert sorted(geno) == [3, 5]
+
+
+def test_illumina_aggregation_on_gpu_summaries():
+    """Reads of the aggregation golden scored on the GPU; the genotype results must equal what the reference's own
+    find_repeat_count_from_alignment_file returned for them (tests/golden/illumina_aggregation.json.gz)."""
+    from advntr_amd import _lib, vntr_finder
+    g = load_golden("illumina_aggregation")
+    dm, _ = device_model_from_golden(dict(g, kind="read_matcher"))
+    for c in g["cases"]:
+        reads = g["reads_by_case"][str(c["reads_ref"])]
+        bases, off = _lib.encode_reads([r["seq"] for r in reads])
+        logp, summ, _ = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32))
+        assert [float(x) for x in logp] == [r["logp"] for r in reads]
+        res = vntr_finder.find_repeat_count_from_selected_reads(list(summ), accuracy_filter=c["accuracy_filter"],
+                                                                average_coverage=c["average_coverage"])
+        assert (None if res.copy_numbers is None else list(res.copy_numbers)) == c["copy_numbers"]
+        assert (res.spanning_reads_count, res.flanking_reads_count) == (c["spanning"], c["flanking"])
+        assert res.maximum_likelihood == c["max_likelihood"]

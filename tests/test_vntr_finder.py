@@ -37,3 +37,32 @@ def test_recruit_read_from_summaries_matches_reference_verdicts():
 
 def test_reverse_complement():
     assert vntr_finder.reverse_complement("AACGT") == "ACGTT"
+
+
+def _summary_from_path(g, r):
+    names = g["model"]["state_names"]
+    inner = [names[i] for i in r["path"]][1:-1]
+    lm, lb, rm, rb = O.flanking_counts(inner, r["seq"], g["left"], g["right"])
+    s = np.zeros(8, np.int32)
+    s[_lib.SUM_RU] = O.number_of_repeats(inner)
+    s[_lib.SUM_MATCHES] = O.number_of_matches(inner)
+    s[_lib.SUM_REPEAT_BP] = O.repeat_bp_matches(inner)
+    s[_lib.SUM_LEFT_BP], s[_lib.SUM_RIGHT_BP], s[_lib.SUM_LEFT_MATCH], s[_lib.SUM_RIGHT_MATCH] = lb, rb, lm, rm
+    s[_lib.SUM_PATH_LEN] = len(r["path"])
+    return s
+
+
+def test_illumina_aggregation_matches_reference():
+    """find_repeat_count_from_alignment_file after read selection (vntr_finder.py:807-887): the golden results were
+    produced by the reference's own method with its BAM-reading selection stubbed (tests/golden/make_golden.py)."""
+    g = load_golden("illumina_aggregation")
+    for c in g["cases"]:
+        reads = g["reads_by_case"][str(c["reads_ref"])]
+        summaries = [_summary_from_path(g, r) for r in reads]
+        res = vntr_finder.find_repeat_count_from_selected_reads(summaries, accuracy_filter=c["accuracy_filter"],
+                                                                average_coverage=c["average_coverage"])
+        got = None if res.copy_numbers is None else list(res.copy_numbers)
+        assert got == c["copy_numbers"], c
+        assert (res.recruited_reads_count, res.spanning_reads_count, res.flanking_reads_count) == \
+            (c["recruited"], c["spanning"], c["flanking"]), c
+        assert res.maximum_likelihood == c["max_likelihood"], c
