@@ -9,6 +9,7 @@ is kept:
   find_genotype_based_on_observed_repeats  vntr_finder.py:485-532   (+ get_conditional_likelihood :473-483)
   read_flanks_repeats_with_confidence      vntr_finder.py:311-322
   find_repeat_count_from_alignment_file    vntr_finder.py:807-887   -> find_repeat_count_from_selected_reads (after selection)
+  build_vntr_matcher_hmm / get_dominant_copy_numbers_from_spanning_reads (PacBio)   vntr_finder.py:108-115, 534-585
 
 The reference loops over reads in Python and calls hmm.viterbi twice per unmapped read; here the whole
 locus batch (both strands) goes to the GPU in one advntr_viterbi_batch call and the keep/discard rule is
@@ -194,3 +195,41 @@ def find_repeat_count_from_selected_reads(summaries, accuracy_filter=False, aver
     haplotypes = 1 if is_haploid else 2
     estimate = [int(occurrences / (float(average_coverage) * haplotypes))] * 2
     return GenotypeResult(estimate, len(summaries), len(covered), len(flanking), 0)
+
+
+def build_vntr_matcher_hmm(left_flanking_region, right_flanking_region, repeat_segments, copies, flanking_region_size=100):
+    """vntr_finder.py:108-115: the read-matcher model over the last/first `flanking_region_size` flank bases."""
+    from .hmm_utils import get_read_matcher_model
+    return get_read_matcher_model(left_flanking_region[-flanking_region_size:],
+                                  right_flanking_region[:flanking_region_size], repeat_segments, copies)
+
+
+def pacbio_max_copies(spanning_read_lengths, pattern_length):
+    """vntr_finder.py:538-543: copies of the model = round((longest trimmed read - 100) / len(pattern))."""
+    max_length = 0
+    for n in spanning_read_lengths:
+        if n - 100 > max_length:
+            max_length = n - 100
+    return int(round(max_length / float(pattern_length)))
+
+
+def get_dominant_copy_numbers_from_spanning_reads(left_flanking_region, right_flanking_region, repeat_segments, pattern,
+                                                  spanning_reads, accuracy_filter=False, is_haploid=False):
+    """PacBio RU-count genotyping (vntr_finder.py:534-585): one model sized for the longest spanning read, every
+    spanning read scored on the forward strand (one batch on the GPU, row-tiled kernel), RU count per read, optional
+    >= 3-reads support filter, maximum-likelihood genotype.  spanning_reads = trimmed read sequences."""
+    from collections import Counter
+    from . import settings
+    if len(spanning_reads) < 1:
+        return None, 0
+    max_copies = pacbio_max_copies([len(s) for s in spanning_reads], len(pattern))
+    model = build_vntr_matcher_hmm(left_flanking_region, right_flanking_region, repeat_segments, max_copies)
+    _, summ, _ = model.viterbi_batch(list(spanning_reads), want_paths=False, want_summary=True)
+    observed = [int(s[_lib.SUM_RU]) for s in summ]
+    if accuracy_filter:
+        modified = []
+        for key, count in Counter(observed).most_common():
+            if count >= 3:                                  # settings.ACCURACY_FILTER_SR_MIN_SUPPORT
+                modified.extend([key] * count)
+        observed = modified
+    return find_genotype_based_on_observed_repeats(observed, is_haploid)

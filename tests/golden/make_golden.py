@@ -43,7 +43,8 @@ def _load_vntr_finder_methods():
     tree = ast.parse(open(path).read())
     wanted = {"recruit_read", "get_conditional_likelihood", "find_genotype_based_on_observed_repeats",
               "get_copies_for_hmm", "get_min_score_to_select_a_read", "find_repeat_count_from_alignment_file",
-              "read_flanks_repeats_with_confidence", "get_ru_count_with_coverage_method"}
+              "read_flanks_repeats_with_confidence", "get_ru_count_with_coverage_method",
+              "get_dominant_copy_numbers_from_spanning_reads", "build_vntr_matcher_hmm"}
     cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "VNTRFinder"][0]
     body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in wanted]
     for fn in body:
@@ -283,6 +284,35 @@ def illumina_aggregation_cases():
                                    "reads_by_case": {str(k): v for k, v in all_reads.items()}, "cases": cases})
 
 
+def pacbio_cases():
+    """VNTRFinder.get_dominant_copy_numbers_from_spanning_reads (vntr_finder.py:534-585) on trimmed spanning reads
+    (flank 100 + VNTR + flank 100 with PacBio-like noise), error rate 0.3 as advntr_commands.py:66-71 sets it."""
+    rng = np.random.default_rng(41)
+    settings.MAX_ERROR_RATE = 0.3
+    cases = []
+    for case, (plen, alleles, n_per) in enumerate([(20, (4, 7), 8), (33, (3, 3), 6), (12, (10, 14), 7)]):
+        pattern = rand_seq(rng, plen)
+        left, right = rand_seq(rng, 120), rand_seq(rng, 120)
+        finder = make_finder(left, right, pattern, None)
+        finder.reference_vntr.get_repeat_segments = lambda pattern=pattern: [pattern]      # one segment: no muscle
+        finder.minimum_left_flanking_size = 5
+        finder.minimum_right_flanking_size = 5
+        reads = []
+        for copies in alleles:
+            for _ in range(n_per):
+                s = mutate(rng, left[-100:] + pattern * copies + right[:100], 0.03, 0.04, 0.03)
+                reads.append(types.SimpleNamespace(sequence=s, read_id="p%d" % len(reads),
+                                                   source=types.SimpleNamespace(name="MAPPED")))
+        for acc in (False, True):
+            finder.minimum_left_flanking_size = finder.minimum_right_flanking_size = 5
+            cn, prob = finder.get_dominant_copy_numbers_from_spanning_reads(reads, False, acc)
+            cases.append({"case": case, "pattern": pattern, "left": left, "right": right, "repeat_segments": [pattern],
+                          "reads": [r.sequence for r in reads], "accuracy_filter": acc,
+                          "copy_numbers": None if cn is None else list(cn), "max_prob": prob})
+    settings.MAX_ERROR_RATE = 0.05
+    write("pacbio_dominant_copy_numbers", {"kind": "pacbio_genotype", "cases": cases})
+
+
 def genotype_cases():
     f = make_finder("A", "A", "A", None)
     cases = [[2, 2, 2, 5, 5], [3], [], [4, 4, 4, 4], [1, 2, 3], [7, 7, 8, 8, 8, 9], [10, 10, 2],
@@ -351,6 +381,7 @@ def main():
     generic_model("generic_infinite", 22, 7, 4, False, 40)
     genotype_cases()
     illumina_aggregation_cases()
+    pacbio_cases()
     reference_fixture_answers()
 
 

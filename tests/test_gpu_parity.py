@@ -472,3 +472,20 @@ def test_illumina_aggregation_on_gpu_summaries():
         assert (None if res.copy_numbers is None else list(res.copy_numbers)) == c["copy_numbers"]
         assert (res.spanning_reads_count, res.flanking_reads_count) == (c["spanning"], c["flanking"])
         assert res.maximum_likelihood == c["max_likelihood"]
+
+
+def test_pacbio_dominant_copy_numbers_match_reference():
+    """get_dominant_copy_numbers_from_spanning_reads (vntr_finder.py:534-585): the golden genotypes/probabilities were
+    returned by the reference's own method (tests/golden/make_golden.py); here the reads go through the row-tiled GPU
+    kernel at the PacBio error setting."""
+    from advntr_amd import settings, vntr_finder
+    g = load_golden("pacbio_dominant_copy_numbers")
+    settings.MAX_ERROR_RATE = 0.3
+    try:
+        for c in g["cases"]:
+            geno, prob = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
+                c["left"], c["right"], c["repeat_segments"], c["pattern"], c["reads"], accuracy_filter=c["accuracy_filter"])
+            assert (None if geno is None else list(geno)) == c["copy_numbers"], c["case"]
+            assert prob == c["max_prob"], c["case"]
+    finally:
+        settings.MAX_ERROR_RATE = 0.05
