@@ -1,0 +1,92 @@
+"""Thin command line over the engine: `python -m advntr_amd genotype --loci loci.json --reads reads.fa`.
+
+Not a re-implementation of the reference's CLI (/root/reference/advntr/__main__.py, advntr_commands.py: BAM/CRAM
+input, sqlite model databases, BED/VCF writers are out of scope).  It strings the GPU stages together
+for reads that are already extracted: keyword prefilter -> per-locus Viterbi scoring of both strands -> recruit ->
+Illumina aggregation (or PacBio dominant copy numbers) -> the reference's text output (genome_analyzer.py:158-170:
+the VNTR id on one line, the genotype `a/b` on the next).
+
+loci.json: [{"id": 301645, "left": "...", "right": "...", "pattern": "...", "repeat_segments": ["...", ...],
+             "scaled_score": -1.1}, ...]   (repeat_segments pre-aligned when more than one, equal length)
+reads.fa : two-line FASTA (name line, sequence line), the format adVNTR-Filtering reads (filtering/main.cc:247-252).
+"""
+import argparse
+import json
+import sys
+
+import numpy as np
+
+
+def _read_fasta(path):
+    lines = open(path).read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    return [lines[k][1:] for k in range(0, len(lines) - 1, 2)], [lines[k + 1] for k in range(0, len(lines) - 1, 2)]
+
+
+def genotype(args):
+    from . import filtering, hmm_utils, settings, vntr_finder
+    loci = json.load(open(args.loci))
+    names, seqs = _read_fasta(args.reads)
+    settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
+    out = sys.stdout
+    if args.pacbio:
+        for loc in loci:
+            geno, _ = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
+                loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], [s.upper() for s in seqs],
+                accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
+            _print(out, loc["id"], geno, args.haploid)
+        return 0
+    # Illumina: prefilter every read (both strands) against all loci at once
+    fasta = "".join(">%d\n%s\n" % (i, s.upper()) for i, s in enumerate(seqs))
+    keywords = {int(loc["id"]): filtering.get_keywords_for_filtering(loc["left"], loc["repeat_segments"], loc["right"],
+                                                                       loc["pattern"], True, 15) for loc in loci}
+    _, ids_fwd = filtering.get_filtered_read_ids(fasta, keywords, min_matches=args.min_matches)
+    rc = "".join(">%d\n%s\n" % (i, vntr_finder.reverse_complement(s.upper()) if "N" not in s.upper() else s.upper())
+                 for i, s in enumerate(seqs))
+    _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
+    read_length = int(np.median([len(s) for s in seqs[:5]])) if seqs else 150     # vntr_finder.py:714-718
+    for loc in loci:
+        vid = int(loc["id"])
+        picked = sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))
+        cand = [seqs[i] for i in picked]
+        copies = vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))
+        model = hmm_utils.get_read_matcher_model(loc["left"][-read_length:], loc["right"][:read_length],
+                                                 loc["repeat_segments"], copies)
+        scored = [s for s in vntr_finder.score_reads(model, cand, loc.get("scaled_score"), True) if s is not None]
+        selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
+        res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
+                                                                is_haploid=args.haploid)
+        _print(out, vid, res.copy_numbers, args.haploid)
+    return 0
+
+
+def _print(out, vid, copy_numbers, haploid):
+    out.write("%s\n" % vid)
+    if copy_numbers is None:
+        out.write("None\n")
+    elif haploid:
+        out.write("%s\n" % copy_numbers[0])
+    else:
+        out.write("/".join(str(cn) for cn in sorted(copy_numbers)) + "\n")
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m advntr_amd")
+    sub = ap.add_subparsers(dest="cmd")
+    g = sub.add_parser("genotype", help="RU-count genotypes of the given loci from extracted reads (GPU)")
+    g.add_argument("--loci", required=True)
+    g.add_argument("--reads", required=True)
+    g.add_argument("--pacbio", action="store_true", help="reads are trimmed spanning long reads (error rate 0.3)")
+    g.add_argument("--haploid", action="store_true")
+    g.add_argument("--accuracy-filter", action="store_true")
+    g.add_argument("--min-matches", type=int, default=5)
+    args = ap.parse_args(argv)
+    if args.cmd == "genotype":
+        return genotype(args)
+    ap.print_help()
+    return 2
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -489,3 +489,30 @@ def test_pacbio_dominant_copy_numbers_match_reference():
             assert prob == c["max_prob"], c["case"]
     finally:
         settings.MAX_ERROR_RATE = 0.05
+
+
+def test_cli_genotype_text_output(tmp_path):
+    """python -m advntr_amd genotype: two loci, planted 3/5 and 4/4 genotypes, reference text format."""
+    import json
+    import subprocess
+    import sys
+    from advntr_amd import workloads, vntr_finder
+    rng = np.random.default_rng(2718)
+    loci, reads = [], []
+    for vid, alleles in ((11, (3, 5)), (12, (4, 4))):
+        pattern = workloads.rand_seq(rng, 16)
+        left, right = workloads.rand_seq(rng, 150), workloads.rand_seq(rng, 150)
+        loci.append({"id": vid, "left": left, "right": right, "pattern": pattern, "repeat_segments": [pattern], "scaled_score": None})
+        for copies in alleles:
+            allele = left + pattern * copies + right
+            for _ in range(30):
+                st = int(rng.integers(50, 110))
+                s = allele[st:st + 150]
+                reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
+    reads += [workloads.rand_seq(rng, 150) for _ in range(200)]
+    (tmp_path / "loci.json").write_text(json.dumps(loci))
+    (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"),
+                          "--reads", str(tmp_path / "reads.fa")], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out == "11\n3/5\n12\n4/4\n"
