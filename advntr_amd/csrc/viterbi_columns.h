@@ -258,7 +258,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         if (fl & COL_FLAG_SINK) {
             vB = R.er[k];
             pb = 3;
-            C.sinkbp[(fl >> 4) * C.sink_stride + C.row0 + t] = R.erwin[k];
+            if (t <= C.n_tile) C.sinkbp[(fl >> 4) * C.sink_stride + C.row0 + t] = R.erwin[k];   // padding rows own no slot
             R.er[k] = -INFINITY;
         }
         if (fl & COL_FLAG_FEED) {
