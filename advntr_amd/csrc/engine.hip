@@ -845,6 +845,8 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
         const uint64_t h = kwf_hash(kv.first);
         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
         bitset[b >> 5] |= 1u << (b & 31);
+        const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
+        bitset[b2 >> 5] |= 1u << (b2 & 31);
         size_t fs = kwf_fp_slot(h, (uint32_t)(fp_slots - 1));
         while (fps[fs] != 0) fs = (fs + 1) & (fp_slots - 1);
         fps[fs] = kwf_fp(h);
@@ -917,9 +919,10 @@ extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, co
         KwfArgs a{};
         a.f = F->dev; a.bases = d_bases; a.read_off = d_off; a.n_reads = n_reads;
         a.out_read = d_r; a.out_vntr = d_v; a.out_count = d_c; a.n_out = d_n; a.capacity = capacity;
-        const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus() * 2));
+        const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus()));
+        HIP_TRY(hipFuncSetAttribute((const void *)keyword_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(KWF_BLOCK), 0, nullptr, a);
+        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));

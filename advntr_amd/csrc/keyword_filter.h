@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define KWF_MAX_LENGTHS 4
-#define KWF_BITSET_BITS (1u << 19)          // 64 KiB of LDS
+#define KWF_BITSET_BITS (1u << 20)          // 128 KiB of LDS: one 1024-thread workgroup per CU, two bits per keyword
 #define KWF_EMPTY 0xffffffffffffffffull
 #define KWF_SLOTS 4
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ void kwf_probe(const KwfArgs &a, const uint64_t key, 
 #define KWF_BLOCK 1024      // 16 waves share one 64 KiB bit-set: two workgroups fill a CU (32 waves)
 __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
 {
-    __shared__ uint32_t bits[KWF_BITSET_BITS / 32];
+    extern __shared__ __attribute__((aligned(16))) uint32_t bits[];
     for (int i = threadIdx.x; i < (int)(KWF_BITSET_BITS / 32); i += KWF_BLOCK) bits[i] = a.f.bitset[i];
     __syncthreads();
     const bool single = a.f.n_lengths == 1;
@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
                         key[q] = (win & mask0) | ((uint64_t)L0 << 58);
                         const uint64_t h = kwf_hash(key[q]);
                         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
-                        if ((bits[b >> 5] >> (b & 31)) & 1u) { live |= 1u << q; hh[q] = h; }
+                        const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
+                        if (((bits[b >> 5] >> (b & 31)) & (bits[b2 >> 5] >> (b2 & 31))) & 1u) { live |= 1u << q; hh[q] = h; }
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -188,7 +189,8 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
                         const uint64_t key = (win & a.f.mask[li]) | ((uint64_t)L << 58);
                         const uint64_t h = kwf_hash(key);
                         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
-                        if (!((bits[b >> 5] >> (b & 31)) & 1u)) continue;
+                        const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
+                        if (!(((bits[b >> 5] >> (b & 31)) & (bits[b2 >> 5] >> (b2 & 31))) & 1u)) continue;
                         if (!kwf_fp_maybe(a.f, h, a.f.fps[kwf_fp_slot(h, a.f.fp_mask)])) continue;
                         const uint64_t slot = (h & 0xffffffffull) & a.f.table_mask;
                         kwf_probe(a, key, slot, a.f.keys[slot], r, svid, scnt);
