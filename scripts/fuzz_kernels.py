@@ -1,0 +1,47 @@
+"""Differential fuzz: the anti-diagonal column kernel vs the generic-CSR kernel (two independent implementations of
+the reference's _viterbi) on random loci and reads; log-probs, all 8 summary ints and (on a sample) paths must agree
+bit for bit.  Usage: python scripts/fuzz_kernels.py [n_loci] [seed]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+e.build()
+from advntr_amd import _lib, workloads
+
+n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t0 = time.time()
+total = 0
+for k in range(n_loci):
+    flank = int(rng.integers(3, 160))
+    plen = int(rng.integers(2, 80))
+    copies = int(rng.integers(1, 14))
+    err = float(rng.choice([0.05, 0.3, 0.1]))
+    loc = workloads.make_locus(rng, flank, plen, copies, err, n_units=int(rng.integers(1, 8)))
+    dm = loc.model.device_model()
+    if not dm.has_column_program():
+        print("locus %d has no column program" % k)
+        continue
+    reads = []
+    for _ in range(int(rng.integers(50, 400))):
+        n = int(rng.integers(1, 400))
+        r = workloads.make_reads(rng, loc, 1, n, locus_fraction=0.6, sub_rate=float(rng.choice([0.0, 0.01, 0.1])))[0]
+        if rng.random() < 0.3:      # homopolymer / low-complexity stretches provoke exact ties
+            p = int(rng.integers(0, max(1, n - 5)))
+            r = r[:p] + "A" * min(12, n - p) + r[p + 12:]
+            r = r[:n]
+        reads.append(r)
+    bases, off = _lib.encode_reads(reads)
+    which = np.zeros(len(reads), np.int32)
+    want_paths = (k % 5 == 0)
+    a = _lib.viterbi_batch([dm], bases, off, which, want_paths=want_paths)
+    b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=want_paths)
+    c = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_STREAM)
+    assert np.array_equal(a[0], b[0]), ("logp", k, flank, plen, copies, err)
+    assert np.array_equal(a[1], b[1]), ("summary", k, flank, plen, copies, err, np.flatnonzero((a[1] != b[1]).any(1))[:5])
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), ("stream", k)
+    if want_paths:
+        assert a[2] == b[2], ("paths", k)
+    total += len(reads)
+print("fuzz ok: %d loci, %d reads, %.1f s" % (n_loci, total, time.time() - t0))
