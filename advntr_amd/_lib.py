@@ -46,6 +46,11 @@ SYMBOLS = {
     "advntr_kwfilter_create": (_vp, [_vp, _vp, _vp, _i32]),
     "advntr_kwfilter_destroy": (None, [_vp]),
     "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "advntr_build_read_matchers": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _i32, _vp]),
+    "advntr_built_info": (ctypes.c_int, [_vp, _vp]),
+    "advntr_built_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "advntr_built_upload": (_vp, [_vp]),
+    "advntr_built_destroy": (None, [_vp]),
 }
 
 _lib = None
@@ -155,6 +160,99 @@ class DeviceModel(object):
             self.close()
         except Exception:
             pass
+
+
+class _UploadedModel(DeviceModel):
+    """A DeviceModel around an advntr_hmm handle the library created itself (advntr_built_upload)."""
+
+    def __init__(self, handle, m, silent_start):
+        self._h = handle
+        self.m, self.silent_start = int(m), int(silent_start)
+
+
+EXP_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+def _numpy_exp(src, dst, n, _user):
+    a = np.ctypeslib.as_array(ctypes.cast(src, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+    o = np.ctypeslib.as_array(ctypes.cast(dst, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+    np.exp(a, out=o)
+
+
+_NUMPY_EXP = EXP_FN(_numpy_exp)
+
+
+class BuiltModel(object):
+    """One model made by the native builder (advntr_built): host arrays + upload to the current device."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = np.zeros(6, np.int32)
+        check(load().advntr_built_info(self._h, ptr(info)))
+        self.m, self.silent_start, self.start_index, self.end_index, self.n_edges, self._names_bytes = \
+            [int(x) for x in info]
+
+    def arrays(self):
+        a = dict(m=self.m, silent_start=self.silent_start, start_index=self.start_index, end_index=self.end_index,
+                 in_ptr=np.zeros(self.m + 1, np.int32), in_src=np.zeros(self.n_edges, np.int32),
+                 in_logp=np.zeros(self.n_edges, np.float64), emis_logp=np.zeros((self.silent_start, 4), np.float64),
+                 state_class=np.zeros(self.m, np.uint16))
+        check(load().advntr_built_export(self._h, ptr(a["in_ptr"]), ptr(a["in_src"]), ptr(a["in_logp"]),
+                                         ptr(a["emis_logp"]), ptr(a["state_class"]), None))
+        return a
+
+    def names(self):
+        buf = ctypes.create_string_buffer(self._names_bytes + 1)
+        check(load().advntr_built_export(self._h, None, None, None, None, None, ctypes.addressof(buf)))
+        return buf.raw[:self._names_bytes].decode("ascii").split("\n")
+
+    def upload(self):
+        require_gpu()
+        h = load().advntr_built_upload(self._h)
+        if not h:
+            raise EngineError(ERR_ARG, last_error())
+        return _UploadedModel(h, self.m, self.silent_start)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().advntr_built_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp="numpy", threads=0):
+    """advntr_build_read_matchers over n loci -> list of BuiltModel.  exp: "numpy" passes numpy.exp for the two
+    probability round trips (what the reference calls; bit-identical parameters on the same machine), "libm" lets
+    the library use its own exp (no callback, <= 1 ulp away)."""
+    L = load()
+    n = len(lefts)
+    enc = lambda strs: (ctypes.c_char_p * max(len(strs), 1))(*[x.encode("ascii") for x in strs])
+    flat, off = [], np.zeros(n + 1, np.int32)
+    for i, rows in enumerate(repeat_lists):
+        flat.extend(rows)
+        off[i + 1] = len(flat)
+    cp = np.ascontiguousarray(copies, np.int32)
+    out = (ctypes.c_void_p * max(n, 1))()
+    fn = ctypes.cast(_NUMPY_EXP, ctypes.c_void_p) if exp == "numpy" else None
+    if exp not in ("numpy", "libm"):
+        raise ValueError("exp must be 'numpy' or 'libm'")
+    rc = L.advntr_build_read_matchers(n, enc(lefts), enc(rights), enc(flat), ptr(off), ptr(cp), float(max_error_rate),
+                                      fn, None, int(threads), out)
+    built = [BuiltModel(h) if h else None for h in list(out)[:n]]
+    if rc != OK:
+        msg = last_error()
+        for b in built:
+            if b is not None:
+                b.close()
+        if "not one of ACGT" in msg or "need a multiple alignment" in msg:
+            raise NotImplementedError(msg)
+        raise EngineError(rc, msg)
+    return built
 
 
 def _handles(models):

@@ -20,6 +20,7 @@
 #include "viterbi_columns.h"
 #include "forward_generic.h"
 #include "keyword_filter.h"
+#include "model_builder.h"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -943,3 +944,98 @@ extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, co
     g_err = keep;
     return rc;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Native model builder (model_builder.h) behind the C ABI
+// ------------------------------------------------------------------------------------------------
+struct advntr_built {
+    mb::Built b;
+};
+
+extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
+                                          const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
+                                          double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
+                                          advntr_built **out)
+{
+    if (n_loci < 0 || (n_loci && (!left_flank || !right_flank || !repeats || !repeat_off || !copies || !out)))
+        return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: bad argument");
+    for (int i = 0; i < n_loci; ++i) out[i] = nullptr;
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = std::min<int>(n_threads, std::max(1, n_loci));
+
+    struct Shared {
+        std::mutex exp_mu, err_mu;
+        advntr_exp_fn fn;
+        void *user;
+        int first_bad = -1;
+        std::string msg;
+    } sh;
+    sh.fn = exp_fn;
+    sh.user = user;
+    // serialise the caller's exp (a Python callback holds the interpreter lock anyway)
+    auto locked_exp = [](const double *in, double *o, int64_t n, void *u) {
+        Shared *s = (Shared *)u;
+        std::lock_guard<std::mutex> lk(s->exp_mu);
+        s->fn(in, o, n, s->user);
+    };
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_loci) return;
+            try {
+                if (!left_flank[i] || !right_flank[i]) throw std::invalid_argument("null flanking region");
+                std::vector<std::string> rows;
+                for (int r = repeat_off[i]; r < repeat_off[i + 1]; ++r) rows.emplace_back(repeats[r] ? repeats[r] : "");
+                advntr_built *B = new advntr_built;
+                B->b = mb::build_read_matcher(left_flank[i], right_flank[i], rows, copies[i], max_error_rate,
+                                              exp_fn ? (mb::ExpFn)locked_exp : nullptr, &sh);
+                out[i] = B;
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(sh.err_mu);
+                if (sh.first_bad < 0 || i < sh.first_bad) { sh.first_bad = i; sh.msg = e.what(); }
+            }
+        }
+    };
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    if (sh.first_bad >= 0) return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: locus %d: %s", sh.first_bad, sh.msg.c_str());
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_built_info(const advntr_built *B, int32_t *info)
+{
+    if (!B || !info) return fail(ADVNTR_ERR_ARG, "advntr_built_info: null argument");
+    info[0] = B->b.m; info[1] = B->b.silent_start; info[2] = B->b.start_index; info[3] = B->b.end_index;
+    info[4] = (int32_t)B->b.in_src.size(); info[5] = (int32_t)B->b.names.size();
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_built_export(const advntr_built *B, int32_t *in_ptr, int32_t *in_src, double *in_logp,
+                                   double *emis_logp, uint16_t *state_class, char *names)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_built_export: null model");
+    const mb::Built &b = B->b;
+    if (in_ptr) memcpy(in_ptr, b.in_ptr.data(), b.in_ptr.size() * sizeof(int32_t));
+    if (in_src) memcpy(in_src, b.in_src.data(), b.in_src.size() * sizeof(int32_t));
+    if (in_logp) memcpy(in_logp, b.in_logp.data(), b.in_logp.size() * sizeof(double));
+    if (emis_logp) memcpy(emis_logp, b.emis.data(), b.emis.size() * sizeof(double));
+    if (state_class) memcpy(state_class, b.state_class.data(), b.state_class.size() * sizeof(uint16_t));
+    if (names) memcpy(names, b.names.data(), b.names.size());
+    return ADVNTR_OK;
+}
+
+extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
+{
+    if (!B) { fail(ADVNTR_ERR_ARG, "advntr_built_upload: null model"); return nullptr; }
+    const mb::Built &b = B->b;
+    return advntr_hmm_create(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
+                             b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data());
+}
+
+extern "C" void advntr_built_destroy(advntr_built *B) { delete B; }

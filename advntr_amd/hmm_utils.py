@@ -191,7 +191,27 @@ def get_variable_number_of_repeats_matcher_hmm(patterns, copies=1, vpaths=None):
     return _rebuild_from_matrix(model, mat, states, 'Repeat Matcher HMM Model')
 
 
-def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None):
+def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None, native=True,
+                           exp="numpy"):
+    """hmm_utils.py:553-595.  native=True (default) builds the model in the library's C++ builder
+    (csrc/model_builder.h, ~1 ms); native=False assembles it call by call through advntr_amd.pomegranate, the way the
+    reference does through its pomegranate (~50 ms).  Both give the same arrays (tests/test_native_builder.py)."""
+    if native and not vpaths:
+        return build_read_matcher_models([(left_flanking_region, right_flanking_region, patterns, copies)],
+                                         threads=1, exp=exp)[0]
+    return _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies, vpaths)
+
+
+def build_read_matcher_models(loci, threads=0, exp="numpy"):
+    """Many loci at once on host threads: loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...]
+    -> list of baked models (advntr_build_read_matchers)."""
+    loci = list(loci)
+    built = _lib.build_read_matchers([l[0] for l in loci], [l[1] for l in loci], [list(l[2]) for l in loci],
+                                     [int(l[3]) for l in loci], settings.MAX_ERROR_RATE, exp=exp, threads=threads)
+    return [Model._from_built(b, 'Read Matcher') for b in built]
+
+
+def _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None):
     model = get_suffix_matcher_hmm(left_flanking_region)
     repeats_matcher = get_variable_number_of_repeats_matcher_hmm(patterns, copies, vpaths)
     right_flanking_matcher = get_prefix_matcher_hmm(right_flanking_region)

@@ -332,6 +332,11 @@ class HiddenMarkovModel(object):
         model.bake(verbose=verbose, merge=merge)
         return model
 
+    @classmethod
+    def _from_built(cls, built, name):
+        """A baked model around a model of the native builder (_lib.BuiltModel)."""
+        return _BuiltHiddenMarkovModel(built, name)
+
     # ---- device residency --------------------------------------------------------------------
     def baked_arrays(self):
         """The arrays the C ABI takes (advntr_hmm_create)."""
@@ -392,3 +397,71 @@ class HiddenMarkovModel(object):
     def log_probability_batch(self, sequences):
         bases, off = _lib.encode_reads(sequences)
         return _lib.forward_batch([self.device_model()], bases, off, np.zeros(len(sequences), np.int32))
+
+
+class _BuiltHiddenMarkovModel(HiddenMarkovModel):
+    """Same attributes as a model after bake(), backed by the native builder's arrays (csrc/model_builder.h).  The
+    host copies (CSR arrays, State list) are only materialised when something asks for them: scoring needs neither,
+    the model goes from the builder straight to the device (advntr_built_upload).  `states` carry the reference's
+    names (all any consumer of a vpath reads) and, for emitting states, a distribution made from the baked
+    log-probabilities."""
+
+    def __init__(self, built, name):
+        HiddenMarkovModel.__init__(self, name=name)
+        self.graph = None                      # the construction graph stays inside the native builder
+        self._built = built
+        self._arrays = None
+        self._states = None
+        self.n_states, self.n_edges = built.m, built.n_edges
+        self.silent_start, self.start_index, self.end_index = built.silent_start, built.start_index, built.end_index
+        self.d = 1
+        self.keymap = [{c: i for i, c in enumerate("ACGT")}]
+
+    @property
+    def states(self):
+        if self._states is None:
+            emis = self.baked_arrays()["emis_logp"]
+            out = []
+            for i, nm in enumerate(self._built.names()):
+                dist = None
+                if i < self.silent_start:
+                    dist = DiscreteDistribution({c: math.exp(emis[i, j]) for j, c in enumerate("ACGT")})
+                    dist.log_dist = {c: float(emis[i, j]) for j, c in enumerate("ACGT")}
+                out.append(State(dist, name=nm))
+            self._states = out
+            self.start, self.end = out[self.start_index], out[self.end_index]
+        return self._states
+
+    @states.setter
+    def states(self, value):
+        self._states = value or None
+
+    def bake(self, verbose=False, merge="All"):
+        pass                                   # already baked
+
+    def baked_arrays(self):
+        if self._arrays is None:
+            self._arrays = self._built.arrays()
+            a = self._arrays
+            self._in_ptr, self._in_src, self._in_logp, self._emis = a["in_ptr"], a["in_src"], a["in_logp"], a["emis_logp"]
+            self.finite = int(a["in_ptr"][self.end_index + 1] != a["in_ptr"][self.end_index])
+        return self._arrays
+
+    def state_classes(self):
+        return self.baked_arrays()["state_class"]
+
+    def set_flank_bases(self, mapping):
+        raise NotImplementedError("the native builder already encodes the flank bases in the state classes")
+
+    def dense_transition_matrix(self):
+        a = self.baked_arrays()
+        m = a["m"]
+        out = np.zeros((m, m))
+        dst = np.repeat(np.arange(m), np.diff(a["in_ptr"]))
+        out[a["in_src"], dst] = np.exp(a["in_logp"])
+        return out
+
+    def device_model(self):
+        if self._device is None:
+            self._device = self._built.upload()
+        return self._device

@@ -13,9 +13,40 @@ def rand_seq(rng, n):
 
 
 class Locus(object):
-    def __init__(self, left, right, units, copies, error_rate, model):
-        self.left, self.right, self.units, self.copies, self.error_rate, self.model = \
+    """Flanks, aligned repeat units, copies; the read-matcher model is built on first use."""
+
+    def __init__(self, left, right, units, copies, error_rate, model=None):
+        self.left, self.right, self.units, self.copies, self.error_rate, self._model = \
             left, right, units, copies, error_rate, model
+
+    @property
+    def model(self):
+        if self._model is None:
+            old = settings.MAX_ERROR_RATE
+            settings.MAX_ERROR_RATE = self.error_rate
+            try:
+                self._model = hmm_utils.get_read_matcher_model(self.left, self.right, self.units, self.copies)
+            finally:
+                settings.MAX_ERROR_RATE = old
+        return self._model
+
+    def device_model(self):
+        return self.model.device_model()
+
+
+def build_models(loci, threads=0):
+    """Build the models of many loci at once on host threads (advntr_build_read_matchers)."""
+    todo = [l for l in loci if l._model is None]
+    for rate in sorted(set(l.error_rate for l in todo)):
+        group = [l for l in todo if l.error_rate == rate]
+        old = settings.MAX_ERROR_RATE
+        settings.MAX_ERROR_RATE = rate
+        try:
+            models = hmm_utils.build_read_matcher_models([(l.left, l.right, l.units, l.copies) for l in group], threads)
+        finally:
+            settings.MAX_ERROR_RATE = old
+        for l, m in zip(group, models):
+            l._model = m
 
 
 def make_locus(rng, flank, pattern_len, copies, error_rate=0.05, n_units=1, max_subs=2):
@@ -29,13 +60,7 @@ def make_locus(rng, flank, pattern_len, copies, error_rate=0.05, n_units=1, max_
         for _ in range(int(rng.integers(0, max_subs + 1))):
             u[int(rng.integers(0, pattern_len))] = "ACGT"[int(rng.integers(0, 4))]
         units.append("".join(u))
-    old = settings.MAX_ERROR_RATE
-    settings.MAX_ERROR_RATE = error_rate
-    try:
-        model = hmm_utils.get_read_matcher_model(left, right, units, copies)
-    finally:
-        settings.MAX_ERROR_RATE = old
-    return Locus(left, right, units, copies, error_rate, model)
+    return Locus(left, right, units, copies, error_rate)
 
 
 def make_reads(rng, locus, n_reads, read_len, locus_fraction=0.4, sub_rate=0.01):
@@ -70,7 +95,7 @@ def s300(seed=20240601):
 
 
 def _c2_locus(args):
-    """One C2 locus (worker of make_c2's process pool): returns what the parent needs to upload the model."""
+    """One C2 locus and its calls (worker of make_c2_parallel's process pool; the model is built by the parent)."""
     k, seed, read_len, mapped_mean, unmapped_mean = args
     from .vntr_finder import get_copies_for_hmm, reverse_complement
     rng = np.random.default_rng([seed, k])
@@ -79,28 +104,13 @@ def _c2_locus(args):
     mapped = make_reads(rng, loc, int(rng.poisson(mapped_mean)), read_len, locus_fraction=0.9)
     unmapped = make_reads(rng, loc, int(rng.poisson(unmapped_mean)), read_len, locus_fraction=0.5)
     calls = mapped + unmapped + [reverse_complement(s) for s in unmapped]
-    return loc.model.baked_arrays(), calls
+    return (loc.left, loc.right, loc.units, loc.copies, loc.error_rate), calls
 
 
-class ArrayLocus(object):
-    """A locus known only through its baked arrays (built in a worker process)."""
-
-    def __init__(self, arrays):
-        self.arrays = arrays
-        self._dm = None
-
-    def device_model(self):
-        from . import _lib
-        if self._dm is None:
-            a = self.arrays
-            self._dm = _lib.DeviceModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], a["in_ptr"],
-                                        a["in_src"], a["in_logp"], a["emis_logp"], a["state_class"])
-        return self._dm
-
-
-def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None):
-    """make_c2 with the (Python) model construction spread over a process pool: 6719 loci take ~20 min on one core.
-    Per-locus seeds are independent of the worker count.  Returns ([ArrayLocus], reads, read_locus)."""
+def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None, build=True):
+    """make_c2 with the synthetic read generation spread over a process pool (per-locus seeds, independent of the
+    worker count); the models are then built by the native builder on host threads.  Returns ([Locus], reads,
+    read_locus)."""
     import multiprocessing as mp
     import os
     workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
@@ -108,10 +118,12 @@ def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapp
     with mp.get_context("fork").Pool(workers) as pool:
         res = pool.map(_c2_locus, jobs, chunksize=8)
     loci, reads, which = [], [], []
-    for k, (arrays, calls) in enumerate(res):
-        loci.append(ArrayLocus(arrays))
+    for k, (params, calls) in enumerate(res):
+        loci.append(Locus(*params))
         reads += calls
         which += [k] * len(calls)
+    if build:
+        build_models(loci)
     return loci, reads, np.asarray(which, dtype=np.int32)
 
 

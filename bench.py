@@ -98,8 +98,9 @@ def main():
     n = 150
     flags = _lib.FLAG_FORCE_GENERIC if args.generic else (_lib.FLAG_STREAM if args.stream else 0)
     if args.workload == "c2":
+        loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602 + rank, build=False)
         t_build = time.perf_counter()
-        loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602 + rank)
+        workloads.build_models(loci)           # native builder, all host cores
         t_build = time.perf_counter() - t_build
         locus = loci[0]
         bases, off = _lib.encode_reads(reads)
@@ -109,8 +110,7 @@ def main():
         dm = dms[0]
         ms = np.array([d.m for d in dms])
         m = int(round(float(np.mean(ms[which]))))
-        a = locus.arrays
-        P, E = a["silent_start"], int(np.mean([len(l.arrays["in_src"]) for l in loci]))
+        P, E = locus.model.silent_start, int(np.mean([l.model.n_edges for l in loci]))
         args.no_cpu = True
     else:
         locus = workloads.ref150()
@@ -191,7 +191,7 @@ def main():
                                     "150-bp reads per GPU, seed 20240601") if args.workload == "c1" else
                                    ("C2: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x "
                                     "~Poisson(80) mapped + 2*Poisson(40) unmapped-strand calls, seed 20240602; "
-                                    "host model build %.1f s (process pool)" % (args.loci, t_build)),
+                                    "host model build %.2f s (native builder, %d threads)" % (args.loci, t_build, os.cpu_count() or 1)),
                        "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
                        "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
                        "relaxations_per_s": value * (n + 1) * E},

@@ -142,6 +142,32 @@ int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const in
                          int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity, int64_t *n_out,
                          float *kernel_ms);
 
+/* ---- native model builder (the step that feeds advntr_hmm_create) ---------------------------------------
+ * Replaces, for the read-matcher model family, the Python construction route of the reference:
+ * get_read_matcher_model and its sub-builders (advntr/hmm_utils.py:290-595), the profile parameters
+ * (advntr/profile_hmm.py:13-161) and the pomegranate calls underneath (bake(merge=None) hmm.pyx:673-1123,
+ * dense_transition_matrix :492-514, from_matrix :3146-3238, concatenate :584-615) -- 0.8-1.0 s per locus there.
+ * Builds n_loci models on n_threads host threads (<= 0: all cores).  Locus i: left/right flanking regions as
+ * NUL-terminated ACGT strings (already trimmed to the wanted length), aligned repeat units
+ * repeats[repeat_off[i] .. repeat_off[i+1]) (equal-length rows over ACGT and '-'), copies[i] repeat copies.
+ * exp_fn: the exponential applied to log-probabilities where the reference calls numpy.exp (hmm.pyx:514); NULL =
+ * libm exp.  It is called from the worker threads, one call at a time.  out[i] receives the model or NULL;
+ * returns ADVNTR_OK or the first error (advntr_last_error names the locus).                                       */
+typedef struct advntr_built advntr_built;
+typedef void (*advntr_exp_fn)(const double *in, double *out, int64_t n, void *user);
+int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
+                               const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
+                               double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
+                               advntr_built **out);
+/* info[6] = m, silent_start, start_index, end_index, n_edges, bytes of the '\n'-joined state names (no NUL) */
+int advntr_built_info(const advntr_built *built, int32_t *info);
+/* copy out the arrays advntr_hmm_create takes (any pointer may be NULL to skip it) */
+int advntr_built_export(const advntr_built *built, int32_t *in_ptr, int32_t *in_src, double *in_logp,
+                        double *emis_logp, uint16_t *state_class, char *names);
+/* advntr_hmm_create on the built arrays (current device) */
+advntr_hmm *advntr_built_upload(const advntr_built *built);
+void advntr_built_destroy(advntr_built *built);
+
 #ifdef __cplusplus
 }
 #endif

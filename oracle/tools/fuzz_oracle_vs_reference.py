@@ -19,7 +19,7 @@ from oracle.oracle import OracleModel                # noqa: E402
 n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 seq = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
-n_reads = n_exact = 0
+n_reads = n_exact = n_native_exact = 0
 for k in range(n_loci):
     flank, plen, copies = int(rng.integers(3, 120)), int(rng.integers(2, 60)), int(rng.integers(1, 9))
     err = float(rng.choice([0.05, 0.3]))
@@ -27,7 +27,8 @@ for k in range(n_loci):
     ref_settings.MAX_ERROR_RATE = err
     my_settings.MAX_ERROR_RATE = err
     m = ref_hmm_utils.get_read_matcher_model(left, right, [pat], copies)
-    mine = my_hmm_utils.get_read_matcher_model(left, right, [pat], copies)
+    mine = my_hmm_utils.get_read_matcher_model(left, right, [pat], copies, native=False)
+    native = my_hmm_utils.get_read_matcher_model(left, right, [pat], copies)          # the library's C++ builder
     idx = {s: i for i, s in enumerate(m.states)}
     edges = [(idx[a], idx[b], d["probability"]) for a, b, d in m.graph.edges_iter(data=True)]
     assert [s.name for s in m.states] == [s.name for s in mine.states]
@@ -37,6 +38,13 @@ for k in range(n_loci):
     n_exact += int(all(x[2] == y[2] for x, y in zip(edges, mine_edges)))
     emis = [[s.distribution.log_probability(c) for c in "ACGT"] for s in m.states[:m.silent_start]]
     O = OracleModel(len(m.states), m.silent_start, m.start_index, m.end_index, edges, emis)
+    in_ptr, in_src, in_logp, _ = O.csr()
+    na = native.baked_arrays()
+    assert [s.name for s in m.states] == [s.name for s in native.states]
+    assert (na["silent_start"], na["start_index"], na["end_index"]) == (m.silent_start, m.start_index, m.end_index)
+    assert np.array_equal(na["in_ptr"], in_ptr) and np.array_equal(na["in_src"], in_src), "native builder: CSR order differs"
+    assert np.array_equal(na["emis_logp"], np.array(emis))
+    n_native_exact += int(np.array_equal(na["in_logp"], in_logp))
     for _ in range(40):
         n = int(rng.integers(1, 160))
         if rng.random() < 0.6:
@@ -56,4 +64,5 @@ for k in range(n_loci):
         assert abs(m.log_probability(r) - O.forward(r)) == 0.0, (k, r)
         n_reads += 1
 print("oracle == reference on %d loci / %d reads (logp, path, forward all bit-equal); product builder: structure identical on all, "
-      "log-probs bit-identical on %d/%d loci" % (n_loci, n_reads, n_exact, n_loci))
+      "log-probs bit-identical on %d/%d loci (stepwise) and %d/%d loci (native C++ builder)"
+      % (n_loci, n_reads, n_exact, n_loci, n_native_exact, n_loci))

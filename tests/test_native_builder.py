@@ -1,0 +1,99 @@
+"""The library's C++ model builder (csrc/model_builder.h, advntr_build_read_matchers) against the call-by-call
+assembly through the pomegranate mirror, which tests/test_builder_golden.py pins on the reference's own baked models.
+Host-only: no GPU is needed to build a model."""
+import numpy as np
+import pytest
+
+from advntr_amd import _lib, hmm_utils
+
+
+def _random_locus(rng, rows_max=6):
+    L = int(rng.integers(1, 40))
+    flank_l, flank_r = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+    dna = lambda n: "".join(rng.choice(list("ACGT"), n))
+    base = dna(L)
+    rows = []
+    for _ in range(int(rng.integers(1, rows_max + 1))):
+        r = list(base)
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, L))] = str(rng.choice(list("ACGT-")))
+        rows.append("".join(r))
+    if all(set(r) == {"-"} for r in rows):
+        rows[0] = base
+    copies = int(rng.integers(1, 6))
+    return dna(flank_l), dna(flank_r), rows, copies
+
+
+def _same(a, b, exact):
+    A, B = a.baked_arrays(), b.baked_arrays()
+    assert [s.name for s in a.states] == [s.name for s in b.states]
+    for k in ("m", "silent_start", "start_index", "end_index"):
+        assert A[k] == B[k], k
+    for k in ("in_ptr", "in_src", "state_class"):
+        assert np.array_equal(A[k], B[k]), k
+    assert np.array_equal(A["emis_logp"], B["emis_logp"])
+    if exact:
+        assert np.array_equal(A["in_logp"], B["in_logp"])
+    else:
+        fin = np.isfinite(B["in_logp"])
+        assert np.array_equal(np.isfinite(A["in_logp"]), fin)
+        assert np.all(np.abs(A["in_logp"][fin] - B["in_logp"][fin]) <= 4 * np.spacing(np.abs(B["in_logp"][fin])))
+    assert a.finite == b.finite
+
+
+def _usable(rows):
+    # the reference (and both builders) need at least one match column
+    gaps = [sum(r[c] == "-" for r in rows) for c in range(len(rows[0]))]
+    return any(g < 0.5 * len(rows) for g in gaps)
+
+
+def test_native_equals_stepwise_on_random_loci():
+    rng = np.random.default_rng(99)
+    loci = []
+    while len(loci) < 40:
+        l = _random_locus(rng)
+        if _usable(l[2]):
+            loci.append(l)
+    native = hmm_utils.build_read_matcher_models(loci, threads=4)               # numpy.exp through the callback
+    libm = hmm_utils.build_read_matcher_models(loci, threads=4, exp="libm")
+    for locus, n, lm in zip(loci, native, libm):
+        ref = hmm_utils.get_read_matcher_model(*locus, native=False)
+        _same(n, ref, exact=True)
+        _same(lm, ref, exact=False)
+
+
+def test_illumina_shapes_and_thread_counts_agree():
+    rng = np.random.default_rng(5)
+    dna = lambda n: "".join(rng.choice(list("ACGT"), n))
+    loci = [(dna(150), dna(150), [dna(L)], int(round(150.0 / L + 0.5))) for L in (6, 14, 57, 100)]
+    one = hmm_utils.build_read_matcher_models(loci, threads=1)
+    many = hmm_utils.build_read_matcher_models(loci, threads=0)
+    for locus, a, b in zip(loci, one, many):
+        _same(a, b, exact=True)
+        _same(a, hmm_utils.get_read_matcher_model(*locus, native=False), exact=True)
+    assert (one[1].n_states, one[1].silent_start, one[1].n_edges) == (1413, 921, 4626)      # REF150
+
+
+def test_builder_errors():
+    with pytest.raises(NotImplementedError):
+        hmm_utils.get_read_matcher_model("ACGTNACGT", "TTGACCAA", ["ACGTT"], 2)
+    with pytest.raises(NotImplementedError):
+        hmm_utils.get_read_matcher_model("ACGTACGT", "TTGACCAA", ["ACGTT", "ACG"], 2)
+    with pytest.raises(_lib.EngineError):
+        hmm_utils.get_read_matcher_model("ACGTACGT", "TTGACCAA", ["ACGTT"], 0)
+    with pytest.raises(_lib.EngineError):
+        hmm_utils.get_read_matcher_model("", "TTGACCAA", ["ACGTT"], 1)
+    # one bad locus in a batch: the call fails as a whole and names it
+    with pytest.raises(NotImplementedError, match="locus 1"):
+        hmm_utils.build_read_matcher_models([("ACGT", "ACGT", ["ACG"], 1), ("ACXT", "ACGT", ["ACG"], 1)])
+
+
+def test_built_model_host_surface():
+    m = hmm_utils.get_read_matcher_model("ACGTACGTAC", "TTGACCAATG", ["ACGTT"], 2)
+    assert m.states[m.start_index].name == "Read Matcher-start" and m.states[m.end_index].name == "Read Matcher-end"
+    assert m.start is m.states[m.start_index]
+    assert all(s.is_silent() == (i >= m.silent_start) for i, s in enumerate(m.states))
+    ref = hmm_utils.get_read_matcher_model("ACGTACGTAC", "TTGACCAATG", ["ACGTT"], 2, native=False)
+    assert np.array_equal(m.dense_transition_matrix(), ref.dense_transition_matrix())
+    i = m.silent_start - 1
+    assert m.states[i].distribution.log_probability("A") == ref.states[i].distribution.log_probability("A")
