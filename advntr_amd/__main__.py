@@ -6,6 +6,10 @@ for reads that are already extracted: keyword prefilter -> per-locus Viterbi sco
 Illumina aggregation (or PacBio dominant copy numbers) -> the reference's text output (genome_analyzer.py:158-170:
 the VNTR id on one line, the genotype `a/b` on the next).
 
+Loci come from --loci loci.json or from --models FILE.db, the reference's sqlite model database (table `vntrs`,
+advntr/models.py:120-161), optionally narrowed with --vntr-id.  Repeat segments of unequal length need --align-repeats
+(the library's own aligner stands in for the reference's `muscle` call).
+
 loci.json: [{"id": 301645, "left": "...", "right": "...", "pattern": "...", "repeat_segments": ["...", ...],
              "scaled_score": -1.1}, ...]   (repeat_segments pre-aligned when more than one, equal length)
 reads.fa : two-line FASTA (name line, sequence line), the format adVNTR-Filtering reads (filtering/main.cc:247-252).
@@ -26,7 +30,17 @@ def _read_fasta(path):
 
 def genotype(args):
     from . import filtering, hmm_utils, settings, vntr_finder
-    loci = json.load(open(args.loci))
+    settings.ALIGN_REPEATS = bool(args.align_repeats)
+    if args.models:
+        from . import models
+        wanted = set(args.vntr_id or ())
+        loci = [{"id": v.id, "left": v.left_flanking_region, "right": v.right_flanking_region, "pattern": v.pattern,
+                 "repeat_segments": v.get_repeat_segments() or [v.pattern],
+                 "scaled_score": v.scaled_score if v.scaled_score else None}
+                for v in models.load_unique_vntrs_data(args.models)
+                if (not wanted or v.id in wanted) and v.left_flanking_region and v.right_flanking_region]
+    else:
+        loci = json.load(open(args.loci))
     names, seqs = _read_fasta(args.reads)
     settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
     out = sys.stdout
@@ -75,7 +89,12 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m advntr_amd")
     sub = ap.add_subparsers(dest="cmd")
     g = sub.add_parser("genotype", help="RU-count genotypes of the given loci from extracted reads (GPU)")
-    g.add_argument("--loci", required=True)
+    src = g.add_mutually_exclusive_group(required=True)
+    src.add_argument("--loci", help="JSON list of loci")
+    src.add_argument("--models", help="sqlite model database in the reference's format (table vntrs)")
+    g.add_argument("--vntr-id", type=int, action="append", help="with --models: genotype only these ids")
+    g.add_argument("--align-repeats", action="store_true",
+                   help="align repeat segments of unequal length with the built-in aligner (instead of refusing them)")
     g.add_argument("--reads", required=True)
     g.add_argument("--pacbio", action="store_true", help="reads are trimmed spanning long reads (error rate 0.3)")
     g.add_argument("--haploid", action="store_true")

@@ -46,7 +46,8 @@ SYMBOLS = {
     "advntr_kwfilter_create": (_vp, [_vp, _vp, _vp, _i32]),
     "advntr_kwfilter_destroy": (None, [_vp]),
     "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "advntr_build_read_matchers": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _i32, _vp]),
+    "advntr_build_read_matchers": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _i32, _u32, _vp]),
+    "advntr_align_repeats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "advntr_built_info": (ctypes.c_int, [_vp, _vp]),
     "advntr_built_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "advntr_built_upload": (_vp, [_vp]),
@@ -225,7 +226,33 @@ class BuiltModel(object):
             pass
 
 
-def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp="numpy", threads=0):
+BUILD_ALIGN_REPEATS = 1
+
+
+def align_repeats(units):
+    """advntr_align_repeats: the built-in progressive aligner (stands in for the reference's `muscle` call; parity
+    with muscle is not claimed).  Returns the rows in input order."""
+    L = load()
+    n = len(units)
+    arr = (ctypes.c_char_p * max(n, 1))(*[u.encode("ascii") for u in units])
+    width = ctypes.c_int32(0)
+    cap = n * (2 * max([len(u) for u in units] or [0]) + 8)
+    buf = ctypes.create_string_buffer(max(cap, 1))
+    rc = L.advntr_align_repeats(arr, n, buf, cap, ctypes.byref(width))
+    if rc == ERR_TOO_LARGE:
+        cap = n * width.value
+        buf = ctypes.create_string_buffer(max(cap, 1))
+        rc = L.advntr_align_repeats(arr, n, buf, cap, ctypes.byref(width))
+    if rc != OK:
+        msg = last_error()
+        if "not one of ACGT" in msg:
+            raise NotImplementedError(msg)
+        raise EngineError(rc, msg)
+    w = width.value
+    return [buf.raw[i * w:(i + 1) * w].decode("ascii") for i in range(n)]
+
+
+def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp="numpy", threads=0, align=False):
     """advntr_build_read_matchers over n loci -> list of BuiltModel.  exp: "numpy" passes numpy.exp for the two
     probability round trips (what the reference calls; bit-identical parameters on the same machine), "libm" lets
     the library use its own exp (no callback, <= 1 ulp away)."""
@@ -242,7 +269,7 @@ def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp
     if exp not in ("numpy", "libm"):
         raise ValueError("exp must be 'numpy' or 'libm'")
     rc = L.advntr_build_read_matchers(n, enc(lefts), enc(rights), enc(flat), ptr(off), ptr(cp), float(max_error_rate),
-                                      fn, None, int(threads), out)
+                                      fn, None, int(threads), BUILD_ALIGN_REPEATS if align else 0, out)
     built = [BuiltModel(h) if h else None for h in list(out)[:n]]
     if rc != OK:
         msg = last_error()

@@ -21,6 +21,7 @@
 #include "forward_generic.h"
 #include "keyword_filter.h"
 #include "model_builder.h"
+#include "repeat_msa.h"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -956,7 +957,7 @@ struct advntr_built {
 extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
                                           const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
                                           double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
-                                          advntr_built **out)
+                                          uint32_t flags, advntr_built **out)
 {
     if (n_loci < 0 || (n_loci && (!left_flank || !right_flank || !repeats || !repeat_off || !copies || !out)))
         return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: bad argument");
@@ -988,6 +989,11 @@ extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *lef
                 if (!left_flank[i] || !right_flank[i]) throw std::invalid_argument("null flanking region");
                 std::vector<std::string> rows;
                 for (int r = repeat_off[i]; r < repeat_off[i + 1]; ++r) rows.emplace_back(repeats[r] ? repeats[r] : "");
+                if (flags & ADVNTR_BUILD_ALIGN_REPEATS) {
+                    bool ragged = false;
+                    for (const std::string &r : rows) ragged |= r.size() != rows[0].size();
+                    if (ragged) rows = msa::align_units(rows);
+                }
                 advntr_built *B = new advntr_built;
                 B->b = mb::build_read_matcher(left_flank[i], right_flank[i], rows, copies[i], max_error_rate,
                                               exp_fn ? (mb::ExpFn)locked_exp : nullptr, &sh);
@@ -1039,3 +1045,20 @@ extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
 }
 
 extern "C" void advntr_built_destroy(advntr_built *B) { delete B; }
+
+extern "C" int advntr_align_repeats(const char *const *units, int32_t n, char *out, int64_t capacity, int32_t *width)
+{
+    if (n < 0 || (n && !units) || !width) return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: bad argument");
+    try {
+        std::vector<std::string> in;
+        for (int i = 0; i < n; ++i) in.emplace_back(units[i] ? units[i] : "");
+        const std::vector<std::string> rows = msa::align_units(in);
+        *width = rows.empty() ? 0 : (int32_t)rows[0].size();
+        if ((int64_t)n * *width > capacity || (n && !out))
+            return fail(ADVNTR_ERR_TOO_LARGE, "advntr_align_repeats: need %lld bytes", (long long)n * *width);
+        for (int i = 0; i < n; ++i) memcpy(out + (size_t)i * *width, rows[i].data(), (size_t)*width);
+    } catch (const std::exception &e) {
+        return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: %s", e.what());
+    }
+    return ADVNTR_OK;
+}

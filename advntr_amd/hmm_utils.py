@@ -202,12 +202,15 @@ def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns
     return _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies, vpaths)
 
 
-def build_read_matcher_models(loci, threads=0, exp="numpy"):
+def build_read_matcher_models(loci, threads=0, exp="numpy", align=None):
     """Many loci at once on host threads: loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...]
-    -> list of baked models (advntr_build_read_matchers)."""
+    -> list of baked models (advntr_build_read_matchers).  align (default settings.ALIGN_REPEATS): align repeat
+    units of unequal length with the library's own aligner instead of refusing them."""
     loci = list(loci)
+    align = settings.ALIGN_REPEATS if align is None else align
     built = _lib.build_read_matchers([l[0] for l in loci], [l[1] for l in loci], [list(l[2]) for l in loci],
-                                     [int(l[3]) for l in loci], settings.MAX_ERROR_RATE, exp=exp, threads=threads)
+                                     [int(l[3]) for l in loci], settings.MAX_ERROR_RATE, exp=exp, threads=threads,
+                                     align=align)
     return [Model._from_built(b, 'Read Matcher') for b in built]
 
 

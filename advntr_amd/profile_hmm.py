@@ -121,7 +121,11 @@ def build_profile_hmm_for_repeats(repeats, error_rate):
     aligned (equal length); the reference would call the external `muscle` here (profile_hmm.py:166-171)."""
     if len(repeats) > 1:
         width = len(repeats[0])
-        if any(len(r) != width for r in repeats):
+        from . import settings
+        if any(len(r) != width for r in repeats) and settings.ALIGN_REPEATS:
+            from . import _lib
+            repeats = _lib.align_repeats(list(repeats))
+        elif any(len(r) != width for r in repeats):
             raise NotImplementedError("multiple un-aligned repeat units need an MSA (the reference shells out to "
                                       "`muscle`); pass pre-aligned rows -- see DESIGN.md, out of scope")
     return build_profile_hmm_pseudocounts_for_alignment(error_rate, list(repeats))

@@ -1,3 +1,9 @@
 """Run-time constants of the scoring path (mirror of the fields of /root/reference/advntr/settings.py that
 the path reads).  MAX_ERROR_RATE: 0.05 for Illumina, 0.3 for PacBio/nanopore (advntr_commands.py:66-71)."""
 MAX_ERROR_RATE = 0.05
+# The reference aligns the repeat units of a locus with the external program `muscle` (profile_hmm.py:166-171).  That
+# program is not part of this framework: by default repeat units must come aligned (equal-length rows) and unequal
+# lengths are refused; True lets the library's own progressive aligner (csrc/repeat_msa.h) stand in -- models built
+# that way are NOT claimed to equal a muscle-based build.
+ALIGN_REPEATS = False
+TRAINED_MODELS_DB = None        # path of the sqlite `vntrs` database (advntr/settings.py:10); see advntr_amd/models.py

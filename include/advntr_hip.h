@@ -151,14 +151,20 @@ int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const in
  * NUL-terminated ACGT strings (already trimmed to the wanted length), aligned repeat units
  * repeats[repeat_off[i] .. repeat_off[i+1]) (equal-length rows over ACGT and '-'), copies[i] repeat copies.
  * exp_fn: the exponential applied to log-probabilities where the reference calls numpy.exp (hmm.pyx:514); NULL =
- * libm exp.  It is called from the worker threads, one call at a time.  out[i] receives the model or NULL;
- * returns ADVNTR_OK or the first error (advntr_last_error names the locus).                                       */
+ * libm exp.  It is called from the worker threads, one call at a time.  flags: ADVNTR_BUILD_ALIGN_REPEATS aligns
+ * repeat units of unequal length with the built-in progressive aligner (the reference shells out to `muscle` there,
+ * profile_hmm.py:166-171; parity with muscle is NOT claimed, see csrc/repeat_msa.h) -- without it they are an error.
+ * out[i] receives the model or NULL; returns ADVNTR_OK or the first error (advntr_last_error names the locus).       */
 typedef struct advntr_built advntr_built;
 typedef void (*advntr_exp_fn)(const double *in, double *out, int64_t n, void *user);
+#define ADVNTR_BUILD_ALIGN_REPEATS 0x1u
 int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
                                const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
                                double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
-                               advntr_built **out);
+                               uint32_t flags, advntr_built **out);
+/* The aligner on its own: n units (ACGT) -> n rows of *width characters over ACGT and '-', written back to back into
+ * out (capacity bytes).  ADVNTR_ERR_TOO_LARGE with *width set when capacity < n * *width.                          */
+int advntr_align_repeats(const char *const *units, int32_t n, char *out, int64_t capacity, int32_t *width);
 /* info[6] = m, silent_start, start_index, end_index, n_edges, bytes of the '\n'-joined state names (no NUL) */
 int advntr_built_info(const advntr_built *built, int32_t *info);
 /* copy out the arrays advntr_hmm_create takes (any pointer may be NULL to skip it) */

@@ -516,3 +516,39 @@ def test_cli_genotype_text_output(tmp_path):
     out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"),
                           "--reads", str(tmp_path / "reads.fa")], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
     assert out == "11\n3/5\n12\n4/4\n"
+
+
+@pytest.mark.gpu
+def test_cli_genotype_from_model_database(tmp_path):
+    """The same pipeline fed from a sqlite model database in the reference's format, one locus with repeat segments of
+    unequal length (needs --align-repeats; refused without it)."""
+    import subprocess
+    import sys
+    from advntr_amd import models, workloads, vntr_finder
+    from conftest import ROOT
+    rng = np.random.default_rng(1618)
+    db = str(tmp_path / "models.db")
+    models.create_vntrs_database(db)
+    reads = []
+    for vid, alleles, ragged in ((21, (2, 4), False), (22, (3, 6), True)):
+        pattern = workloads.rand_seq(rng, 18)
+        left, right = workloads.rand_seq(rng, 500), workloads.rand_seq(rng, 500)
+        segs = [pattern, pattern, pattern[:7] + pattern[8:]] if ragged else [pattern, pattern]
+        v = models.ReferenceVNTR(vid, pattern, 1000 * vid, "chr1", None, None, len(segs))
+        v.init_from_xml(segs, left, right)
+        models.save_reference_vntr_to_database(v, db)
+        for copies in alleles:
+            allele = left + pattern * copies + right
+            for _ in range(30):
+                st = int(rng.integers(400, 460))
+                s = allele[st:st + 150]
+                reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
+    reads += [workloads.rand_seq(rng, 150) for _ in range(100)]
+    (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+    cmd = [sys.executable, "-m", "advntr_amd", "genotype", "--models", db, "--reads", str(tmp_path / "reads.fa")]
+    out = subprocess.run(cmd + ["--align-repeats"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out == "21\n2/4\n22\n3/6\n"
+    out = subprocess.run(cmd + ["--vntr-id", "21"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out == "21\n2/4\n"
+    bad = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert bad.returncode != 0 and b"alignment" in bad.stderr

@@ -97,3 +97,69 @@ def test_built_model_host_surface():
     assert np.array_equal(m.dense_transition_matrix(), ref.dense_transition_matrix())
     i = m.silent_start - 1
     assert m.states[i].distribution.log_probability("A") == ref.states[i].distribution.log_probability("A")
+
+
+# ---- the built-in repeat aligner (stands in for muscle; parity with muscle is not claimed) -----------------------
+def _check_alignment(units, rows):
+    assert len(rows) == len(units)
+    assert len(set(len(r) for r in rows)) == 1
+    for u, r in zip(units, rows):
+        assert r.replace("-", "") == u
+    width = len(rows[0])
+    assert all(any(r[c] != "-" for r in rows) for c in range(width))        # no all-gap column
+
+
+def test_aligner_properties():
+    rng = np.random.default_rng(3)
+    dna = lambda n: "".join(rng.choice(list("ACGT"), n))
+    # equal lengths, substitutions only: gap-free, i.e. the input itself
+    base = dna(30)
+    units = [base] * 3
+    for _ in range(4):
+        u = list(base)
+        u[int(rng.integers(0, 30))] = "ACGT"[int(rng.integers(0, 4))]
+        units.append("".join(u))
+    assert _lib.align_repeats(units) == units
+    # planted indels: every row still spells its unit, identical units get identical rows
+    for trial in range(30):
+        base = dna(int(rng.integers(4, 50)))
+        units = []
+        for _ in range(int(rng.integers(2, 12))):
+            u = list(base)
+            for _ in range(int(rng.integers(0, 3))):
+                p = int(rng.integers(0, len(u)))
+                kind = rng.random()
+                if kind < 0.4 and len(u) > 2:
+                    u.pop(p)
+                elif kind < 0.8:
+                    u.insert(p, "ACGT"[int(rng.integers(0, 4))])
+                else:
+                    u[p] = "ACGT"[int(rng.integers(0, 4))]
+            units.append("".join(u))
+        rows = _lib.align_repeats(units)
+        _check_alignment(units, rows)
+        assert rows == _lib.align_repeats(units)                               # deterministic
+        seen = {}
+        for u, r in zip(units, rows):
+            assert seen.setdefault(u, r) == r
+    # one deleted base against a majority: one gap in that row, no other row changes
+    rows = _lib.align_repeats(["ACGTTGCAACC", "ACGTGCAACC", "ACGTTGCAACC"])
+    assert rows[0] == rows[2] == "ACGTTGCAACC" and rows[1].count("-") == 1 and len(rows[1]) == 11
+
+
+def test_builder_aligns_ragged_units_only_on_request():
+    from advntr_amd import settings
+    left, right = "ACGTACGTACGGTCA", "TTGACCAATGCATGC"
+    units = ["ACGTTGCAACC", "ACGTGCAACC", "ACGTTGCAACC", "ACGTTGGCAACC"]
+    with pytest.raises(NotImplementedError):
+        hmm_utils.get_read_matcher_model(left, right, units, 3)
+    rows = _lib.align_repeats(units)
+    want = hmm_utils.get_read_matcher_model(left, right, rows, 3)
+    got = hmm_utils.build_read_matcher_models([(left, right, units, 3)], align=True)[0]
+    _same(got, want, exact=True)
+    settings.ALIGN_REPEATS = True
+    try:
+        _same(hmm_utils.get_read_matcher_model(left, right, units, 3), want, exact=True)
+        _same(hmm_utils.get_read_matcher_model(left, right, units, 3, native=False), want, exact=True)
+    finally:
+        settings.ALIGN_REPEATS = False
