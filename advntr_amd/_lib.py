@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadvntr_hip.so")
+LIB_PATH = os.environ.get("ADVNTR_HIP_LIB") or os.path.join(_HERE, "libadvntr_hip.so")   # override: kernel experiments
 
 OK, ERR_ARG, ERR_SYMBOL, ERR_DEVICE, ERR_TOO_LARGE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY, FLAG_STREAM = 1, 2, 4, 8

@@ -462,6 +462,9 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     out.n_cols = NC;
     out.n_sinks = n_sinks;
     if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");
+    // the sweep addresses class and emission records through 16-bit LDS addresses (tables start 16 B into LDS)
+    if (out.classes.size() * sizeof(ColClass) + out.emis.size() * sizeof(double) + 64 > 0x10000)
+        return fail("class + emission tables larger than 64 KiB of LDS");
     out.valid = true;
     return true;
 }

@@ -169,7 +169,9 @@ struct advntr_hmm {
     std::vector<uint16_t> sclass;
     bool has_class = false;
     ColProgramHost colprog;       // empty when the model is not a recognised read matcher
-    int32_t col_lds_bytes = 0;
+    int32_t col_lds_bytes = 0;     // LDS-resident tables of the column program: classes, emissions, column info, states
+    int32_t col_lds_core = 0;      // ... without the state table (only the traceback reads it)
+    int32_t col_lds_min = 0;       // ... without the column-info table either (the sweep indexes a padded copy of it)
     bool generic_ok = true;
     void *d_blob = nullptr;
     size_t blob_bytes = 0;
@@ -293,6 +295,8 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
     if (H->colprog.valid) {
         colblob = H->colprog.serialize();
         H->col_lds_bytes = ((const ColProgram *)colblob.data())->lds_bytes;
+        H->col_lds_core = (((const ColProgram *)colblob.data())->off_state - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
+        H->col_lds_min = (((const ColProgram *)colblob.data())->off_info - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
         o_col = B.add(colblob);
     }
     H->blob_bytes = B.bytes.size();
@@ -488,14 +492,23 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         ColumnLaunch &C = B->col;
         C.stream = (flags & ADVNTR_FLAG_STREAM) != 0;
         int n_max_col = 0;
+        size_t lds_core = 0, lds_min = 0;
         for (int r : col_reads) {
             const advntr_hmm *H = B->models[read_model[r]];
             C.nc_max = std::max(C.nc_max, H->colprog.n_cols);
-            C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes + (size_t)(H->colprog.n_cols + 128 * 4) * sizeof(ColInfo));
+            const size_t pad = (size_t)(H->colprog.n_cols + 128 * 4) * sizeof(ColInfo);
+            C.lds_bytes = std::max(C.lds_bytes, (size_t)H->col_lds_bytes + pad);
+            lds_core = std::max(lds_core, (size_t)H->col_lds_core + pad);
+            lds_min = std::max(lds_min, (size_t)H->col_lds_min + pad);
             n_max_col = std::max<int>(n_max_col, (int)(read_off[r + 1] - read_off[r]));
         }
-        int per_cu = (int)std::min<size_t>(4, (150 * 1024) / (C.lds_bytes + 16 + 1024));
-        per_cu = std::max(per_cu, 1);
+        // workgroups per CU are bounded by LDS (4 waves each; 1 workgroup per CU = 1 wave per SIMD): wide models (PacBio:
+        // > 1000 columns) leave the traceback's state table, then the unpadded column-info table, in HBM/L2 when
+        // that buys another resident workgroup
+        auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + 1024))); };
+        if (wgs(lds_core) > wgs(C.lds_bytes)) { C.lds_bytes = lds_core; C.lds_level = 1; }
+        if (wgs(lds_min) > wgs(C.lds_bytes)) { C.lds_bytes = lds_min; C.lds_level = 0; }
+        int per_cu = wgs(C.lds_bytes);
         if (C.stream) {
             // stream kernel: reads of one model, any length, packed back to back by each wavefront
             std::stable_sort(col_reads.begin(), col_reads.end(), [&](int a, int b) { return read_model[a] < read_model[b]; });

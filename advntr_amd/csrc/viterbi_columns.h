@@ -12,8 +12,8 @@
 // (v + t) + e in fp64, candidates compared in the reference's in-edge order with strict '>'
 // (/root/reference/pomegranate/hmm.pyx:2026-2083), so scores and back-pointers are bit-identical.
 //
-// Back-pointers: one byte per (row, column) cell = three 2-bit pointers (I, M, b slots), written in
-// diagonal-major order so that a chunk stores 64 consecutive bytes per step.  The last row's values are
+// Back-pointers: one byte per (row, column) cell = the outcomes of the cell's seven comparisons (relax_bit), written
+// in diagonal-major order so that a chunk stores 64 consecutive bytes per step.  The last row's values are
 // also written to a small per-wave buffer from which the "tail" states (prefix_end_prefix, model end:
 // fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  Lane 0 then walks
 // the pointers back and the wave summarises the path (path_summary.h).
@@ -25,12 +25,23 @@
 #include "viterbi_generic.h"
 
 #define COL_WAVES 4                 // wavefronts per workgroup (all on one model at a time)
+#ifndef COL_UNROLL2_MAX_K
+#define COL_UNROLL2_MAX_K 3          // sweeps with at most this many chunks run two steps per loop iteration
+#endif
 #define COL_MAX_TAIL 16
 #define COL_TILE_READS 16
-#define COL_LONG_K 4            // chunks per row tile of the long-read kernel (256-row tiles at 2 waves/SIMD measured best: 96 k
-                                // reads/s on the PacBio-size bench vs 87 k for 192-row tiles at 3 waves, 73 k at 4 waves with spills)
+// Long reads (> COL_MAX_READ rows) are swept in row tiles of 64*COL_LONG_K rows.  Measured on the PacBio-size bench
+// (scripts/pacbio_bench.py 40000: 1440-column model, reads of 900-1500 bases), once LDS no longer limited the
+// resident workgroups (ColArgs::lds_level): 192-row tiles at 4 waves/SIMD 265 k reads/s, 128-row tiles at 4 waves
+// 254 k, 192-row tiles at 3 waves 229 k, 256-row tiles at 2 waves 161 k.
+#ifndef COL_LONG_K
+#define COL_LONG_K 3
+#endif
 #ifndef COL_LONG_WAVES
-#define COL_LONG_WAVES 3
+#define COL_LONG_WAVES 4
+#endif
+#ifndef COL_LONG4_WAVES
+#define COL_LONG4_WAVES 2
 #endif
 #ifndef COL_MIN_WAVES_PER_SIMD
 #define COL_MIN_WAVES_PER_SIMD 4
@@ -54,6 +65,10 @@ struct ColArgs {
     int32_t lds_tables;      // bytes of LDS reserved for the tables
     int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
     int32_t ring;            // stream kernel: back-pointer slabs per wave (row tiles kept for the traceback)
+    int32_t lds_level;       // which tables of the column program are staged in LDS: 2 = all; 1 = all but the traceback's
+                             // column->state table; 0 = only classes and emissions (+ the padded info copy the sweep
+                             // indexes).  The rest is read from the model blob in HBM/L2, which leaves room for more
+                             // resident workgroups per CU on wide models (PacBio: > 1000 columns)
 };
 
 __device__ __forceinline__ int dpp_wave_shr1(int old, int src)
@@ -75,27 +90,51 @@ __device__ __forceinline__ double bcast63(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// One Viterbi relaxation: if (cand > best) { best = cand; ptr = code; }  -- strict '>' keeps the first maximum,
-// as the reference does (hmm.pyx:2039,2060,2080).  hipcc lowers this to v_cmp_gt_f64 + v_cndmask_b32 x3.  A
-// micro-benchmark (scripts/ubench/valu_rate.hip, profiles/r01_valu_ubench.txt) shows VCC-masked selects at ~23 cycles
-// each when issued back to back, so an assembly form (compare into an SGPR pair, v_max_f64 for the value, one e64
-// select for the pointer) was tried: inside this kernel the two are equal on the 150-base workload (5.26 vs 5.25 M
-// reads/s) and the assembly is 7 % slower on the long-read kernel (opaque blocks cost the scheduler more than the
-// selects cost the VALU), so the plain form is the default; -DCOL_RELAX_ASM builds the other one.
-__device__ __forceinline__ void relax_gt(double &best, int &ptr, const double cand, const int code)
+// One Viterbi relaxation: if (cand > best) best = cand  -- strict '>' keeps the first maximum, as the reference
+// does (hmm.pyx:2039,2060,2080) -- and the outcome of the comparison is shifted into `bits` (bits = 2*bits + won).
+// A cell's seven comparisons leave seven bits = its back-pointer byte (layout below), so no per-pointer selects and
+// no packing are needed.  Three instructions: v_cmp_gt_f64 into VCC, v_max_f64 for the value (equal to the select:
+// no NaNs occur and max(a,b) of equal values is that value), v_addc_co_u32 bits+bits+VCC.  Written as assembly
+// because the compiler lowers the C form to a compare, two or three VOP3 selects per relaxation and an or/shift
+// chain per cell (SQ_INSTS_VALU per launch 13.3 G -> see profiles); -DCOL_RELAX_PLAIN builds the C form.
+//   byte = aI<<6 | bI<<5 | aM<<4 | xM<<3 | bM<<2 | aB<<1 | bB      (a: 2nd candidate won, x: entry edge, b: last)
+__device__ __forceinline__ void relax_bit(double &best, int &bits, const double cand)
 {
-#ifndef COL_RELAX_ASM
-    if (cand > best) { best = cand; ptr = code; }
+#ifdef COL_RELAX_PLAIN
+    const bool won = cand > best;
+    best = won ? cand : best;
+    bits = bits + bits + (won ? 1 : 0);
 #else
-    unsigned long long m;
-    asm("v_cmp_gt_f64_e64 %0, %3, %1\n\t"
-        "v_max_f64 %1, %1, %3\n\t"
+    asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
+        "v_max_f64 %0, %0, %2\n\t"
         "s_nop 0\n\t"
-        "v_cndmask_b32_e64 %2, %2, %4, %0"
-        : "=&s"(m), "+v"(best), "+v"(ptr)
-        : "v"(cand), "v"(code));
+        "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
+        : "+v"(best), "+v"(bits)
+        : "v"(cand)
+        : "vcc");
 #endif
 }
+// the first relaxation of a cell starts the byte (bits = won): saves the move that would clear it
+__device__ __forceinline__ void relax_bit_first(double &best, int &bits, const double cand)
+{
+#ifdef COL_RELAX_PLAIN
+    const bool won = cand > best;
+    best = won ? cand : best;
+    bits = won ? 1 : 0;
+#else
+    asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
+        "v_max_f64 %0, %0, %2\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %3, vcc"
+        : "+v"(best), "=v"(bits)
+        : "v"(cand), "v"(0)
+        : "vcc");
+#endif
+}
+// pointers out of a back-pointer byte: 0/1/2(/3) = index of the winning candidate in evaluation order
+__device__ __forceinline__ int bp_ptr_I(const int byte) { return (byte & 0x20) ? 2 : ((byte >> 6) & 1); }
+__device__ __forceinline__ int bp_ptr_M(const int byte) { return (byte & 0x04) ? 3 : ((byte & 0x08) ? 2 : ((byte >> 4) & 1)); }
+__device__ __forceinline__ int bp_ptr_B(const int byte) { return (byte & 0x01) ? 2 : ((byte >> 1) & 1); }
 
 #ifndef ADVNTR_LSE2_DEFINED
 #define ADVNTR_LSE2_DEFINED
@@ -113,11 +152,31 @@ __device__ __forceinline__ double lse2(double x, double y)
 }
 #endif
 
+// LDS byte address of a pointer into the workgroup's shared memory, and typed reads at such an address.  The sweep's
+// info words carry ready LDS addresses of the column's transition class and emission records (16 bits each: the class
+// and emission tables sit at the start of the table area, far below 64 KiB), so a lane reaches its parameters with
+// an `and`/`add` instead of an unpack-multiply-add chain per table.
+typedef __attribute__((address_space(3))) const ColClass LdsClass;
+typedef __attribute__((address_space(3))) const double LdsDouble;
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+typedef __attribute__((address_space(3))) const unsigned long long LdsU64;
+__device__ __forceinline__ uint2 lds_uint2(const unsigned addr)
+{
+    const unsigned long long w = *(LdsU64 *)(size_t)addr;
+    return make_uint2((unsigned)w, (unsigned)(w >> 32));
+}
+
 struct LdsTables {
+    unsigned class_base, emis_base;   // LDS byte addresses of the two tables
+    unsigned pinfo;                   // LDS byte address of the padded info copy (record c + 64K; 0 if it does not fit):
+                                      // {v0b, class address | flags << 16, emM address | emI address << 16}
     const ColClass *classes;
     const double *emis;
-    const ColInfo *info;      // what the sweep indexes: padded copy (c + 64K) or the original (c + 1)
-    const ColInfo *info0;     // original table, index c + 1
+    const ColInfo *info0;     // original table, index c + 1 (LDS or, for wide models, the model blob in HBM/L2)
     const ColState *state;
 };
 
@@ -127,6 +186,8 @@ struct ColRegs {
     int erwin[K], x[K];
     uint2 meta[K];             // this step's column info words (class / emission ids / flags), loaded a step ahead
     double v0b0;               // chunk 0: row-0 value of this step's column
+    double n0I, n0M;           // chunk 0, first tile: shifted I/M values; lane 0 holds the row-0 value -inf for the
+                               // whole sweep (wave_shr never writes lane 0), so the shift needs no fill move
     int sflag[K];              // stream mode: bit 0 = first row of a read, bit 1 = last row, bits 8.. = capture slot
     // row-tiling only: values of the previous tile's last row for 64 columns (lane i <-> column cb+i), and
     // the next 64 (prefetched)
@@ -154,8 +215,10 @@ struct TileCtx {
 __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
 {
     // lane i <- v[i-1]; lane 0 <- prev_chunk[63]   (wave_ror:1 feeds the `old` operand of wave_shr:1)
-    const int rlo = __builtin_amdgcn_update_dpp(0, __double2loint(prev_chunk), 0x13C, 0xf, 0xf, false);
-    const int rhi = __builtin_amdgcn_update_dpp(0, __double2hiint(prev_chunk), 0x13C, 0xf, 0xf, false);
+    // (every lane of a rotate has a source, so the move needs no `old` value: mov_dpp instead of update_dpp saves
+    // the v_mov that would initialise it)
+    const int rlo = __builtin_amdgcn_mov_dpp(__double2loint(prev_chunk), 0x13C, 0xf, 0xf, false);
+    const int rhi = __builtin_amdgcn_mov_dpp(__double2hiint(prev_chunk), 0x13C, 0xf, 0xf, false);
     const int lo = dpp_wave_shr1(rlo, __double2loint(v));
     const int hi = dpp_wave_shr1(rhi, __double2hiint(v));
     return __hiloint2double(hi, lo);
@@ -176,21 +239,23 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     const int t = 64 * k + lane + 1;
     const int c = s - t;
     const int cc = CHECKED ? min(max(c + 1, 0), NC + 1) : c + TPAD;
+    // meta.x = class LDS address | flags << 16;  meta.y = emM record LDS address | emI record LDS address << 16
     uint2 meta;
     double v0b = 0.0;
     if (CHECKED) {
         const ColInfo inf = L.info0[cc];
-        meta = make_uint2((unsigned)inf.tclass | ((unsigned)inf.emM << 16), (unsigned)inf.emI | ((unsigned)inf.flags << 16));
+        meta = make_uint2((L.class_base + (unsigned)inf.tclass * (unsigned)sizeof(ColClass)) | ((unsigned)inf.flags << 16),
+                          (L.emis_base + (unsigned)inf.emM * (COL_EMIS_STRIDE * 8u)) |
+                              ((L.emis_base + (unsigned)inf.emI * (COL_EMIS_STRIDE * 8u)) << 16));
         v0b = inf.v0b;
     } else {
         // the info word was loaded during the previous step (software pipelining of the dependent LDS chain
         // info -> class record); fetch the next column's now
         meta = R.meta[k];
-        R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc + 1) + 8);
-        if (MODE == 0 && k == 0) { v0b = R.v0b0; R.v0b0 = L.info[cc + 1].v0b; }
+        R.meta[k] = lds_uint2(L.pinfo + (unsigned)(cc + 1) * 16u + 8u);
+        if (MODE == 0 && k == 0) { v0b = R.v0b0; R.v0b0 = *(LdsDouble *)(size_t)(L.pinfo + (unsigned)(cc + 1) * 16u); }
     }
-    const unsigned tclass = meta.x & 0xffffu, emM = meta.x >> 16, emI = meta.y & 0xffffu;
-    const ColClass *T = L.classes + tclass;
+    LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
     double fwd_mX = -INFINITY;
     if (FWD && MODE == 0 && k == 0) {            // row 0 / entry terms of the sum-product recursion (lane 0 only)
         const int cq = min(max(c, 0), NC - 1);
@@ -201,8 +266,8 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     double nI, nM, nB;
     if (k == 0) {
         if (MODE == 0) {
-            nI = shift_up1(R.I[0], -INFINITY);
-            nM = shift_up1(R.M[0], -INFINITY);
+            nI = R.n0I = shift_up1(R.I[0], R.n0I);
+            nM = R.n0M = shift_up1(R.M[0], R.n0M);
             nB = shift_up1(R.B[0], v0b);          // row 0 is read independent (host precomputed)
         } else {
             nI = shift_up1(R.I[0], injI);
@@ -217,23 +282,24 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     const bool first_row = MODE == 2 ? (R.sflag[k] & 1) != 0 : false;
     const bool chunk_first = MODE == 2 && ((C.hasfirst >> k) & 1u);          // wave-uniform
     if (chunk_first) {                            // a read starts in this chunk: its row 0 is the model's
-        const double v0c = CHECKED ? v0b : L.info[cc].v0b;
+        const double v0c = CHECKED ? v0b : *(LdsDouble *)(size_t)(L.pinfo + (unsigned)cc * 16u);
         nI = first_row ? -INFINITY : nI;
         nM = first_row ? -INFINITY : nM;
         nB = first_row ? v0c : nB;
     }
-    const double eI = L.emis[emI * COL_EMIS_STRIDE + R.x[k]];
-    const double eM = L.emis[emM * COL_EMIS_STRIDE + R.x[k]];
+    const double eI = *(LdsDouble *)(size_t)((meta.y >> 16) + R.x[k]);          // R.x = 8 * base code
+    const double eM = *(LdsDouble *)(size_t)((meta.y & 0xffffu) + R.x[k]);
     double vI, vM, vB;
-    int pi = 0, pm = 0, pb = 0;
+    int bits;                     // the cell's back-pointer byte, one comparison outcome per bit (relax_bit)
     if (FWD) {
+        bits = 0;
         // sum-product: pair_lse folds in the reference's in-edge order (hmm.pyx:1429-1480), emission added last
         vI = lse2(lse2(nI + T->iI, nM + T->iM), nB + T->iD) + eI;
         double accM = lse2(R.pI[k] + T->mI, R.pM[k] + T->mM);
         if (MODE == 0 && k == 0) accM = lse2(accM, (t == 1) ? fwd_mX : -INFINITY);
         vM = lse2(accM, R.pB[k] + T->mD) + eM;
         vB = lse2(lse2(R.I[k] + T->dI, R.M[k] + T->dM), R.B[k] + T->dD);
-        const unsigned flf = meta.y >> 16;
+        const unsigned flf = meta.x >> 16;
         if (__ballot((flf & 3u) != 0)) {
             if (flf & COL_FLAG_SINK) { vB = R.er[k]; R.er[k] = -INFINITY; }
             if (flf & COL_FLAG_FEED) R.er[k] = lse2(R.er[k], vB + T->erw);
@@ -241,23 +307,24 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     } else {
     // I_c(t) <- [I_c, M_c, b_c](t-1)
     vI = (nI + T->iI) + eI;
-    relax_gt(vI, pi, (nM + T->iM) + eI, 1);
-    relax_gt(vI, pi, (nB + T->iD) + eI, 2);
+    relax_bit_first(vI, bits, (nM + T->iM) + eI);
+    relax_bit(vI, bits, (nB + T->iD) + eI);
     // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); the entry edge X only exists for row 1 (chunk 0, lane 0)
     vM = (R.pI[k] + T->mI) + eM;
-    relax_gt(vM, pm, (R.pM[k] + T->mM) + eM, 1);
-    if (MODE == 0 && k == 0) relax_gt(vM, pm, ((t == 1) ? T->mX : -INFINITY) + eM, 2);
-    if (chunk_first) relax_gt(vM, pm, (first_row ? T->mX : -INFINITY) + eM, 2);
-    relax_gt(vM, pm, (R.pB[k] + T->mD) + eM, 3);
+    relax_bit(vM, bits, (R.pM[k] + T->mM) + eM);
+    if (MODE == 0 && k == 0) relax_bit(vM, bits, ((t == 1) ? T->mX : -INFINITY) + eM);
+    else if (chunk_first) relax_bit(vM, bits, (first_row ? T->mX : -INFINITY) + eM);
+    else bits += bits;                                               // no entry edge here: its bit stays 0
+    relax_bit(vM, bits, (R.pB[k] + T->mD) + eM);
     // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
     vB = R.I[k] + T->dI;
-    relax_gt(vB, pb, R.M[k] + T->dM, 1);
-    relax_gt(vB, pb, R.B[k] + T->dD, 2);
-    const unsigned fl = meta.y >> 16;
+    relax_bit(vB, bits, R.M[k] + T->dM);
+    relax_bit(vB, bits, R.B[k] + T->dD);
+    const unsigned fl = meta.x >> 16;
     if (__ballot((fl & 3u) != 0)) {                                  // wave-uniform skip
         if (fl & COL_FLAG_SINK) {
-            vB = R.er[k];
-            pb = 3;
+            vB = R.er[k];                                            // fan-in column: the traceback reads the winner
+                                                                     // from sinkbp whatever the byte's B bits say
             if (t <= C.n_tile) C.sinkbp[(fl >> 4) * C.sink_stride + C.row0 + t] = R.erwin[k];   // padding rows own no slot
             R.er[k] = -INFINITY;
         }
@@ -270,7 +337,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
     R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
 #ifndef EXP_NO_BP
-    if (!FWD) C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)(pi | (pm << 2) | (pb << 4));
+    if (!FWD) C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)bits;
 #endif
     if (MODE == 2) {
         if (k == K - 1) {                                            // last row of a full tile -> next tile's seam
@@ -324,14 +391,23 @@ __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int
 #pragma unroll
     for (int k = KHI; k >= KLO; --k) {              // info words of the phase's first step
         const int cc = s0 - (64 * k + lane + 1) + TPAD;
-        R.meta[k] = *(const uint2 *)((const uint8_t *)(L.info + cc) + 8);
-        if (MODE == 0 && k == 0) R.v0b0 = L.info[cc].v0b;
+        R.meta[k] = lds_uint2(L.pinfo + (unsigned)cc * 16u + 8u);
+        if (MODE == 0 && k == 0) R.v0b0 = *(LdsDouble *)(size_t)(L.pinfo + (unsigned)cc * 16u);
     }
-    for (int s = s0; s <= s1; ++s) {
+    auto step = [&](const int s) {
         double injI = 0, injM = 0, injB = 0;
         if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
         for (int k = KHI; k >= KLO; --k) col_cell<K, false, MODE, FWD>(R, k, L, C, s, lane, injI, injM, injB);
+    };
+    // two steps per iteration: the "previous step" copies (pI/pM/pB <- shifted values) become register renames and
+    // the loop overhead halves (-4.6 % kernel time at K = 3); at K = 4 the doubled body only adds spills
+    if (COL_UNROLL2_MAX_K >= K) {
+        int s = s0;
+        for (; s < s1; s += 2) { step(s); step(s + 1); }
+        if (s == s1) step(s);
+    } else {
+        for (int s = s0; s <= s1; ++s) step(s);
     }
 }
 
@@ -340,7 +416,7 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
                                           const uint8_t *__restrict__ seq_tile, const int lane,
                                           const int *slot_x = nullptr, const int *slot_flag = nullptr)
 {
-    const int NC = C.NC, n = C.n_tile;
+    const int NC = __builtin_amdgcn_readfirstlane(C.NC), n = __builtin_amdgcn_readfirstlane(C.n_tile);   // scalar loop bounds
     ColRegs<K> R;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -348,14 +424,15 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
         R.erwin[k] = 0;
         const int t = 64 * k + lane + 1;
         if (MODE == 2) {
-            R.x[k] = slot_x[k];
+            R.x[k] = slot_x[k] * 8;
             R.sflag[k] = slot_flag[k];
         } else {
-            R.x[k] = (t <= n) ? (int)seq_tile[t - 1] : 0;
+            R.x[k] = (t <= n) ? 8 * (int)seq_tile[t - 1] : 0;
             R.sflag[k] = 0;
         }
     }
     R.sI = R.sM = R.sB = R.tI = R.tM = R.tB = -INFINITY;
+    R.n0I = R.n0M = -INFINITY;
     if (MODE != 0) {                                // columns 0..63 of the seam; seam_fetch rotates at s = 1
         const int cn = min(lane, NC - 1);
         R.tI = C.seam[cn * 3 + 0];
@@ -462,7 +539,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             const int tt = t - lane, cc = c - lane;
             const bool valid = tt >= 1 && cc >= 1;
             const int byte = valid ? bp_at(tt, cc) : 0xff;
-            const unsigned long long mm = __ballot(valid && ((byte >> 2) & 3) == 1);
+            const unsigned long long mm = __ballot(valid && bp_ptr_M(byte) == 1);
             // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
             const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
@@ -472,7 +549,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
             const int lastbyte = __shfl(byte, run, 64);
-            const int p = (lastbyte >> 2) & 3;
+            const int p = bp_ptr_M(lastbyte);
             const ColState cs = L.state[c - run + 1];
             t -= run + 1;
             c -= run;
@@ -488,13 +565,13 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             const int tt = t - lane;
             const bool valid = tt >= 1;
             const int byte = valid ? bp_at(tt, c) : 0xff;
-            const unsigned long long ii = __ballot(valid && (byte & 3) == 0);
+            const unsigned long long ii = __ballot(valid && bp_ptr_I(byte) == 0);
             const int run = (~ii == 0ull) ? 64 : (__ffsll((long long)~ii) - 1);
             const int cells = min(run + 1, 64);
             if (lane < cells) rev[len + lane] = cs.sI;
             len += cells;
             if (run >= 64) { t -= 64; continue; }
-            slot = __shfl(byte, run, 64) & 3;                          // 1 -> M, 2 -> b of the same column
+            slot = bp_ptr_I(__shfl(byte, run, 64));                    // 1 -> M, 2 -> b of the same column
             t -= run + 1;
             continue;
         }
@@ -502,7 +579,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
         ++len;
         const int byte = bp_at(t, c);
         {
-            const int p = (byte >> 4) & 3;
+            const int p = (L.info0[c + 1].flags & COL_FLAG_SINK) ? 3 : bp_ptr_B(byte);
             if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
             else { c -= 1; slot = p; }
         }
@@ -524,28 +601,43 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
 // copy fits.
 template <int K>
 __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, uint8_t *tables, const int lds_tables,
-                                            LdsTables &L, const int tid)
+                                            const int lds_level, LdsTables &L, const int tid)
 {
     __syncthreads();
     const uint4 *src = (const uint4 *)((const uint8_t *)cp + cp->off_class);
     uint4 *dst = (uint4 *)tables;
-    for (int i = tid; i < cp->lds_bytes / 16; i += COL_WAVES * 64) dst[i] = src[i];
+    const int staged = lds_level >= 2 ? cp->lds_bytes
+                     : (((lds_level == 1 ? cp->off_state : cp->off_info) - cp->off_class + 15) & ~15);
+    for (int i = tid; i < staged / 16; i += COL_WAVES * 64) dst[i] = src[i];
     L.classes = (const ColClass *)tables;
     L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
-    L.info = (const ColInfo *)(tables + (cp->off_info - cp->off_class));
-    L.info0 = L.info;
-    L.state = (const ColState *)(tables + (cp->off_state - cp->off_class));
-    const bool padded = (size_t)cp->lds_bytes + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)lds_tables;
+    L.class_base = lds_addr(L.classes);
+    L.emis_base = lds_addr(L.emis);
+    L.info0 = lds_level >= 1 ? (const ColInfo *)(tables + (cp->off_info - cp->off_class))
+                             : (const ColInfo *)((const uint8_t *)cp + cp->off_info);
+    L.pinfo = 0;
+    L.state = lds_level >= 2 ? (const ColState *)(tables + (cp->off_state - cp->off_class))
+                             : (const ColState *)((const uint8_t *)cp + cp->off_state);
+    // (the 16-bit address fields need the class and emission tables below 64 KiB of LDS)
+    const bool padded = (size_t)staged + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)lds_tables &&
+                        L.emis_base + (unsigned)cp->n_eclass * (COL_EMIS_STRIDE * 8u) <= 0x10000u;
     if (padded) {
         __syncthreads();
-        uint4 *pinfo = (uint4 *)(tables + cp->lds_bytes);
-        const uint4 *sinfo = (const uint4 *)L.info0;
+        uint4 *pinfo = (uint4 *)(tables + staged);
         const int ncol = cp->n_cols;
         for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
             const int c = i - 64 * K;
-            pinfo[i] = sinfo[(c >= 0 && c < ncol) ? c + 1 : 0];
+            const ColInfo inf = L.info0[(c >= 0 && c < ncol) ? c + 1 : 0];
+            uint4 w;
+            const unsigned long long vb = (unsigned long long)__double_as_longlong(inf.v0b);
+            w.x = (unsigned)vb;
+            w.y = (unsigned)(vb >> 32);
+            w.z = (L.class_base + (unsigned)inf.tclass * (unsigned)sizeof(ColClass)) | ((unsigned)inf.flags << 16);
+            w.w = (L.emis_base + (unsigned)inf.emM * (COL_EMIS_STRIDE * 8u)) |
+                  ((L.emis_base + (unsigned)inf.emI * (COL_EMIS_STRIDE * 8u)) << 16);
+            pinfo[i] = w;
         }
-        L.info = (const ColInfo *)pinfo;
+        L.pinfo = lds_addr(pinfo);
     }
     __syncthreads();
     return padded;
@@ -593,7 +685,7 @@ __device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t
 
 // LONG = reads longer than 64*K rows, processed in row tiles of 64*K rows (K = 4).
 template <int K, bool LONG>
-__global__ void __launch_bounds__(COL_WAVES * 64, (K >= 4 ? (LONG ? 2 : 3) : (LONG ? COL_LONG_WAVES : COL_MIN_WAVES_PER_SIMD)))
+__global__ void __launch_bounds__(COL_WAVES * 64, (K >= 4 ? (LONG ? COL_LONG4_WAVES : 3) : (LONG ? COL_LONG_WAVES : COL_MIN_WAVES_PER_SIMD)))
 viterbi_columns_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -618,14 +710,14 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
         __syncthreads();
-        const int ti = *tile_slot;
+        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);    // wave-uniform => scalar loop bounds downstream
         if (ti >= g.n_tiles) break;
         const ColTile tile = g.tiles[ti];
         if (tile.model != cur_model) {                      // (re)stage the model's class tables in LDS
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
+            padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = cp->n_cols;
         const int64_t slab = (int64_t)(TPAD + NC) * TPAD;      // back-pointer bytes per row tile
@@ -724,14 +816,14 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
         __syncthreads();
-        const int ti = *tile_slot;
+        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);    // wave-uniform => scalar loop bounds downstream
         if (ti >= g.n_tiles) break;
         const ColTile tile = g.tiles[ti];
         if (tile.model != cur_model) {
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
+            padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = cp->n_cols;
         for (int j = wave; j < tile.count; j += COL_WAVES) {
@@ -815,14 +907,14 @@ viterbi_columns_stream_kernel(ColArgs g, uint32_t flags)
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
         __syncthreads();
-        const int ti = *tile_slot;
+        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);    // wave-uniform => scalar loop bounds downstream
         if (ti >= g.n_tiles) break;
         const ColTile tile = g.tiles[ti];
         if (tile.model != cur_model) {
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<K>(cp, tables, g.lds_tables, L, tid);
+            padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = cp->n_cols;
         const int64_t slab = (int64_t)(TPAD + NC) * TPAD;
@@ -921,6 +1013,7 @@ struct ColumnLaunch {
     int nc_max = 0;
     int sink_stride = COL_MAX_READ + 1;
     size_t lds_bytes = 0;
+    int lds_level = 2;
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
@@ -946,6 +1039,7 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
     g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     const int grid = std::min(cl.grid, g.n_tiles);
     hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
@@ -964,6 +1058,7 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
     g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.ring = cl.ring;
     const int grid = std::min(cl.grid, g.n_tiles);
@@ -983,6 +1078,7 @@ static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a,
     g.tile_counter = cl.d_tile_counters + slot;
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
     const int grid = std::min(cl.grid, g.n_tiles);
     hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g);
 }
