@@ -94,34 +94,58 @@ def s300(seed=20240601):
     return make_locus(np.random.default_rng(seed), 30, 12, 3, 0.05)
 
 
-def _c2_locus(args):
-    """One C2 locus and its calls (worker of make_c2_parallel's process pool; the model is built by the parent)."""
+def _c2_plan(args):
+    """Locus k of the C2 model set and its read counts (cheap: no reads are generated).  Seeded per locus, so any
+    subset of the loci can be produced on any rank."""
     k, seed, read_len, mapped_mean, unmapped_mean = args
-    from .vntr_finder import get_copies_for_hmm, reverse_complement
+    from .vntr_finder import get_copies_for_hmm
     rng = np.random.default_rng([seed, k])
     plen = int(rng.integers(6, 101))
     loc = make_locus(rng, read_len, plen, get_copies_for_hmm(read_len, plen), 0.05, n_units=int(rng.integers(2, 21)))
-    mapped = make_reads(rng, loc, int(rng.poisson(mapped_mean)), read_len, locus_fraction=0.9)
-    unmapped = make_reads(rng, loc, int(rng.poisson(unmapped_mean)), read_len, locus_fraction=0.5)
+    return loc, int(rng.poisson(mapped_mean)), int(rng.poisson(unmapped_mean))
+
+
+def c2_plan(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40):
+    """[(calls, states)] of every C2 locus -- what the multi-GPU partitioner needs (sharding.locus_work's inputs)
+    without generating a read: calls = mapped + 2 * unmapped, states = 6F + 3C(L+1) + 18."""
+    out = []
+    for k in range(n_loci):
+        loc, nm, nu = _c2_plan((k, seed, read_len, mapped_mean, unmapped_mean))
+        L = len(loc.units[0])
+        out.append((nm + 2 * nu, 6 * read_len + 3 * loc.copies * (L + 1) + 18))
+    return out
+
+
+def _c2_locus(args):
+    """One C2 locus and its calls (worker of make_c2_parallel's process pool; the model is built by the parent)."""
+    k, seed, read_len, mapped_mean, unmapped_mean = args
+    from .vntr_finder import reverse_complement
+    loc, n_mapped, n_unmapped = _c2_plan(args)
+    rng = np.random.default_rng([seed, k, 1])
+    mapped = make_reads(rng, loc, n_mapped, read_len, locus_fraction=0.9)
+    unmapped = make_reads(rng, loc, n_unmapped, read_len, locus_fraction=0.5)
     calls = mapped + unmapped + [reverse_complement(s) for s in unmapped]
     return (loc.left, loc.right, loc.units, loc.copies, loc.error_rate), calls
 
 
-def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None, build=True):
+def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None, build=True,
+                     only=None):
     """make_c2 with the synthetic read generation spread over a process pool (per-locus seeds, independent of the
-    worker count); the models are then built by the native builder on host threads.  Returns ([Locus], reads,
-    read_locus)."""
+    worker count); the models are then built by the native builder on host threads.  only = the locus indices this
+    rank owns (multi-GPU sharding: every rank can produce exactly its share).  Returns ([Locus], reads, read_locus)
+    with read_locus indexing the returned list."""
     import multiprocessing as mp
     import os
     workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
-    jobs = [(k, seed, read_len, mapped_mean, unmapped_mean) for k in range(n_loci)]
+    ks = list(range(n_loci)) if only is None else [int(k) for k in only]
+    jobs = [(k, seed, read_len, mapped_mean, unmapped_mean) for k in ks]
     with mp.get_context("fork").Pool(workers) as pool:
         res = pool.map(_c2_locus, jobs, chunksize=8)
     loci, reads, which = [], [], []
-    for k, (params, calls) in enumerate(res):
+    for i, (params, calls) in enumerate(res):
         loci.append(Locus(*params))
         reads += calls
-        which += [k] * len(calls)
+        which += [i] * len(calls)
     if build:
         build_models(loci)
     return loci, reads, np.asarray(which, dtype=np.int32)

@@ -69,8 +69,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
     ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
-    ap.add_argument("--workload", default="c1", choices=["c1", "c2"],
-                    help="c1 (default, the bench line): 1 REF150 locus x --reads; c2: --loci synthetic loci x ~160 calls")
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3"],
+                    help="c1 (default, the bench line): 1 REF150 locus x --reads per GPU; c2: --loci synthetic loci x ~160 "
+                         "calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by estimated work "
+                         "(strong scaling, BASELINE config 3), per-call records gathered to rank 0 over RCCL")
     ap.add_argument("--loci", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -97,8 +99,18 @@ def main():
 
     n = 150
     flags = _lib.FLAG_FORCE_GENERIC if args.generic else (_lib.FLAG_STREAM if args.stream else 0)
-    if args.workload == "c2":
-        loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602 + rank, build=False)
+    total_calls = None
+    if args.workload in ("c2", "c3"):
+        if args.workload == "c3":
+            # every rank derives the same plan and the same LPT partition without communicating
+            from advntr_amd import sharding
+            plan = workloads.c2_plan(args.loci, seed=20240602)
+            work = [calls * 151 * states for calls, states in plan]
+            mine = sharding.partition_loci(work, world)[rank]
+            total_calls = int(sum(c for c, _ in plan))
+            loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602, build=False, only=mine)
+        else:
+            loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602 + rank, build=False)
         t_build = time.perf_counter()
         workloads.build_models(loci)           # native builder, all host cores
         t_build = time.perf_counter() - t_build
@@ -125,8 +137,17 @@ def main():
     gathered = None
     if use_dist:
         p_logp, p_sum = batch.result_ptrs()
-        t_logp = torch.as_tensor(_CudaArray(p_logp, (args.reads,), "<f8"), device="cuda")
-        t_sum = torch.as_tensor(_CudaArray(p_sum, (args.reads, 8), "<i4"), device="cuda")
+        e_logp = torch.as_tensor(_CudaArray(p_logp, (args.reads,), "<f8"), device="cuda")
+        e_sum = torch.as_tensor(_CudaArray(p_sum, (args.reads, 8), "<i4"), device="cuda")
+        # ranks may hold different numbers of calls (c3): gather fixed-size buffers padded to the largest share
+        cap = torch.tensor([args.reads], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+        cap = int(cap.item())
+        if cap == args.reads:
+            t_logp, t_sum = e_logp, e_sum
+        else:
+            t_logp = torch.zeros(cap, dtype=torch.float64, device="cuda")
+            t_sum = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
         if rank == 0:
             gathered = ([torch.empty_like(t_logp) for _ in range(world)],
                         [torch.empty_like(t_sum) for _ in range(world)])
@@ -135,6 +156,9 @@ def main():
         batch.run()
         if use_dist:
             batch.sync()
+            if t_logp is not e_logp:
+                t_logp[:args.reads].copy_(e_logp)
+                t_sum[:args.reads].copy_(e_sum)
             dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0)
             dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0)
 
@@ -172,26 +196,32 @@ def main():
     logp, summ = batch.fetch()
     if use_dist and rank == 0:
         # the gathered copy of rank 0's own records must equal what the engine holds
-        assert np.array_equal(gathered[0][0].cpu().numpy(), logp), "RCCL gather returned different log-probs"
-        assert np.array_equal(gathered[1][0].cpu().numpy(), summ), "RCCL gather returned different summaries"
+        assert np.array_equal(gathered[0][0][:args.reads].cpu().numpy(), logp), "RCCL gather returned different log-probs"
+        assert np.array_equal(gathered[1][0][:args.reads].cpu().numpy(), summ), "RCCL gather returned different summaries"
 
     if rank == 0:
-        total_reads = args.reads * world
+        total_reads = total_calls if total_calls is not None else args.reads * world
         value = total_reads * args.steps / elapsed
         B = algorithmic_bytes(n, m)
         achieved = B * args.reads / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": ("reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
                        if args.workload == "c1" else
+                       "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (args.loci, world)
+                       if args.workload == "c3" else
                        "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs, mean %d states)" % (args.loci, m)),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.workload == "c3" else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
                                     "150-bp reads per GPU, seed 20240601") if args.workload == "c1" else
-                                   ("C2: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x "
-                                    "~Poisson(80) mapped + 2*Poisson(40) unmapped-strand calls, seed 20240602; "
-                                    "host model build %.2f s (native builder, %d threads)" % (args.loci, t_build, os.cpu_count() or 1)),
+                                   ("%s: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x "
+                                    "~Poisson(80) mapped + 2*Poisson(40) unmapped-strand calls, seed 20240602%s; "
+                                    "host model build %.2f s (native builder, %d threads)"
+                                    % (args.workload.upper(), args.loci,
+                                       " (whole loci assigned to ranks by LPT on calls x states)" if args.workload == "c3" else "",
+                                       t_build, os.cpu_count() or 1)),
                        "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
                        "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
                        "relaxations_per_s": value * (n + 1) * E},

@@ -66,3 +66,22 @@ def test_gather_world_size_2_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_c3_plan_matches_the_generated_share():
+    """bench.py --workload c3: every rank derives the same plan (calls, states per locus) without generating reads,
+    partitions it, and generates exactly its share; the shares cover the locus set once."""
+    from advntr_amd import sharding, workloads
+    plan = workloads.c2_plan(24, seed=99)
+    parts = sharding.partition_loci([c * 151 * m for c, m in plan], 3)
+    assert sorted(int(k) for p in parts for k in p) == list(range(24))
+    loads = [sum(plan[int(k)][0] * plan[int(k)][1] for k in p) for p in parts]
+    assert max(loads) < 1.25 * min(loads)
+    loci, reads, which = workloads.make_c2_parallel(24, seed=99, only=parts[1], workers=2)
+    assert len(loci) == len(parts[1]) and len(reads) == sum(plan[int(k)][0] for k in parts[1])
+    for locus, k in zip(loci, parts[1]):
+        assert locus.model.n_states == plan[int(k)][1]
+    # the same locus comes out identical whichever rank asks for it
+    again, reads2, _ = workloads.make_c2_parallel(24, seed=99, only=[int(parts[1][0])], workers=1, build=False)
+    assert (again[0].left, again[0].units) == (loci[0].left, loci[0].units)
+    assert reads2 == reads[:len(reads2)]
