@@ -5,7 +5,8 @@ A "step" is one pass of the hot path (Viterbi DP + traceback + path summaries) o
 of synthetic reads.  Workload at every N: config C1 of BASELINE.json / SURVEY 8d -- one REF150 locus
 (flank 150, 14-bp pattern, 11 copies: 1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp
 reads PER GPU (weak scaling: the read x locus batch shards with no data-path collective; the only RCCL
-call is the final gather of the 40-B/read result records to rank 0, inside the timed region).
+call is the gather of the 40-B/read result records to rank 0, inside the timed region; the gather of pass i
+runs from staging buffers while the kernel of pass i+1 computes, and all of them complete before the clock stops).
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -143,27 +144,36 @@ def main():
         cap = torch.tensor([args.reads], dtype=torch.int64, device="cuda")
         dist.all_reduce(cap, op=dist.ReduceOp.MAX)
         cap = int(cap.item())
-        if cap == args.reads:
-            t_logp, t_sum = e_logp, e_sum
-        else:
-            t_logp = torch.zeros(cap, dtype=torch.float64, device="cuda")
-            t_sum = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
+        # staging buffers: the gather of step i runs from them while the kernel of step i+1 refills the engine's
+        # result arrays (the only collective of the path overlaps the next pass instead of serialising with it)
+        t_logp = torch.zeros(cap, dtype=torch.float64, device="cuda")
+        t_sum = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
         if rank == 0:
             gathered = ([torch.empty_like(t_logp) for _ in range(world)],
                         [torch.empty_like(t_sum) for _ in range(world)])
+    pending = []
 
     def step():
         batch.run()
         if use_dist:
-            batch.sync()
-            if t_logp is not e_logp:
-                t_logp[:args.reads].copy_(e_logp)
-                t_sum[:args.reads].copy_(e_sum)
-            dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0)
+            batch.sync()                                   # this pass's records are final
+            for w in pending:                              # the previous gather has had a whole pass to finish
+                w.wait()
+            del pending[:]
+            t_logp[:args.reads].copy_(e_logp)
+            t_sum[:args.reads].copy_(e_sum)
+            torch.cuda.current_stream().synchronize()      # engine buffers may be overwritten by the next pass
+            pending.append(dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0, async_op=True))
+            pending.append(dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0, async_op=True))
+
+    def drain():
+        for w in pending:
+            w.wait()
+        del pending[:]
 
     for _ in range(args.warmup):
         step()
+    drain()
     batch.sync()
     torch.cuda.synchronize()
     if use_dist:
@@ -171,6 +181,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                                # every gather of the timed steps completes inside the region
     batch.sync()
     torch.cuda.synchronize()
     if use_dist:
