@@ -60,18 +60,22 @@ def genotype(args):
                  for i, s in enumerate(seqs))
     _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
     read_length = int(np.median([len(s) for s in seqs[:5]])) if seqs else 150     # vntr_finder.py:714-718
+    # all models in one native build, all (read, strand, locus) calls in one engine batch
+    specs, cands = [], []
     for loc in loci:
         vid = int(loc["id"])
         picked = sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))
-        cand = [seqs[i] for i in picked]
-        copies = vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))
-        model = hmm_utils.get_read_matcher_model(loc["left"][-read_length:], loc["right"][:read_length],
-                                                 loc["repeat_segments"], copies)
-        scored = [s for s in vntr_finder.score_reads(model, cand, loc.get("scaled_score"), True) if s is not None]
+        cands.append([seqs[i] for i in picked])
+        specs.append((loc["left"][-read_length:], loc["right"][:read_length], loc["repeat_segments"],
+                      vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))))
+    models = hmm_utils.build_read_matcher_models(specs)
+    scored_all = vntr_finder.score_reads_multi(models, cands, [loc.get("scaled_score") for loc in loci], True)
+    for loc, scored in zip(loci, scored_all):
+        scored = [s for s in scored if s is not None]
         selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
         res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
                                                                 is_haploid=args.haploid)
-        _print(out, vid, res.copy_numbers, args.haploid)
+        _print(out, int(loc["id"]), res.copy_numbers, args.haploid)
     return 0
 
 

@@ -72,24 +72,43 @@ def score_reads(model, sequences, scaled_score=None, compute_reverse=True):
     strand replaces the forward one iff logp < rev_logp (vntr_finder.py:242-246).  Reads holding 'N' are
     skipped before scoring, as the reference does (vntr_finder.py:237).  Returns a list of ScoredRead
     (None for skipped reads)."""
-    keep = [i for i, s in enumerate(sequences) if s.count('N') <= 0]
-    fwd = [sequences[i].upper() for i in keep]
-    batch = list(fwd)
-    if compute_reverse:
-        batch += [reverse_complement(s) for s in fwd]
-    out = [None] * len(sequences)
+    return score_reads_multi([model], [sequences], [scaled_score], compute_reverse)[0]
+
+
+def score_reads_multi(models, read_lists, scaled_scores=None, compute_reverse=True):
+    """score_reads for many loci in ONE engine call: models[i] scores read_lists[i].  The reference walks loci and
+    reads in nested Python loops (genome_analyzer.py:280, vntr_finder.py:235-254); here the whole read x strand x
+    locus batch is a single advntr_viterbi_batch launch set, and the keep/discard rule runs on the returned
+    summaries.  Returns one list of ScoredRead (None for reads holding 'N') per locus."""
+    n_loci = len(models)
+    scaled_scores = list(scaled_scores) if scaled_scores is not None else [None] * n_loci
+    batch, which, layout = [], [], []
+    for i, seqs in enumerate(read_lists):
+        keep = [j for j, s in enumerate(seqs) if s.count('N') <= 0]
+        fwd = [seqs[j].upper() for j in keep]
+        start = len(batch)
+        batch += fwd
+        if compute_reverse:
+            batch += [reverse_complement(s) for s in fwd]
+        which += [i] * (len(batch) - start)
+        layout.append((keep, start, len(fwd)))
+    out = [[None] * len(seqs) for seqs in read_lists]
     if not batch:
         return out
-    logp, summ, _ = model.viterbi_batch(batch, want_paths=False, want_summary=True)
-    nf = len(fwd)
-    for j, i in enumerate(keep):
-        seq, lp, sm, rev = fwd[j], float(logp[j]), summ[j], False
-        if compute_reverse and lp < float(logp[nf + j]):
-            seq, lp, sm, rev = batch[nf + j], float(logp[nf + j]), summ[nf + j], True
-        ok = False
-        if sm[_lib.SUM_PATH_LEN] > 2:
-            ok = recruit_read(lp, sm, get_min_score_to_select_a_read(scaled_score, len(seq)), len(seq))
-        out[i] = ScoredRead(seq, lp, sm, rev, ok)
+    bases, off = _lib.encode_reads(batch)
+    logp, summ, _ = _lib.viterbi_batch([m.device_model() for m in models], bases, off, np.asarray(which, np.int32),
+                                       want_paths=False, want_summary=True)
+    for i, (keep, start, nf) in enumerate(layout):
+        for j, pos in enumerate(keep):
+            a = start + j
+            seq, lp, sm, rev = batch[a], float(logp[a]), summ[a], False
+            if compute_reverse and lp < float(logp[a + nf]):
+                b = a + nf
+                seq, lp, sm, rev = batch[b], float(logp[b]), summ[b], True
+            ok = False
+            if sm[_lib.SUM_PATH_LEN] > 2:
+                ok = recruit_read(lp, sm, get_min_score_to_select_a_read(scaled_scores[i], len(seq)), len(seq))
+            out[i][pos] = ScoredRead(seq, lp, sm, rev, ok)
     return out
 
 

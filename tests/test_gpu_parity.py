@@ -552,3 +552,26 @@ def test_cli_genotype_from_model_database(tmp_path):
     assert out == "21\n2/4\n"
     bad = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode != 0 and b"alignment" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_score_reads_multi_equals_per_locus_calls():
+    """One engine batch over several loci == the per-locus calls (same strand choice, logp, summaries, verdicts)."""
+    from advntr_amd import workloads, vntr_finder
+    rng = np.random.default_rng(4242)
+    loci = [workloads.make_locus(rng, 150, int(L), vntr_finder.get_copies_for_hmm(150, int(L))) for L in (9, 14, 40)]
+    workloads.build_models(loci)
+    reads = [workloads.make_reads(rng, loc, 60, 150, locus_fraction=0.7) for loc in loci]
+    reads[1][3] = reads[1][3][:20] + "N" + reads[1][3][21:]
+    scores = [None, -1.2, None]
+    multi = vntr_finder.score_reads_multi([l.model for l in loci], reads, scores)
+    for loc, rs, sc, got in zip(loci, reads, scores, multi):
+        want = vntr_finder.score_reads(loc.model, rs, sc)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            if b is None:
+                assert a is None
+                continue
+            assert (a.sequence, a.logp, a.reversed, a.recruited) == (b.sequence, b.logp, b.reversed, b.recruited)
+            assert np.array_equal(a.summary, b.summary)
+    assert multi[1][3] is None and sum(s.recruited for s in multi[0] if s) > 10
