@@ -255,6 +255,16 @@ def main():
                                    "sample": "first %d reads of rank 0's batch, oracle/viterbi_oracle.c, 1 thread; "
                                              "GPU logp bit-equal on the sample" % len(cpu_logp)}
             out["config"]["speedup_vs_cpu_1thread"] = value / cps
+            # the same restatement on every host core (the reference has no such mode; stated for scale only)
+            cores = os.cpu_count() or 1
+            n_mt = min(args.reads, max(2000, 150 * cores))
+            t0 = time.perf_counter()
+            mt_logp = O.viterbi_many_threads(bases[:off[n_mt]], off[:n_mt + 1], cores)
+            dt = time.perf_counter() - t0
+            assert np.array_equal(mt_logp, logp[:n_mt]), "GPU/oracle log-prob mismatch on the all-cores sample"
+            out["cpu_baseline_all_cores"] = {"value": n_mt / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                                             "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
+                                                       "bit-equal on the sample" % (n_mt, cores)}
         print(json.dumps(out), flush=True)
     batch.close()
     if use_dist:

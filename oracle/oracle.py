@@ -48,6 +48,9 @@ def lib():
         L.oracle_viterbi_many.restype = None
         L.oracle_viterbi_many.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_viterbi_many_mt.restype = None
+        L.oracle_viterbi_many_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -124,6 +127,17 @@ class OracleModel(object):
         lib().oracle_viterbi_many(self._h, bases.ctypes.data, off.ctypes.data, n_reads, out.ctypes.data,
                                   scratch.ctypes.data, cap, lens.ctypes.data)
         return out, lens
+
+    def viterbi_many_threads(self, bases, off, n_threads):
+        """log-probs only, reads spread over n_threads host threads (bench.py's all-cores baseline)."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        off = np.ascontiguousarray(off, np.int64)
+        n_reads = len(off) - 1
+        out = np.zeros(n_reads, np.float64)
+        cap = int((off[1:] - off[:-1]).max()) + self.m + 2 if n_reads else 1
+        lib().oracle_viterbi_many_mt(self._h, bases.ctypes.data, off.ctypes.data, n_reads, out.ctypes.data, cap,
+                                     int(n_threads))
+        return out
 
 
 # ---------------------------------------------------------------------------------------------

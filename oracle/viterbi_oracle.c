@@ -22,7 +22,9 @@
  * CSR in-edges in graph.edges_iter() order, fp64 throughout, strict '>' so the first maximum in
  * in-edge order wins, and the (v + t) + e association of hmm.pyx:2036-2037.
  */
+#include <malloc.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -255,4 +257,46 @@ void oracle_viterbi_many(const oracle_model *M, const uint8_t *bases, const int6
         out_logp[r] = oracle_viterbi(M, bases + off[r], (int)(off[r + 1] - off[r]), scratch_path, path_cap, &len);
         if (out_path_len) out_path_len[r] = len;
     }
+}
+
+
+/* The same loop on n_threads host threads (reads are independent; the reference itself is single-threaded on this
+ * path -- this only serves bench.py's "all host cores" baseline figure).  Each thread owns its path scratch. */
+typedef struct {
+    const oracle_model *M;
+    const uint8_t *bases;
+    const int64_t *off;
+    int n_reads, path_cap, n_threads, tid;
+    double *out_logp;
+} many_job;
+
+static void *many_worker(void *arg)
+{
+    many_job *j = (many_job *)arg;
+    int *scratch = (int *)malloc(sizeof(int) * (size_t)j->path_cap);
+    for (int r = j->tid; r < j->n_reads; r += j->n_threads) {
+        int len = 0;
+        j->out_logp[r] = oracle_viterbi(j->M, j->bases + j->off[r], (int)(j->off[r + 1] - j->off[r]), scratch, j->path_cap, &len);
+    }
+    free(scratch);
+    return NULL;
+}
+
+void oracle_viterbi_many_mt(const oracle_model *M, const uint8_t *bases, const int64_t *off, int n_reads,
+                            double *out_logp, int path_cap, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    /* the per-call tables (several MB, calloc'd as the reference does) would otherwise be mmap'd and unmapped on every
+     * call, which serialises the threads in the kernel's address-space lock; keep them on the per-thread heaps */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    many_job *jobs = (many_job *)malloc(sizeof(many_job) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t] = (many_job){M, bases, off, n_reads, path_cap, n_threads, t, out_logp};
+        pthread_create(&th[t], NULL, many_worker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
 }
