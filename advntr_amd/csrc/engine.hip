@@ -413,10 +413,21 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             return fail(ADVNTR_ERR_ARG, "batch: read_model[%d]=%d out of range", r, read_model[r]);
         B->n_max = std::max<int>(B->n_max, (int)(read_off[r + 1] - read_off[r]));
     }
-    for (int64_t i = 0; i < total; ++i)
-        if (bases[i] > 3)   // the reference raises ValueError("Symbol ... not defined") (hmm.pyx:72,79)
-            return fail(ADVNTR_ERR_SYMBOL, "batch: base code %d at offset %lld is not one of A,C,G,T", (int)bases[i],
-                        (long long)i);
+    {   // symbol check, eight codes per test (a valid code has no bit above the low two)
+        uint64_t bad = 0;
+        int64_t i = 0;
+        for (; i + 8 <= total; i += 8) {
+            uint64_t w;
+            memcpy(&w, bases + i, 8);
+            bad |= w & 0xFCFCFCFCFCFCFCFCull;
+        }
+        for (; i < total; ++i) bad |= (uint64_t)(bases[i] & 0xFC);
+        if (bad)
+            for (i = 0; i < total; ++i)
+                if (bases[i] > 3)   // the reference raises ValueError("Symbol ... not defined") (hmm.pyx:72,79)
+                    return fail(ADVNTR_ERR_SYMBOL, "batch: base code %d at offset %lld is not one of A,C,G,T", (int)bases[i],
+                                (long long)i);
+    }
     for (auto *H : B->models) B->m_max = std::max(B->m_max, H->m);
 
     B->device = current_device();
@@ -456,11 +467,16 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
     // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read
     auto kof = [&](int r) { return (int)std::min<int64_t>(5, (read_off[r + 1] - read_off[r] + 63) / 64); };
-    std::stable_sort(col_reads.begin(), col_reads.end(), [&](int a, int b) {
-        if (kof(a) != kof(b)) return kof(a) < kof(b);
-        if (read_model[a] != read_model[b]) return read_model[a] < read_model[b];
-        return (read_off[a + 1] - read_off[a]) > (read_off[b + 1] - read_off[b]);
-    });
+    {   // one 64-bit key per read (bucket | model | inverted length), index in the low bits keeps the sort stable
+        std::vector<std::pair<uint64_t, int32_t>> keyed(col_reads.size());
+        for (size_t i = 0; i < col_reads.size(); ++i) {
+            const int r = col_reads[i];
+            const uint64_t len = (uint64_t)(read_off[r + 1] - read_off[r]);
+            keyed[i] = {((uint64_t)kof(r) << 56) | ((uint64_t)(uint32_t)read_model[r] << 24) | (uint64_t)(0xFFFFFFu - std::min<uint64_t>(len, 0xFFFFFFu)), r};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t i = 0; i < keyed.size(); ++i) col_reads[i] = keyed[i].second;
+    }
     // generic reads: heaviest (n+1)*E first (dynamic dequeue in-kernel)
     std::stable_sort(gen_reads.begin(), gen_reads.end(), [&](int a, int b) {
         const int64_t wa = (read_off[a + 1] - read_off[a] + 1) * (int64_t)B->models[read_model[a]]->n_edges;

@@ -19,3 +19,7 @@ for _ in range(3):
 B = _lib.DeviceBatch([dm], bases, off, which)
 t = time.perf_counter(); B.run(); B.sync(); dt = time.perf_counter() - t
 print("resident batch, run+sync: %.1f ms" % (dt * 1e3))
+for _ in range(2):
+    t0 = time.perf_counter(); B2 = _lib.DeviceBatch([dm], bases, off, which); t1 = time.perf_counter()
+    B2.run(); B2.sync(); t2 = time.perf_counter(); r = B2.fetch(); t3 = time.perf_counter(); B2.close(); t4 = time.perf_counter()
+    print("create %.2f ms, run %.2f ms, fetch %.2f ms, destroy %.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
