@@ -112,6 +112,68 @@ def score_reads_multi(models, read_lists, scaled_scores=None, compute_reverse=Tr
     return out
 
 
+def recruit_mask(logp, summary, read_lengths, min_scores):
+    """recruit_read (vntr_finder.py:179-190) on arrays: logp float64[n], summary int32[n][8], read_lengths int[n],
+    min_scores float64[n] with NaN where the locus has no trained score.  Reads without a path are not recruited."""
+    logp = np.asarray(logp, np.float64)
+    s = np.asarray(summary).reshape(-1, _lib.SUMMARY_INTS)
+    n = np.asarray(read_lengths, np.float64)
+    ms = np.asarray(min_scores, np.float64)
+    lb, rb = s[:, _lib.SUM_LEFT_BP].astype(np.float64), s[:, _lib.SUM_RIGHT_BP].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        left = np.where(lb != 0, s[:, _lib.SUM_LEFT_MATCH] / lb, 1.0)
+        right = np.where(rb != 0, s[:, _lib.SUM_RIGHT_MATCH] / rb, 1.0)
+    rate_ok = np.minimum(left, right) >= 0.90
+    has_score = ~np.isnan(ms)
+    with np.errstate(invalid="ignore"):
+        by_score = has_score & (logp > ms)
+    by_default = ~has_score & (s[:, _lib.SUM_MATCHES] >= 0.9 * n) & (logp > -n)
+    return rate_ok & (by_score | by_default) & (s[:, _lib.SUM_PATH_LEN] > 2)
+
+
+def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=True):
+    """score_reads_multi without a Python object per read, for genome-scale runs: returns a dict of arrays over all
+    kept reads (reads holding 'N' are dropped): locus, index (position in read_lists[locus]), logp, summary,
+    reversed, recruited, length -- the chosen strand per read (reverse iff logp < rev_logp, vntr_finder.py:242-246)."""
+    n_loci = len(models)
+    scaled = [np.nan if (s is None or s == 0) else float(s) for s in (scaled_scores or [None] * n_loci)]
+    fwd, locus, index = [], [], []
+    for i, seqs in enumerate(read_lists):
+        for j, s in enumerate(seqs):
+            if 'N' not in s:
+                fwd.append(s.upper())
+                locus.append(i)
+                index.append(j)
+    nf = len(fwd)
+    out = dict(locus=np.asarray(locus, np.int32), index=np.asarray(index, np.int32))
+    if nf == 0:
+        out.update(logp=np.zeros(0), summary=np.zeros((0, _lib.SUMMARY_INTS), np.int32), reversed=np.zeros(0, bool),
+                   recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
+        return out
+    bases, off = _lib.encode_reads(fwd)
+    lens = np.diff(off)
+    which = out["locus"]
+    if compute_reverse:
+        # reverse complement on the code array: code -> 3 - code, each read reversed in place
+        starts = np.repeat(off[:-1], lens)
+        rev = (3 - bases)[starts + (np.repeat(off[1:], lens) - 1 - np.arange(len(bases)))]
+        bases = np.concatenate([bases, rev.astype(np.uint8)])
+        off = np.concatenate([off, off[-1] + off[1:]])
+        which = np.concatenate([which, which])
+    logp, summ, _ = _lib.viterbi_batch([m.device_model() for m in models], bases, off, which, want_paths=False,
+                                       want_summary=True)
+    if compute_reverse:
+        use_rev = logp[:nf] < logp[nf:]
+        logp = np.where(use_rev, logp[nf:], logp[:nf])
+        summ = np.where(use_rev[:, None], summ[nf:], summ[:nf])
+    else:
+        use_rev = np.zeros(nf, bool)
+    min_scores = np.asarray(scaled, np.float64)[out["locus"]] * lens
+    out.update(logp=logp, summary=summ, reversed=use_rev, length=lens,
+               recruited=recruit_mask(logp, summ, lens, min_scores))
+    return out
+
+
 def get_conditional_likelihood(ck, ci, cj, r, r_e):
     if ck == ci == cj:
         return 1 - r

@@ -575,3 +575,25 @@ def test_score_reads_multi_equals_per_locus_calls():
             assert (a.sequence, a.logp, a.reversed, a.recruited) == (b.sequence, b.logp, b.reversed, b.recruited)
             assert np.array_equal(a.summary, b.summary)
     assert multi[1][3] is None and sum(s.recruited for s in multi[0] if s) > 10
+
+
+@pytest.mark.gpu
+def test_score_reads_arrays_equals_object_path():
+    """The array form (no Python object per read, reverse complement on the code array, vectorised recruit rule)
+    gives the same strand, logp, summaries and verdicts as score_reads_multi."""
+    from advntr_amd import workloads, vntr_finder
+    rng = np.random.default_rng(777)
+    loci = [workloads.make_locus(rng, 150, int(L), vntr_finder.get_copies_for_hmm(150, int(L))) for L in (7, 22, 61)]
+    workloads.build_models(loci)
+    reads = [workloads.make_reads(rng, loc, 80, int(n), locus_fraction=0.7) for loc, n in zip(loci, (150, 150, 120))]
+    reads[2][5] = "N" + reads[2][5][1:]
+    scores = [None, -1.15, 0]
+    objs = vntr_finder.score_reads_multi([l.model for l in loci], reads, scores)
+    arr = vntr_finder.score_reads_arrays([l.model for l in loci], reads, scores)
+    assert len(arr["logp"]) == sum(1 for rs in objs for s in rs if s is not None)
+    for k in range(len(arr["logp"])):
+        o = objs[int(arr["locus"][k])][int(arr["index"][k])]
+        assert (o.logp, o.reversed, o.recruited, len(o.sequence)) == (float(arr["logp"][k]), bool(arr["reversed"][k]),
+                                                                      bool(arr["recruited"][k]), int(arr["length"][k]))
+        assert np.array_equal(o.summary, arr["summary"][k])
+    assert arr["recruited"].sum() > 30 and (~arr["recruited"]).sum() > 30 and arr["reversed"].sum() > 5

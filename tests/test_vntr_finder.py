@@ -66,3 +66,30 @@ def test_illumina_aggregation_matches_reference():
         assert (res.recruited_reads_count, res.spanning_reads_count, res.flanking_reads_count) == \
             (c["recruited"], c["spanning"], c["flanking"]), c
         assert res.maximum_likelihood == c["max_likelihood"], c
+
+
+def test_recruit_mask_equals_scalar_rule():
+    """The vectorised keep/discard rule against recruit_read (pinned on the reference's verdicts by the goldens),
+    on random summaries covering every branch (zero flank bp, with/without a trained score, ties at the bounds)."""
+    import numpy as np
+    from advntr_amd import _lib, vntr_finder
+    rng = np.random.default_rng(12)
+    n = 4000
+    summ = np.zeros((n, 8), np.int32)
+    summ[:, _lib.SUM_LEFT_BP] = rng.integers(0, 40, n) * (rng.random(n) < 0.8)
+    summ[:, _lib.SUM_RIGHT_BP] = rng.integers(0, 40, n) * (rng.random(n) < 0.8)
+    summ[:, _lib.SUM_LEFT_MATCH] = (summ[:, _lib.SUM_LEFT_BP] * rng.choice([1.0, 0.95, 0.9, 0.85], n)).astype(np.int32)
+    summ[:, _lib.SUM_RIGHT_MATCH] = (summ[:, _lib.SUM_RIGHT_BP] * rng.choice([1.0, 0.95, 0.9, 0.5], n)).astype(np.int32)
+    lens = rng.integers(100, 151, n)
+    summ[:, _lib.SUM_MATCHES] = (lens * rng.choice([1.0, 0.9, 0.89, 0.5], n)).astype(np.int32)
+    summ[:, _lib.SUM_PATH_LEN] = rng.choice([0, 2, 200], n, p=[0.05, 0.05, 0.9])
+    logp = -rng.random(n) * 2.0 * lens
+    scaled = rng.choice([np.nan, -1.0, -0.5], n)
+    logp[::17] = (scaled * lens)[::17]                      # exact ties with the threshold
+    logp[np.isnan(logp)] = -50.0
+    got = vntr_finder.recruit_mask(logp, summ, lens, scaled * lens)
+    for i in range(n):
+        ms = None if np.isnan(scaled[i]) else float(scaled[i] * lens[i])
+        want = summ[i, _lib.SUM_PATH_LEN] > 2 and vntr_finder.recruit_read(float(logp[i]), summ[i], ms, int(lens[i]))
+        assert bool(got[i]) == bool(want), i
+    assert 0.05 < got.mean() < 0.95
