@@ -51,6 +51,7 @@ SYMBOLS = {
     "advntr_built_info": (ctypes.c_int, [_vp, _vp]),
     "advntr_built_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "advntr_built_upload": (_vp, [_vp]),
+    "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
     "advntr_built_destroy": (None, [_vp]),
 }
 
@@ -256,6 +257,16 @@ def align_repeats(units):
         raise EngineError(rc, msg)
     w = width.value
     return [buf.raw[i * w:(i + 1) * w].decode("ascii") for i in range(n)]
+
+
+def upload_built_models(built, threads=0):
+    """advntr_built_upload_many: one device allocation and one copy for a whole list of BuiltModel."""
+    require_gpu()
+    n = len(built)
+    handles = (ctypes.c_void_p * max(n, 1))(*[b._h for b in built])
+    out = (ctypes.c_void_p * max(n, 1))()
+    check(load().advntr_built_upload_many(handles, n, int(threads), out))
+    return [_UploadedModel(out[i], built[i].m, built[i].silent_start) for i in range(n)]
 
 
 def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp="numpy", threads=0, align=False):

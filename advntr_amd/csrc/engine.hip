@@ -173,9 +173,18 @@ struct advntr_hmm {
     int32_t col_lds_core = 0;      // ... without the state table (only the traceback reads it)
     int32_t col_lds_min = 0;       // ... without the column-info table either (the sweep indexes a padded copy of it)
     bool generic_ok = true;
-    void *d_blob = nullptr;
+    void *d_blob = nullptr;        // own allocation, or nullptr when the model lives in a shared slab
+    struct ModelSlab *slab = nullptr;
     size_t blob_bytes = 0;
+    std::vector<uint8_t> host_blob;   // filled by hmm_prepare, released once the model is on the device
+    size_t off[14] = {0};             // table offsets inside the blob (hmm_bind)
     DevModel dev{};
+};
+
+// One device allocation shared by the models of a bulk upload (advntr_built_upload_many); freed with its last model.
+struct ModelSlab {
+    void *d = nullptr;
+    std::atomic<int> refs{0};
 };
 
 namespace {
@@ -193,11 +202,18 @@ struct BlobBuilder {
 
 }  // namespace
 
-extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index,
-                                         int32_t end_index, int32_t n_edges, const int32_t *in_ptr,
-                                         const int32_t *in_src, const double *in_logp,
-                                         const double *emis_logp, const uint16_t *state_class)
+// Host half of advntr_hmm_create: validation, kernel-side tables, column program, the serialized blob.  No HIP call,
+// no global state: safe to run on many threads (errors come back through `err`).
+static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index, int32_t n_edges,
+                               const int32_t *in_ptr, const int32_t *in_src, const double *in_logp,
+                               const double *emis_logp, const uint16_t *state_class, std::string &err)
 {
+    auto fail = [&](int, const char *fmt, auto... args) {
+        char buf[512];
+        snprintf(buf, sizeof buf, fmt, args...);
+        err = buf;
+        return 0;
+    };
     if (m <= 0 || silent_start < 0 || silent_start > m || start_index < 0 || start_index >= m ||
         end_index < 0 || end_index >= m || n_edges < 0 || !in_ptr || (n_edges && (!in_src || !in_logp)) ||
         (silent_start && !emis_logp)) {
@@ -300,25 +316,52 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
         o_col = B.add(colblob);
     }
     H->blob_bytes = B.bytes.size();
+    H->host_blob.swap(B.bytes);
+    const size_t offs[14] = {o_eptr, o_esrc, o_elogp, o_emis, o_sptr, o_smid, o_ssrc, o_sord, o_slogp, o_rptr, o_rsrc, o_rlogp,
+                             o_cls, o_col};
+    memcpy(H->off, offs, sizeof offs);
+    return H;
+}
+
+// Point the model's device view at its blob, uploaded at device address `d`.
+static void hmm_bind(advntr_hmm *H, const void *dptr)
+{
+    const uint8_t *d = (const uint8_t *)dptr;
+    const size_t *o = H->off;
+    DevModel &D = H->dev;
+    D.m = H->m; D.P = H->P; D.start = H->start; D.end = H->end; D.finite = H->finite;
+    D.bp_width = H->bp_width; D.n_chunks = (H->m - H->P + ADV_WAVE - 1) / ADV_WAVE; D.max_indeg = H->max_indeg;
+    D.e_ptr = (const int32_t *)(d + o[0]); D.e_src = (const int32_t *)(d + o[1]);
+    D.e_logp = (const double *)(d + o[2]); D.emis = (const double *)(d + o[3]);
+    D.s_ptr = (const int32_t *)(d + o[4]); D.s_mid = (const int32_t *)(d + o[5]);
+    D.s_src = (const int32_t *)(d + o[6]); D.s_ord = (const int32_t *)(d + o[7]);
+    D.s_logp = (const double *)(d + o[8]); D.r_ptr = (const int32_t *)(d + o[9]);
+    D.r_src = (const int32_t *)(d + o[10]); D.r_logp = (const double *)(d + o[11]);
+    D.sclass = (const uint16_t *)(d + o[12]);
+    D.cols = H->colprog.valid ? (const ColProgram *)(d + o[13]) : nullptr;
+    std::vector<uint8_t>().swap(H->host_blob);
+}
+
+extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index,
+                                         int32_t end_index, int32_t n_edges, const int32_t *in_ptr,
+                                         const int32_t *in_src, const double *in_logp,
+                                         const double *emis_logp, const uint16_t *state_class)
+{
+    std::string err;
+    advntr_hmm *H = hmm_prepare(m, silent_start, start_index, end_index, n_edges, in_ptr, in_src, in_logp, emis_logp,
+                                state_class, err);
+    if (!H) {
+        fail(err.find("LDS rows") != std::string::npos ? ADVNTR_ERR_TOO_LARGE : ADVNTR_ERR_ARG, "%s", err.c_str());
+        return nullptr;
+    }
     if (hipMalloc(&H->d_blob, H->blob_bytes) != hipSuccess ||
-        hipMemcpy(H->d_blob, B.bytes.data(), H->blob_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(H->d_blob, H->host_blob.data(), H->blob_bytes, hipMemcpyHostToDevice) != hipSuccess) {
         fail(ADVNTR_ERR_DEVICE, "advntr_hmm_create: device upload failed (%zu B)", H->blob_bytes);
         if (H->d_blob) (void)hipFree(H->d_blob);
         delete H;
         return nullptr;
     }
-    const uint8_t *d = (const uint8_t *)H->d_blob;
-    DevModel &D = H->dev;
-    D.m = m; D.P = P; D.start = start_index; D.end = end_index; D.finite = H->finite;
-    D.bp_width = H->bp_width; D.n_chunks = (S + ADV_WAVE - 1) / ADV_WAVE; D.max_indeg = max_indeg;
-    D.e_ptr = (const int32_t *)(d + o_eptr); D.e_src = (const int32_t *)(d + o_esrc);
-    D.e_logp = (const double *)(d + o_elogp); D.emis = (const double *)(d + o_emis);
-    D.s_ptr = (const int32_t *)(d + o_sptr); D.s_mid = (const int32_t *)(d + o_smid);
-    D.s_src = (const int32_t *)(d + o_ssrc); D.s_ord = (const int32_t *)(d + o_sord);
-    D.s_logp = (const double *)(d + o_slogp); D.r_ptr = (const int32_t *)(d + o_rptr);
-    D.r_src = (const int32_t *)(d + o_rsrc); D.r_logp = (const double *)(d + o_rlogp);
-    D.sclass = (const uint16_t *)(d + o_cls);
-    D.cols = H->colprog.valid ? (const ColProgram *)(d + o_col) : nullptr;
+    hmm_bind(H, H->d_blob);
     return H;
 }
 
@@ -326,6 +369,10 @@ extern "C" void advntr_hmm_destroy(advntr_hmm *H)
 {
     if (!H) return;
     if (H->d_blob) (void)hipFree(H->d_blob);
+    if (H->slab && H->slab->refs.fetch_sub(1) == 1) {
+        (void)hipFree(H->slab->d);
+        delete H->slab;
+    }
     delete H;
 }
 
@@ -1071,6 +1118,69 @@ extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
     const mb::Built &b = B->b;
     return advntr_hmm_create(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
                              b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data());
+}
+
+extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out)
+{
+    if (n < 0 || (n && (!built || !out))) return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: bad argument");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    if (n == 0) return ADVNTR_OK;
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = std::min(n_threads, n);
+    std::mutex err_mu;
+    int first_bad = -1;
+    std::string msg;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            std::string err = "null model";
+            advntr_hmm *H = nullptr;
+            if (built[i]) {
+                const mb::Built &b = built[i]->b;
+                H = hmm_prepare(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
+                                b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data(), err);
+            }
+            if (H) out[i] = H;
+            else {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (first_bad < 0 || i < first_bad) { first_bad = i; msg = err; }
+            }
+        }
+    };
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    auto drop_all = [&]() {
+        for (int i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+    };
+    if (first_bad >= 0) {
+        drop_all();
+        return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
+    }
+    // one slab, 256-B aligned sub-blobs, one copy
+    std::vector<size_t> at(n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { at[i] = total; total += (out[i]->blob_bytes + 255) & ~size_t(255); }
+    std::vector<uint8_t> staging(total);
+    for (int i = 0; i < n; ++i) memcpy(staging.data() + at[i], out[i]->host_blob.data(), out[i]->blob_bytes);
+    ModelSlab *slab = new ModelSlab;
+    if (hipMalloc(&slab->d, total) != hipSuccess || hipMemcpy(slab->d, staging.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        if (slab->d) (void)hipFree(slab->d);
+        delete slab;
+        drop_all();
+        return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
+    }
+    slab->refs = n;
+    for (int i = 0; i < n; ++i) {
+        out[i]->slab = slab;
+        hmm_bind(out[i], (const uint8_t *)slab->d + at[i]);
+    }
+    return ADVNTR_OK;
 }
 
 extern "C" void advntr_built_destroy(advntr_built *B) { delete B; }

@@ -465,3 +465,13 @@ class _BuiltHiddenMarkovModel(HiddenMarkovModel):
         if self._device is None:
             self._device = self._built.upload()
         return self._device
+
+
+def device_models(models, threads=0):
+    """The device handles of a list of baked models; the ones that came from the native builder and are not on the
+    device yet go up together (one allocation, one copy: _lib.upload_built_models)."""
+    todo = [m for m in models if isinstance(m, _BuiltHiddenMarkovModel) and m._device is None]
+    if len(todo) > 1:
+        for m, dm in zip(todo, _lib.upload_built_models([m._built for m in todo], threads)):
+            m._device = dm
+    return [m.device_model() for m in models]

@@ -18,6 +18,7 @@ applied to the 8-int summaries the kernel returns (no Viterbi path leaves the de
 import numpy as np
 
 from . import _lib
+from .pomegranate import device_models
 from .hmm_utils import flanking_rate_from_counts
 
 _COMP = bytes.maketrans(b"ACGT", b"TGCA")
@@ -96,7 +97,7 @@ def score_reads_multi(models, read_lists, scaled_scores=None, compute_reverse=Tr
     if not batch:
         return out
     bases, off = _lib.encode_reads(batch)
-    logp, summ, _ = _lib.viterbi_batch([m.device_model() for m in models], bases, off, np.asarray(which, np.int32),
+    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, np.asarray(which, np.int32),
                                        want_paths=False, want_summary=True)
     for i, (keep, start, nf) in enumerate(layout):
         for j, pos in enumerate(keep):
@@ -160,7 +161,7 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
         bases = np.concatenate([bases, rev.astype(np.uint8)])
         off = np.concatenate([off, off[-1] + off[1:]])
         which = np.concatenate([which, which])
-    logp, summ, _ = _lib.viterbi_batch([m.device_model() for m in models], bases, off, which, want_paths=False,
+    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, which, want_paths=False,
                                        want_summary=True)
     if compute_reverse:
         use_rev = logp[:nf] < logp[nf:]

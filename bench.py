@@ -117,7 +117,8 @@ def main():
         t_build = time.perf_counter() - t_build
         locus = loci[0]
         bases, off = _lib.encode_reads(reads)
-        dms = [l.device_model() for l in loci]
+        from advntr_amd.pomegranate import device_models
+        dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
         args.reads = len(reads)
         batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
         dm = dms[0]

@@ -172,6 +172,11 @@ int advntr_built_export(const advntr_built *built, int32_t *in_ptr, int32_t *in_
                         double *emis_logp, uint16_t *state_class, char *names);
 /* advntr_hmm_create on the built arrays (current device) */
 advntr_hmm *advntr_built_upload(const advntr_built *built);
+/* The same for n models at once: kernel-side tables and column programs are prepared on n_threads host threads
+ * (<= 0: all cores), then ONE device allocation and ONE host-to-device copy carry all of them (a model database of
+ * thousands of loci otherwise pays a hipMalloc + synchronous copy per model).  The models share that allocation; it
+ * is released with the last of them (advntr_hmm_destroy each, as usual).  out[i] = model or NULL on error.          */
+int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out);
 void advntr_built_destroy(advntr_built *built);
 
 #ifdef __cplusplus

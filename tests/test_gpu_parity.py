@@ -597,3 +597,34 @@ def test_score_reads_arrays_equals_object_path():
                                                                       bool(arr["recruited"][k]), int(arr["length"][k]))
         assert np.array_equal(o.summary, arr["summary"][k])
     assert arr["recruited"].sum() > 30 and (~arr["recruited"]).sum() > 30 and arr["reversed"].sum() > 5
+
+
+@pytest.mark.gpu
+def test_bulk_uploaded_models_equal_single_uploads():
+    """advntr_built_upload_many (one slab for many models) vs one advntr_built_upload per model: same results; the slab
+    survives until its last model is destroyed."""
+    import gc
+    from advntr_amd import workloads, hmm_utils
+    from advntr_amd.pomegranate import device_models
+    rng = np.random.default_rng(31)
+    specs = []
+    for L in (6, 11, 30, 57):
+        loc = workloads.make_locus(rng, 150, L, 3, n_units=3)
+        specs.append((loc.left, loc.right, loc.units, loc.copies))
+    bulk = hmm_utils.build_read_matcher_models(specs)
+    single = hmm_utils.build_read_matcher_models(specs)
+    dms = device_models(bulk)
+    assert all(d.has_column_program() for d in dms)
+    reads = [workloads.rand_seq(rng, 150) for _ in range(40)] + [s[2][0] * 4 for s in specs]
+    bases, off = _lib.encode_reads(reads * 4)
+    which = np.repeat(np.arange(4, dtype=np.int32), len(reads))
+    a = _lib.viterbi_batch(dms, bases, off, which)
+    b = _lib.viterbi_batch([m.device_model() for m in single], bases, off, which)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # drop three of the four slab models; the fourth must still score
+    keep = bulk[2]
+    del dms, bulk
+    gc.collect()
+    one, off1 = _lib.encode_reads(reads)
+    c = _lib.viterbi_batch([keep.device_model()], one, off1, np.zeros(len(reads), np.int32))
+    assert np.array_equal(c[0], a[0][2 * len(reads):3 * len(reads)])
