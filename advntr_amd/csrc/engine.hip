@@ -176,8 +176,12 @@ struct advntr_hmm {
     void *d_blob = nullptr;        // own allocation, or nullptr when the model lives in a shared slab
     struct ModelSlab *slab = nullptr;
     size_t blob_bytes = 0;
-    std::vector<uint8_t> host_blob;   // filled by hmm_prepare, released once the model is on the device
-    size_t off[14] = {0};             // table offsets inside the blob (hmm_bind)
+    std::vector<uint8_t> host_blob;   // core blob (state classes + column program), filled by hmm_prepare, released once
+                                      // the model is on the device; generic-only models carry their kernel tables in it too
+    size_t off[14] = {0};             // table offsets: [0..11] generic-kernel tables, [12] classes, [13] column program
+    bool gen_in_blob = false;         // the generic-kernel tables are part of host_blob / the core allocation
+    void *d_gen = nullptr;            // generic-kernel tables uploaded on demand (hmm_ensure_generic)
+    std::mutex gen_mu;
     DevModel dev{};
 };
 
@@ -202,52 +206,12 @@ struct BlobBuilder {
 
 }  // namespace
 
-// Host half of advntr_hmm_create: validation, kernel-side tables, column program, the serialized blob.  No HIP call,
-// no global state: safe to run on many threads (errors come back through `err`).
-static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index, int32_t n_edges,
-                               const int32_t *in_ptr, const int32_t *in_src, const double *in_logp,
-                               const double *emis_logp, const uint16_t *state_class, std::string &err)
+// Tables of the generic-CSR kernel, appended to `B`; o[0..11] receive their offsets.
+static void generic_tables(const advntr_hmm &H, BlobBuilder &B, size_t *o)
 {
-    auto fail = [&](int, const char *fmt, auto... args) {
-        char buf[512];
-        snprintf(buf, sizeof buf, fmt, args...);
-        err = buf;
-        return 0;
-    };
-    if (m <= 0 || silent_start < 0 || silent_start > m || start_index < 0 || start_index >= m ||
-        end_index < 0 || end_index >= m || n_edges < 0 || !in_ptr || (n_edges && (!in_src || !in_logp)) ||
-        (silent_start && !emis_logp)) {
-        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: bad argument");
-        return nullptr;
-    }
-    if (in_ptr[0] != 0 || in_ptr[m] != n_edges) {
-        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr does not span n_edges");
-        return nullptr;
-    }
-    for (int l = 0; l < m; ++l)
-        if (in_ptr[l + 1] < in_ptr[l]) {
-            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr not monotone");
-            return nullptr;
-        }
-    for (int k = 0; k < n_edges; ++k)
-        if (in_src[k] < 0 || in_src[k] >= m) {
-            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: edge source out of range");
-            return nullptr;
-        }
-    const int P = silent_start, S = m - P;
-    advntr_hmm *H = new advntr_hmm();
-    H->m = m; H->P = P; H->start = start_index; H->end = end_index; H->n_edges = n_edges;
-    H->in_ptr.assign(in_ptr, in_ptr + m + 1);
-    H->in_src.assign(in_src, in_src + n_edges);
-    H->in_logp.assign(in_logp, in_logp + n_edges);
-    H->emis.assign(emis_logp, emis_logp + (size_t)P * 4);
-    H->finite = (in_ptr[end_index + 1] - in_ptr[end_index]) != 0;   // hmm.pyx:977-980
-    H->sclass.assign(m, 0);
-    if (state_class) {
-        H->sclass.assign(state_class, state_class + m);
-        H->has_class = true;
-    }
-
+    const int m = H.m, P = H.P, S = m - P;
+    const int32_t *in_ptr = H.in_ptr.data(), *in_src = H.in_src.data();
+    const double *in_logp = H.in_logp.data();
     // emitting CSR = the reference's, verbatim
     std::vector<int32_t> e_ptr(in_ptr, in_ptr + P + 1);
     const int eE = P ? in_ptr[P] : 0;
@@ -286,8 +250,72 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
         for (int q : idx) { s_src.push_back(r_src[q]); s_logp.push_back(r_logp[q]); s_ord.push_back(q - r0); }
         s_ptr[ls + 1] = (int)s_src.size();
     }
-    H->max_indeg = max_indeg;
-    H->bp_width = max_indeg > 255 ? 2 : 1;
+
+    (void)max_indeg;
+    o[0] = B.add(e_ptr); o[1] = B.add(e_src); o[2] = B.add(e_logp); o[3] = B.add(H.emis);
+    o[4] = B.add(s_ptr); o[5] = B.add(s_mid); o[6] = B.add(s_src); o[7] = B.add(s_ord);
+    o[8] = B.add(s_logp); o[9] = B.add(r_ptr); o[10] = B.add(r_src); o[11] = B.add(r_logp);
+}
+
+// Host half of advntr_hmm_create: validation, kernel-side tables, column program, the serialized blob.  No HIP call,
+// no global state: safe to run on many threads (errors come back through `err`).
+static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index, int32_t n_edges,
+                               const int32_t *in_ptr, const int32_t *in_src, const double *in_logp,
+                               const double *emis_logp, const uint16_t *state_class, std::string &err)
+{
+    auto fail = [&](int, const char *fmt, auto... args) {
+        char buf[512];
+        if (sizeof...(args) == 0) snprintf(buf, sizeof buf, "%s", fmt);
+        else snprintf(buf, sizeof buf, fmt, args...);
+        err = buf;
+        return 0;
+    };
+    if (m <= 0 || silent_start < 0 || silent_start > m || start_index < 0 || start_index >= m ||
+        end_index < 0 || end_index >= m || n_edges < 0 || !in_ptr || (n_edges && (!in_src || !in_logp)) ||
+        (silent_start && !emis_logp)) {
+        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: bad argument");
+        return nullptr;
+    }
+    if (in_ptr[0] != 0 || in_ptr[m] != n_edges) {
+        fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr does not span n_edges");
+        return nullptr;
+    }
+    for (int l = 0; l < m; ++l)
+        if (in_ptr[l + 1] < in_ptr[l]) {
+            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: in_ptr not monotone");
+            return nullptr;
+        }
+    for (int k = 0; k < n_edges; ++k)
+        if (in_src[k] < 0 || in_src[k] >= m) {
+            fail(ADVNTR_ERR_ARG, "advntr_hmm_create: edge source out of range");
+            return nullptr;
+        }
+    const int P = silent_start;
+    advntr_hmm *H = new advntr_hmm();
+    H->m = m; H->P = P; H->start = start_index; H->end = end_index; H->n_edges = n_edges;
+    H->in_ptr.assign(in_ptr, in_ptr + m + 1);
+    H->in_src.assign(in_src, in_src + n_edges);
+    H->in_logp.assign(in_logp, in_logp + n_edges);
+    H->emis.assign(emis_logp, emis_logp + (size_t)P * 4);
+    H->finite = (in_ptr[end_index + 1] - in_ptr[end_index]) != 0;   // hmm.pyx:977-980
+    H->sclass.assign(m, 0);
+    if (state_class) {
+        H->sclass.assign(state_class, state_class + m);
+        H->has_class = true;
+    }
+
+    // widest in-edge list the generic kernel will see (decides its back-pointer width)
+    {
+        int max_indeg = 0;
+        for (int l = 0; l < P; ++l) max_indeg = std::max(max_indeg, in_ptr[l + 1] - in_ptr[l]);
+        for (int l = P; l < m; ++l) {
+            int deg = 0;
+            for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) deg += in_src[k] < l;
+            max_indeg = std::max(max_indeg, deg);
+        }
+        H->max_indeg = max_indeg;
+        H->bp_width = max_indeg > 255 ? 2 : 1;
+    }
 
     // column program for flank-repeats-flank read matchers (optional fast path)
     build_column_program(*H, H->colprog);
@@ -301,26 +329,49 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
         return nullptr;
     }
 
+    // the generic kernel's tables are three quarters of a read matcher's device data and are only needed when a read
+    // cannot take the column kernel (forced, or longer than 65 536 bases): models with a column program upload them on
+    // first use (hmm_ensure_generic), generic-only models carry them from the start
     BlobBuilder B;
-    const size_t o_eptr = B.add(e_ptr), o_esrc = B.add(e_src), o_elogp = B.add(e_logp), o_emis = B.add(H->emis);
-    const size_t o_sptr = B.add(s_ptr), o_smid = B.add(s_mid), o_ssrc = B.add(s_src), o_sord = B.add(s_ord);
-    const size_t o_slogp = B.add(s_logp), o_rptr = B.add(r_ptr), o_rsrc = B.add(r_src), o_rlogp = B.add(r_logp);
-    const size_t o_cls = B.add(H->sclass);
-    size_t o_col = 0;
-    std::vector<uint8_t> colblob;
+    size_t offs[14] = {0};
+    H->gen_in_blob = !H->colprog.valid;
+    if (H->gen_in_blob) generic_tables(*H, B, offs);
+    offs[12] = B.add(H->sclass);
     if (H->colprog.valid) {
-        colblob = H->colprog.serialize();
+        const std::vector<uint8_t> colblob = H->colprog.serialize();
         H->col_lds_bytes = ((const ColProgram *)colblob.data())->lds_bytes;
         H->col_lds_core = (((const ColProgram *)colblob.data())->off_state - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
         H->col_lds_min = (((const ColProgram *)colblob.data())->off_info - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
-        o_col = B.add(colblob);
+        offs[13] = B.add(colblob);
     }
     H->blob_bytes = B.bytes.size();
     H->host_blob.swap(B.bytes);
-    const size_t offs[14] = {o_eptr, o_esrc, o_elogp, o_emis, o_sptr, o_smid, o_ssrc, o_sord, o_slogp, o_rptr, o_rsrc, o_rlogp,
-                             o_cls, o_col};
     memcpy(H->off, offs, sizeof offs);
     return H;
+}
+
+static void bind_generic(DevModel &D, const uint8_t *d, const size_t *o)
+{
+    D.e_ptr = (const int32_t *)(d + o[0]); D.e_src = (const int32_t *)(d + o[1]);
+    D.e_logp = (const double *)(d + o[2]); D.emis = (const double *)(d + o[3]);
+    D.s_ptr = (const int32_t *)(d + o[4]); D.s_mid = (const int32_t *)(d + o[5]);
+    D.s_src = (const int32_t *)(d + o[6]); D.s_ord = (const int32_t *)(d + o[7]);
+    D.s_logp = (const double *)(d + o[8]); D.r_ptr = (const int32_t *)(d + o[9]);
+    D.r_src = (const int32_t *)(d + o[10]); D.r_logp = (const double *)(d + o[11]);
+}
+
+// Upload the generic kernel's tables of a model that has so far only run on its column program.
+static int hmm_ensure_generic(advntr_hmm *H)
+{
+    std::lock_guard<std::mutex> lk(H->gen_mu);
+    if (H->gen_in_blob || H->d_gen) return ADVNTR_OK;
+    BlobBuilder B;
+    size_t o[12];
+    generic_tables(*H, B, o);
+    HIP_TRY(hipMalloc(&H->d_gen, B.bytes.size()));
+    HIP_TRY(hipMemcpy(H->d_gen, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice));
+    bind_generic(H->dev, (const uint8_t *)H->d_gen, o);
+    return ADVNTR_OK;
 }
 
 // Point the model's device view at its blob, uploaded at device address `d`.
@@ -331,12 +382,7 @@ static void hmm_bind(advntr_hmm *H, const void *dptr)
     DevModel &D = H->dev;
     D.m = H->m; D.P = H->P; D.start = H->start; D.end = H->end; D.finite = H->finite;
     D.bp_width = H->bp_width; D.n_chunks = (H->m - H->P + ADV_WAVE - 1) / ADV_WAVE; D.max_indeg = H->max_indeg;
-    D.e_ptr = (const int32_t *)(d + o[0]); D.e_src = (const int32_t *)(d + o[1]);
-    D.e_logp = (const double *)(d + o[2]); D.emis = (const double *)(d + o[3]);
-    D.s_ptr = (const int32_t *)(d + o[4]); D.s_mid = (const int32_t *)(d + o[5]);
-    D.s_src = (const int32_t *)(d + o[6]); D.s_ord = (const int32_t *)(d + o[7]);
-    D.s_logp = (const double *)(d + o[8]); D.r_ptr = (const int32_t *)(d + o[9]);
-    D.r_src = (const int32_t *)(d + o[10]); D.r_logp = (const double *)(d + o[11]);
+    if (H->gen_in_blob) bind_generic(D, d, o);
     D.sclass = (const uint16_t *)(d + o[12]);
     D.cols = H->colprog.valid ? (const ColProgram *)(d + o[13]) : nullptr;
     std::vector<uint8_t>().swap(H->host_blob);
@@ -369,6 +415,7 @@ extern "C" void advntr_hmm_destroy(advntr_hmm *H)
 {
     if (!H) return;
     if (H->d_blob) (void)hipFree(H->d_blob);
+    if (H->d_gen) (void)hipFree(H->d_gen);
     if (H->slab && H->slab->refs.fetch_sub(1) == 1) {
         (void)hipFree(H->slab->d);
         delete H->slab;
@@ -483,11 +530,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     B->ev1 = g_cache.get_event(B->device);
     if (!B->stream || !B->ev0 || !B->ev1) return fail(ADVNTR_ERR_DEVICE, "stream/event creation failed");
 
-    std::vector<DevModel> dm;
-    for (auto *H : B->models) dm.push_back(H->dev);
     int rc;
-    if ((rc = B->dmalloc(&B->d_models, dm.size()))) return rc;
-    HIP_TRY(hipMemcpy(B->d_models, dm.data(), dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_bases, (size_t)total + 16))) return rc;
     if (total) HIP_TRY(hipMemcpy(B->d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_read_off, (size_t)n_reads + 1))) return rc;
@@ -531,6 +574,15 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (wa != wb) return wa > wb;
         return read_model[a] < read_model[b];
     });
+    // models of reads that go to the generic kernel need its tables on the device (uploaded on first use)
+    for (int r : gen_reads)
+        if ((rc = hmm_ensure_generic(B->models[read_model[r]]))) return rc;
+    {
+        std::vector<DevModel> dm;
+        for (auto *H : B->models) dm.push_back(H->dev);
+        if ((rc = B->dmalloc(&B->d_models, dm.size()))) return rc;
+        HIP_TRY(hipMemcpy(B->d_models, dm.data(), dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
+    }
     B->n_col = (int)col_reads.size();
     B->n_gen = (int)gen_reads.size();
     std::vector<int32_t> order(col_reads);

@@ -136,37 +136,54 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
     """score_reads_multi without a Python object per read, for genome-scale runs: returns a dict of arrays over all
     kept reads (reads holding 'N' are dropped): locus, index (position in read_lists[locus]), logp, summary,
     reversed, recruited, length -- the chosen strand per read (reverse iff logp < rev_logp, vntr_finder.py:242-246)."""
+    import itertools
     n_loci = len(models)
     scaled = [np.nan if (s is None or s == 0) else float(s) for s in (scaled_scores or [None] * n_loci)]
-    fwd, locus, index = [], [], []
-    for i, seqs in enumerate(read_lists):
-        for j, s in enumerate(seqs):
-            if 'N' not in s:
-                fwd.append(s.upper())
-                locus.append(i)
-                index.append(j)
-    nf = len(fwd)
-    out = dict(locus=np.asarray(locus, np.int32), index=np.asarray(index, np.int32))
+    counts = np.fromiter((len(seqs) for seqs in read_lists), dtype=np.int64, count=n_loci)
+    flat = list(itertools.chain.from_iterable(read_lists))
+    n_all = len(flat)
+    empty = dict(locus=np.zeros(0, np.int32), index=np.zeros(0, np.int32), logp=np.zeros(0),
+                 summary=np.zeros((0, _lib.SUMMARY_INTS), np.int32), reversed=np.zeros(0, bool),
+                 recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
+    if n_all == 0:
+        return empty
+    # one buffer for every read: upper-case, encode and find the reads holding 'N' without a Python loop per read
+    all_len = np.fromiter(map(len, flat), dtype=np.int64, count=n_all)
+    all_off = np.zeros(n_all + 1, np.int64)
+    np.cumsum(all_len, out=all_off[1:])
+    raw = np.frombuffer("".join(flat).upper().encode("latin-1", "replace"), dtype=np.uint8)
+    n_count = np.add.reduceat(np.concatenate([raw == ord('N'), [False]]).astype(np.int64),
+                              np.minimum(all_off[:-1], len(raw)))
+    n_count[all_len == 0] = 0
+    keep = n_count <= 0
+    locus_all = np.repeat(np.arange(n_loci, dtype=np.int32), counts)
+    index_all = (np.arange(n_all, dtype=np.int64) - np.repeat(np.cumsum(counts) - counts, counts)).astype(np.int32)
+    out = dict(locus=locus_all[keep], index=index_all[keep])
+    nf = int(keep.sum())
     if nf == 0:
-        out.update(logp=np.zeros(0), summary=np.zeros((0, _lib.SUMMARY_INTS), np.int32), reversed=np.zeros(0, bool),
-                   recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
-        return out
-    bases, off = _lib.encode_reads(fwd)
-    lens = np.diff(off)
+        return empty
+    lens = all_len[keep]
+    bases = _lib._CODE[raw] if nf == n_all else _lib._CODE[raw[np.repeat(keep, all_len)]]
+    off = np.zeros(nf + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
     which = out["locus"]
     if compute_reverse:
-        # reverse complement on the code array: code -> 3 - code, each read reversed in place
-        starts = np.repeat(off[:-1], lens)
-        rev = (3 - bases)[starts + (np.repeat(off[1:], lens) - 1 - np.arange(len(bases)))]
-        bases = np.concatenate([bases, rev.astype(np.uint8)])
-        off = np.concatenate([off, off[-1] + off[1:]])
-        which = np.concatenate([which, which])
+        # reverse complements without index arithmetic: complementing and reversing the WHOLE code array gives the
+        # reverse complement of every read, the reads themselves in reverse order
+        rc = (3 - bases)[::-1]
+        rlens = lens[::-1]
+        roff = np.zeros(nf + 1, np.int64)
+        np.cumsum(rlens, out=roff[1:])
+        bases = np.concatenate([bases, rc])
+        off = np.concatenate([off, off[-1] + roff[1:]])
+        which = np.concatenate([which, which[::-1]])
     logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, which, want_paths=False,
                                        want_summary=True)
     if compute_reverse:
-        use_rev = logp[:nf] < logp[nf:]
-        logp = np.where(use_rev, logp[nf:], logp[:nf])
-        summ = np.where(use_rev[:, None], summ[nf:], summ[:nf])
+        rlogp, rsumm = logp[nf:][::-1], summ[nf:][::-1]
+        use_rev = logp[:nf] < rlogp
+        logp = np.where(use_rev, rlogp, logp[:nf])
+        summ = np.where(use_rev[:, None], rsumm, summ[:nf])
     else:
         use_rev = np.zeros(nf, bool)
     min_scores = np.asarray(scaled, np.float64)[out["locus"]] * lens

@@ -604,7 +604,7 @@ def test_bulk_uploaded_models_equal_single_uploads():
     """advntr_built_upload_many (one slab for many models) vs one advntr_built_upload per model: same results; the slab
     survives until its last model is destroyed."""
     import gc
-    from advntr_amd import workloads, hmm_utils
+    from advntr_amd import _lib, workloads, hmm_utils
     from advntr_amd.pomegranate import device_models
     rng = np.random.default_rng(31)
     specs = []
