@@ -147,7 +147,7 @@ int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const in
  * get_read_matcher_model and its sub-builders (advntr/hmm_utils.py:290-595), the profile parameters
  * (advntr/profile_hmm.py:13-161) and the pomegranate calls underneath (bake(merge=None) hmm.pyx:673-1123,
  * dense_transition_matrix :492-514, from_matrix :3146-3238, concatenate :584-615) -- 0.8-1.0 s per locus there.
- * Builds n_loci models on n_threads host threads (<= 0: all cores).  Locus i: left/right flanking regions as
+ * Builds n_loci models on n_threads host threads (<= 0: the host's cores, at most 32).  Locus i: left/right flanking regions as
  * NUL-terminated ACGT strings (already trimmed to the wanted length), aligned repeat units
  * repeats[repeat_off[i] .. repeat_off[i+1]) (equal-length rows over ACGT and '-'), copies[i] repeat copies.
  * exp_fn: the exponential applied to log-probabilities where the reference calls numpy.exp (hmm.pyx:514); NULL =
@@ -173,7 +173,7 @@ int advntr_built_export(const advntr_built *built, int32_t *in_ptr, int32_t *in_
 /* advntr_hmm_create on the built arrays (current device) */
 advntr_hmm *advntr_built_upload(const advntr_built *built);
 /* The same for n models at once: kernel-side tables and column programs are prepared on n_threads host threads
- * (<= 0: all cores), then ONE device allocation and ONE host-to-device copy carry all of them (a model database of
+ * (<= 0: the host's cores, at most 32), then ONE device allocation and ONE host-to-device copy carry all of them (a model database of
  * thousands of loci otherwise pays a hipMalloc + synchronous copy per model).  The models share that allocation; it
  * is released with the last of them (advntr_hmm_destroy each, as usual).  out[i] = model or NULL on error.          */
 int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out);
