@@ -263,10 +263,12 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
                                const int32_t *in_ptr, const int32_t *in_src, const double *in_logp,
                                const double *emis_logp, const uint16_t *state_class, std::string &err)
 {
-    auto fail = [&](int, const char *fmt, auto... args) {
+    auto fail = [&err](int, const char *fmt, ...) {
         char buf[512];
-        if (sizeof...(args) == 0) snprintf(buf, sizeof buf, "%s", fmt);
-        else snprintf(buf, sizeof buf, fmt, args...);
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
         err = buf;
         return 0;
     };
