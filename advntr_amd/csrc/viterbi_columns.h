@@ -12,7 +12,7 @@
 // (v + t) + e in fp64, candidates compared in the reference's in-edge order with strict '>'
 // (/root/reference/pomegranate/hmm.pyx:2026-2083), so scores and back-pointers are bit-identical.
 //
-// Back-pointers: one byte per (row, column) cell = the outcomes of the cell's seven comparisons (relax_bit), written
+// Back-pointers: one byte per (row, column) cell = the outcomes of the cell's six comparisons (relax_bit), written
 // in diagonal-major order so that a chunk stores 64 consecutive bytes per step.  The last row's values are
 // also written to a small per-wave buffer from which the "tail" states (prefix_end_prefix, model end:
 // fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  Lane 0 then walks
@@ -92,12 +92,12 @@ __device__ __forceinline__ double bcast63(double v)
 
 // One Viterbi relaxation: if (cand > best) best = cand  -- strict '>' keeps the first maximum, as the reference
 // does (hmm.pyx:2039,2060,2080) -- and the outcome of the comparison is shifted into `bits` (bits = 2*bits + won).
-// A cell's seven comparisons leave seven bits = its back-pointer byte (layout below), so no per-pointer selects and
+// A cell's six comparisons leave six bits = its back-pointer byte (layout below), so no per-pointer selects and
 // no packing are needed.  Three instructions: v_cmp_gt_f64 into VCC, v_max_f64 for the value (equal to the select:
 // no NaNs occur and max(a,b) of equal values is that value), v_addc_co_u32 bits+bits+VCC.  Written as assembly
 // because the compiler lowers the C form to a compare, two or three VOP3 selects per relaxation and an or/shift
 // chain per cell (SQ_INSTS_VALU per launch 13.3 G -> see profiles); -DCOL_RELAX_PLAIN builds the C form.
-//   byte = aI<<6 | bI<<5 | aM<<4 | xM<<3 | bM<<2 | aB<<1 | bB      (a: 2nd candidate won, x: entry edge, b: last)
+//   byte = aI<<5 | bI<<4 | aM<<3 | bM<<2 | aB<<1 | bB      (a: the 2nd candidate won, b: the last one did)
 __device__ __forceinline__ void relax_bit(double &best, int &bits, const double cand)
 {
 #ifdef COL_RELAX_PLAIN
@@ -132,8 +132,9 @@ __device__ __forceinline__ void relax_bit_first(double &best, int &bits, const d
 #endif
 }
 // pointers out of a back-pointer byte: 0/1/2(/3) = index of the winning candidate in evaluation order
-__device__ __forceinline__ int bp_ptr_I(const int byte) { return (byte & 0x20) ? 2 : ((byte >> 6) & 1); }
-__device__ __forceinline__ int bp_ptr_M(const int byte) { return (byte & 0x04) ? 3 : ((byte & 0x08) ? 2 : ((byte >> 4) & 1)); }
+// (M: 0 = I, 1 = M -- or, in a read's first row, the entry edge --, 3 = b of the previous column)
+__device__ __forceinline__ int bp_ptr_I(const int byte) { return (byte & 0x10) ? 2 : ((byte >> 5) & 1); }
+__device__ __forceinline__ int bp_ptr_M(const int byte) { return (byte & 0x04) ? 3 : ((byte >> 3) & 1); }
 __device__ __forceinline__ int bp_ptr_B(const int byte) { return (byte & 0x01) ? 2 : ((byte >> 1) & 1); }
 
 #ifndef ADVNTR_LSE2_DEFINED
@@ -311,10 +312,13 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     relax_bit(vI, bits, (nB + T->iD) + eI);
     // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); the entry edge X only exists for row 1 (chunk 0, lane 0)
     vM = (R.pI[k] + T->mI) + eM;
-    relax_bit(vM, bits, (R.pM[k] + T->mM) + eM);
-    if (MODE == 0 && k == 0) relax_bit(vM, bits, ((t == 1) ? T->mX : -INFINITY) + eM);
-    else if (chunk_first) relax_bit(vM, bits, (first_row ? T->mX : -INFINITY) + eM);
-    else bits += bits;                                               // no entry edge here: its bit stays 0
+    // In a read's first row the I and M candidates are -inf (row 0 holds silent states only), so the entry edge X --
+    // third in the reference's order, ahead of b -- can take the M candidate's place there without changing any
+    // comparison: one select instead of a fourth relaxation, and pointer 1 in row 1 reads "entry edge".
+    double cM = R.pM[k] + T->mM;
+    if (MODE == 0 && k == 0) cM = (t == 1) ? T->mX : cM;
+    else if (chunk_first) cM = first_row ? T->mX : cM;
+    relax_bit(vM, bits, cM + eM);
     relax_bit(vM, bits, (R.pB[k] + T->mD) + eM);
     // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)  (own values of the previous step)
     vB = R.I[k] + T->dI;
@@ -539,7 +543,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             const int tt = t - lane, cc = c - lane;
             const bool valid = tt >= 1 && cc >= 1;
             const int byte = valid ? bp_at(tt, cc) : 0xff;
-            const unsigned long long mm = __ballot(valid && bp_ptr_M(byte) == 1);
+            const unsigned long long mm = __ballot(valid && tt > 1 && bp_ptr_M(byte) == 1);      // row 1: 1 = entry edge
             // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
             const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
@@ -549,7 +553,8 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
             if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
             const int lastbyte = __shfl(byte, run, 64);
-            const int p = bp_ptr_M(lastbyte);
+            int p = bp_ptr_M(lastbyte);
+            if (p == 1) p = 2;                                         // only a first-row cell ends a run on pointer 1
             const ColState cs = L.state[c - run + 1];
             t -= run + 1;
             c -= run;
