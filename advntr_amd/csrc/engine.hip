@@ -672,8 +672,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         size_t n_tiles = 0;
         for (int k = 0; k < 5; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
-        // keep the back-pointer scratch of all resident waves under 48 GB (long reads: fewer resident waves)
-        while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > (int64_t)48 << 30) C.grid = (C.grid + 1) / 2;
+        // back-pointer scratch of all resident waves: at most 60 % of the free HBM (288 GB per MI355X: 4 096 resident
+        // waves x 25 MB for 15-kb reads on a 1 440-column model still fit); beyond that, fewer resident waves
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
+        const int64_t bp_budget = (int64_t)(free_b / 10 * 6) + (int64_t)g_cache.cached[B->device];
+        while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > bp_budget) C.grid = (C.grid + 1) / 2;
         C.aux_stride = COL_MAX_TAIL + (int64_t)COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;

@@ -170,3 +170,57 @@ def make_c2(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=4
         reads += calls
         which += [k] * len(calls)
     return loci, reads, np.asarray(which, dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Config C4 (BASELINE configs[4]): PacBio loci, flank 100, error rate 0.3, trimmed spanning reads
+# ------------------------------------------------------------------------------------------------
+def noisy_copy(rng, s, rate=0.12):
+    """Substitutions, insertions and deletions at a total rate `rate` (a third each), PacBio-like."""
+    a = np.frombuffer(s.encode(), dtype=np.uint8)
+    r = rng.random(len(a))
+    out = []
+    third = rate / 3.0
+    for ch, x in zip(a.tolist(), r.tolist()):
+        if x < third:
+            continue                                            # deletion
+        if x < 2 * third:
+            out.append(int(_ACGT[rng.integers(0, 4)]))          # insertion before the base
+        if 2 * third <= x < rate:
+            ch = int(_ACGT[rng.integers(0, 4)])                 # substitution
+        out.append(ch)
+    return bytes(out).decode()
+
+
+def _c4_locus(args):
+    """One PacBio locus and its 20 trimmed spanning reads: VNTR of U(100,1000) bp, reads = 100-bp flanks around the
+    VNTR at +-20 % of the reference copy number, 12 % noise; the model is sized for the longest read as
+    get_dominant_copy_numbers_from_spanning_reads does (vntr_finder.py:538-549)."""
+    k, seed, n_reads = args
+    from .vntr_finder import pacbio_max_copies
+    rng = np.random.default_rng([seed, k])
+    plen = int(rng.integers(10, 61))
+    ref_copies = max(2, int(round(int(rng.integers(100, 1001)) / plen)))
+    left, right, pattern = rand_seq(rng, 500), rand_seq(rng, 500), rand_seq(rng, plen)
+    reads = []
+    for _ in range(n_reads):
+        c = max(1, int(round(ref_copies * (0.8 + 0.4 * rng.random()))))
+        reads.append(noisy_copy(rng, left[-100:] + pattern * c + right[:100]))
+    copies = pacbio_max_copies([len(r) for r in reads], plen)
+    return (left[-100:], right[:100], [pattern], max(1, copies), 0.3), reads
+
+
+def make_c4(n_loci, seed=20240603, n_reads=20, workers=None, only=None):
+    """([Locus], reads, read_locus) of the PacBio configuration; models built by the native builder (error 0.3)."""
+    import multiprocessing as mp
+    import os
+    workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
+    ks = list(range(n_loci)) if only is None else [int(k) for k in only]
+    with mp.get_context("fork").Pool(workers) as pool:
+        res = pool.map(_c4_locus, [(k, seed, n_reads) for k in ks], chunksize=8)
+    loci, reads, which = [], [], []
+    for i, (params, rs) in enumerate(res):
+        loci.append(Locus(*params))
+        reads += rs
+        which += [i] * len(rs)
+    return loci, reads, np.asarray(which, dtype=np.int32)

@@ -70,10 +70,11 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
     ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
-    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3"],
+    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3", "c4"],
                     help="c1 (default, the bench line): 1 REF150 locus x --reads per GPU; c2: --loci synthetic loci x ~160 "
                          "calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by estimated work "
-                         "(strong scaling, BASELINE config 3), per-call records gathered to rank 0 over RCCL")
+                         "(strong scaling, BASELINE config 3), per-call records gathered to rank 0 over RCCL; "
+                         "c4: --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads per GPU")
     ap.add_argument("--loci", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -101,8 +102,10 @@ def main():
     n = 150
     flags = _lib.FLAG_FORCE_GENERIC if args.generic else (_lib.FLAG_STREAM if args.stream else 0)
     total_calls = None
-    if args.workload in ("c2", "c3"):
-        if args.workload == "c3":
+    if args.workload in ("c2", "c3", "c4"):
+        if args.workload == "c4":
+            loci, reads, which = workloads.make_c4(args.loci, seed=20240603 + rank)
+        elif args.workload == "c3":
             # every rank derives the same plan and the same LPT partition without communicating
             from advntr_amd import sharding
             plan = workloads.c2_plan(args.loci, seed=20240602)
@@ -125,6 +128,11 @@ def main():
         ms = np.array([d.m for d in dms])
         m = int(round(float(np.mean(ms[which]))))
         P, E = locus.model.silent_start, int(np.mean([l.model.n_edges for l in loci]))
+        lens = np.diff(off)
+        n = int(round(float(lens.mean())))
+        # exact sums over the calls (models and read lengths differ per call)
+        alg_bytes_total = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
+        relax_total = float(np.sum((lens + 1) * np.array([l.model.n_edges for l in loci], np.int64)[which]))
         args.no_cpu = True
     else:
         locus = workloads.ref150()
@@ -215,12 +223,16 @@ def main():
         total_reads = total_calls if total_calls is not None else args.reads * world
         value = total_reads * args.steps / elapsed
         B = algorithmic_bytes(n, m)
-        achieved = B * args.reads / (kernel_ms * 1e-3) / 1e9
+        if args.workload == "c1":
+            alg_bytes_total, relax_total = float(B) * args.reads, float(args.reads) * (n + 1) * E
+        achieved = alg_bytes_total / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": ("reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
                        if args.workload == "c1" else
                        "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (args.loci, world)
                        if args.workload == "c3" else
+                       "calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs, "
+                       "mean %d states)" % (n, args.loci, m) if args.workload == "c4" else
                        "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs, mean %d states)" % (args.loci, m)),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -228,6 +240,10 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
                                     "150-bp reads per GPU, seed 20240601") if args.workload == "c1" else
+                                   ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x "
+                                    "20 trimmed spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution "
+                                    "noise, seed 20240603; host model build %.2f s" % (args.loci, t_build))
+                                   if args.workload == "c4" else
                                    ("%s: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x "
                                     "~Poisson(80) mapped + 2*Poisson(40) unmapped-strand calls, seed 20240602%s; "
                                     "host model build %.2f s (native builder, %d threads)"
@@ -236,11 +252,11 @@ def main():
                                        t_build, os.cpu_count() or 1)),
                        "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
                        "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
-                       "relaxations_per_s": value * (n + 1) * E},
+                       "relaxations_per_s": value * relax_total / max(args.reads, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_unit": "GB per launch (profiles/r01_pmc_summary.json: WRITE_SIZE + 2 x FETCH_SIZE)",
-                         "algorithmic_gb_per_launch": B * args.reads / 1e9,
+                         "algorithmic_gb_per_launch": alg_bytes_total / 1e9,
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_read": B,
                          "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the max-plus recurrence is "
                                  "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
