@@ -1,7 +1,7 @@
 """Thin command line over the engine: `python -m advntr_amd genotype --loci loci.json --reads reads.fa`.
 
 Not a re-implementation of the reference's CLI (/root/reference/advntr/__main__.py, advntr_commands.py: BAM/CRAM
-input, sqlite model databases, BED/VCF writers are out of scope).  It strings the GPU stages together
+input is out of scope).  It strings the GPU stages together
 for reads that are already extracted: keyword prefilter -> per-locus Viterbi scoring of both strands -> recruit ->
 Illumina aggregation (or PacBio dominant copy numbers) -> the reference's text output (genome_analyzer.py:158-170:
 the VNTR id on one line, the genotype `a/b` on the next).
@@ -31,25 +31,37 @@ def _read_fasta(path):
 def genotype(args):
     from . import filtering, hmm_utils, settings, vntr_finder
     settings.ALIGN_REPEATS = bool(args.align_repeats)
+    from . import models
     if args.models:
-        from . import models
         wanted = set(args.vntr_id or ())
         loci = [{"id": v.id, "left": v.left_flanking_region, "right": v.right_flanking_region, "pattern": v.pattern,
                  "repeat_segments": v.get_repeat_segments() or [v.pattern],
-                 "scaled_score": v.scaled_score if v.scaled_score else None}
+                 "scaled_score": v.scaled_score if v.scaled_score else None, "vntr": v}
                 for v in models.load_unique_vntrs_data(args.models)
                 if (not wanted or v.id in wanted) and v.left_flanking_region and v.right_flanking_region]
     else:
         loci = json.load(open(args.loci))
+        for loc in loci:        # optional fields of the BED / VCF rows
+            v = models.ReferenceVNTR(loc["id"], loc["pattern"], loc.get("start_point", 0), loc.get("chromosome", "chrUn"),
+                                     loc.get("gene_name"), loc.get("annotation"), len(loc["repeat_segments"]))
+            v.init_from_xml(loc["repeat_segments"], loc["left"], loc["right"])
+            loc["vntr"] = v
+    from . import genome_analyzer
+    if args.outfmt == "bed":
+        sys.stdout.write(genome_analyzer.bed_header(args.haploid))
+    elif args.outfmt == "vcf":
+        sys.stdout.write(genome_analyzer.vcf_header([loc["vntr"] for loc in loci], args.reads))
+
+    def emit(loc, result):
+        sys.stdout.write(genome_analyzer.genotype_row(args.outfmt, loc["vntr"], loc["id"], result, False, args.haploid))
     names, seqs = _read_fasta(args.reads)
     settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
-    out = sys.stdout
     if args.pacbio:
         for loc in loci:
-            geno, _ = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
+            geno, prob = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
                 loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], [s.upper() for s in seqs],
                 accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
-            _print(out, loc["id"], geno, args.haploid)
+            emit(loc, vntr_finder.GenotypeResult(geno, len(seqs), len(seqs), 0, prob))
         return 0
     # Illumina: prefilter every read (both strands) against all loci at once
     fasta = "".join(">%d\n%s\n" % (i, s.upper()) for i, s in enumerate(seqs))
@@ -75,18 +87,8 @@ def genotype(args):
         selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
         res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
                                                                 is_haploid=args.haploid)
-        _print(out, int(loc["id"]), res.copy_numbers, args.haploid)
+        emit(loc, res)
     return 0
-
-
-def _print(out, vid, copy_numbers, haploid):
-    out.write("%s\n" % vid)
-    if copy_numbers is None:
-        out.write("None\n")
-    elif haploid:
-        out.write("%s\n" % copy_numbers[0])
-    else:
-        out.write("/".join(str(cn) for cn in sorted(copy_numbers)) + "\n")
 
 
 def main(argv=None):
@@ -104,6 +106,8 @@ def main(argv=None):
     g.add_argument("--haploid", action="store_true")
     g.add_argument("--accuracy-filter", action="store_true")
     g.add_argument("--min-matches", type=int, default=5)
+    g.add_argument("--outfmt", choices=["text", "bed", "vcf"], default="text",
+                   help="result rows as the reference writes them (genome_analyzer.py:28-170)")
     args = ap.parse_args(argv)
     if args.cmd == "genotype":
         return genotype(args)

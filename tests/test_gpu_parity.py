@@ -552,6 +552,16 @@ def test_cli_genotype_from_model_database(tmp_path):
     assert out == "21\n2/4\n"
     bad = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert bad.returncode != 0 and b"alignment" in bad.stderr
+    # BED and VCF rows (the writers are pinned on the reference's output in tests/test_output_rows.py)
+    bed = subprocess.run(cmd + ["--vntr-id", "21", "--outfmt", "bed"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert bed.splitlines()[0] == "#CHROM\tStart\tEnd\tVNTR_ID\tGene\tMotif\tRefCopy\tR1\tR2"
+    assert bed.splitlines()[1].split("\t")[:4] == ["chr1", "21000", str(21000 + 36), "21"] and bed.splitlines()[1].endswith("\t2\t4")
+    vcf = subprocess.run(cmd + ["--vntr-id", "21", "--outfmt", "vcf"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+    rows = [l for l in vcf.splitlines() if not l.startswith("#")]
+    assert vcf.startswith("##fileformat=VCFv4.2\n") and "##contig=<ID=1>" in vcf and len(rows) == 1
+    f = rows[0].split("\t")
+    assert f[0] == "chr1" and f[7].startswith("END=%d;VID=21;RU=" % (21000 + 36)) and f[8] == "GT:DP:SR:FR:ML"
+    assert f[9].startswith("0/1:")                      # 2 copies = the reference count, 4 = the one alternative allele
 
 
 @pytest.mark.gpu
