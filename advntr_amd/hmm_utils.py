@@ -443,3 +443,14 @@ def path_to_alignment(x, y, path):
         elif state.name.startswith('I'):
             x = x[:i] + '-' + x[i:]
     return x, y
+
+
+def get_emitted_basepair_from_visited_states(state, visited_states, sequence):
+    """hmm_utils.py:106-113: the read base emitted at the first occurrence of `state` on the path."""
+    at = 0
+    for name in visited_states:
+        if name == state:
+            return sequence[at]
+        if is_emitting_state(name):
+            at += 1
+    return None

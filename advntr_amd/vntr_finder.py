@@ -470,3 +470,80 @@ def train_classifier_threshold(reference_vntr, sequences, read_length=150):
     true_scores = find_hmm_score_of_simulated_reads(model, true_reads)
     false_scores = find_hmm_score_of_simulated_reads(model, false_reads)
     return find_recruitment_score_threshold(true_scores, false_scores) / float(read_length)
+
+
+# ------------------------------------------------------------------------------------------------
+# Frameshift identification from Viterbi paths (vntr_finder.py:256-309) -- a consumer of the engine's PATH output
+# ------------------------------------------------------------------------------------------------
+def identify_frameshift(location_coverage, observed_indel_transitions, expected_indels, error_rate=0.01):
+    """vntr_finder.py:256-263: binomial likelihood ratio of "sequencing error" against "frameshift"."""
+    if observed_indel_transitions >= location_coverage:
+        return True
+    from scipy.stats import binom
+    sequencing_error_prob = binom.pmf(observed_indel_transitions, location_coverage, error_rate)
+    frameshift_prob = binom.pmf(observed_indel_transitions, location_coverage, expected_indels)
+    return bool(sequencing_error_prob / frameshift_prob < 0.01)
+
+
+def find_frameshift_from_selected_reads(pattern_length, vntr_length, selected_reads):
+    """vntr_finder.py:265-309.  selected_reads = [(sequence, visited_state_names)] with the names of vpath[1:-1].
+    Counts, per insert/delete state, the repeat units whose length is off by one or two bases from the pattern, and
+    tests the most frequent one against the per-base coverage.  Returns the state label (an insert state carries the
+    inserted base, e.g. 'I3A') or None."""
+    from .hmm_utils import get_emitted_basepair_from_visited_states, get_repeating_pattern_lengths, state_class_from_name
+    mutations = {}
+    repeating_bps_in_data = 0
+    for sequence, visited_states in selected_reads:
+        repeats_lengths = get_repeating_pattern_lengths(visited_states)
+        current_repeat = None
+        for name in visited_states:                       # emitting states outside the flanks = repeat bases
+            c = state_class_from_name(name)
+            if (c & _lib.SC_EMIT) and not (c & _lib.SC_FIX):
+                repeating_bps_in_data += 1
+        for name in visited_states:
+            if name.endswith('fix') or name.startswith('M'):
+                continue
+            if name.startswith('unit_start'):
+                current_repeat = 0 if current_repeat is None else current_repeat + 1
+            if current_repeat is None or current_repeat >= len(repeats_lengths):
+                continue
+            if not name.startswith('I') and not name.startswith('D'):
+                continue
+            if repeats_lengths[current_repeat] == pattern_length:
+                continue
+            state = name.split('_')[0]
+            if state.startswith('I'):
+                state += get_emitted_basepair_from_visited_states(name, visited_states, sequence)
+            if abs(repeats_lengths[current_repeat] - pattern_length) <= 2:
+                mutations[state] = mutations.get(state, 0) + 1
+    ranked = sorted(mutations.items(), key=lambda kv: kv[1])           # stable: ties keep first-seen order
+    candidate = ranked[-1] if ranked else (None, 0)
+    avg_bp_coverage = float(repeating_bps_in_data) / vntr_length / 2
+    if identify_frameshift(avg_bp_coverage, candidate[1], 1 / avg_bp_coverage):
+        return candidate[0]
+    return None
+
+
+def find_frameshift(model, pattern_length, vntr_length, sequences, scaled_score=None):
+    """find_frameshift_from_alignment_file (vntr_finder.py:776-780) on already extracted reads: both strands scored
+    with PATH output in one batch, recruited reads with > 2 repeat bases selected (process_unmapped_read), then the
+    test above."""
+    keep = [s.upper() for s in sequences if s.count('N') <= 0]
+    if not keep:
+        return None
+    batch = keep + [reverse_complement(s) for s in keep]
+    logp, summ, paths = model.viterbi_batch(batch, want_paths=True, want_summary=True)
+    names = [st.name for st in model.states]
+    nf = len(keep)
+    selected = []
+    for j in range(nf):
+        a = j + nf if logp[j] < logp[j + nf] else j
+        if paths[a] is None:
+            continue
+        seq = batch[a]
+        recruited = recruit_read(float(logp[a]), summ[a], get_min_score_to_select_a_read(scaled_score, len(seq)), len(seq))
+        if recruited and summ[a][_lib.SUM_REPEAT_BP] > 2:
+            selected.append((seq, [names[i] for i in paths[a][1:-1]]))
+    if not selected:
+        return None
+    return find_frameshift_from_selected_reads(pattern_length, vntr_length, selected)
