@@ -72,6 +72,17 @@ def genotype(args):
                  for i, s in enumerate(seqs))
     _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
     read_length = int(np.median([len(s) for s in seqs[:5]])) if seqs else 150     # vntr_finder.py:714-718
+    if args.frameshift:        # genome_analyzer.py:260-271: the id, then the frameshift state label or None
+        for loc in loci:
+            vid = int(loc["id"])
+            picked = sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))
+            copies = vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))
+            model = hmm_utils.get_read_matcher_model(loc["left"][-read_length:], loc["right"][:read_length],
+                                                     loc["repeat_segments"], copies)
+            result = vntr_finder.find_frameshift(model, len(loc["pattern"]), sum(len(x) for x in loc["repeat_segments"]),
+                                                 [seqs[i] for i in picked], loc.get("scaled_score"))
+            sys.stdout.write("%s\n%s\n" % (loc["id"], result))
+        return 0
     # all models in one native build, all (read, strand, locus) calls in one engine batch
     specs, cands = [], []
     for loc in loci:
@@ -106,6 +117,8 @@ def main(argv=None):
     g.add_argument("--haploid", action="store_true")
     g.add_argument("--accuracy-filter", action="store_true")
     g.add_argument("--min-matches", type=int, default=5)
+    g.add_argument("-fs", "--frameshift", action="store_true",
+                   help="search for a frameshift in the VNTR instead of a copy number (vntr_finder.py:256-309)")
     g.add_argument("--outfmt", choices=["text", "bed", "vcf"], default="text",
                    help="result rows as the reference writes them (genome_analyzer.py:28-170)")
     args = ap.parse_args(argv)

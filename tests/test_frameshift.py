@@ -34,3 +34,21 @@ def test_frameshift_end_to_end_on_the_gpu():
         model = hmm_utils.get_read_matcher_model(case["left"][-150:], case["right"][:150], case["repeat_segments"], case["copies"])
         got = vntr_finder.find_frameshift(model, len(case["pattern"]), case["vntr_length"], case["reads"])
         assert got == case["frameshift"], case["name"]
+
+
+@pytest.mark.gpu
+def test_cli_frameshift(tmp_path):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = load_golden("frameshift")
+    case = [c for c in g["cases"] if c["name"] == "insertion_both"][0]
+    loci = [{"id": 5, "left": case["left"], "right": case["right"], "pattern": case["pattern"],
+             "repeat_segments": case["repeat_segments"], "scaled_score": None}]
+    (tmp_path / "loci.json").write_text(json.dumps(loci))
+    (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(case["reads"])))
+    out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"),
+                          "--reads", str(tmp_path / "reads.fa"), "--frameshift"], cwd=ROOT, stdout=subprocess.PIPE,
+                         check=True).stdout.decode()
+    assert out == "5\nI5T\n"
