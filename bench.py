@@ -203,11 +203,12 @@ def main():
 
     # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
     # the bench); None when the profile does not describe this workload/kernel
-    traffic = None
+    traffic, valu_insts = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
         if args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_columns":
             traffic = pmc["hbm_bytes_per_launch_fetch_x2"] / 1e9
+            valu_insts = pmc.get("valu_insts_per_launch")
     except Exception:
         traffic = None
 
@@ -261,6 +262,13 @@ def main():
                          "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the max-plus recurrence is "
                                  "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
         }
+        if valu_insts:
+            # what actually bounds the kernel: every wave64 VALU instruction holds its SIMD for 4 cycles (MI355X: 256 CUs x
+            # 4 SIMDs at 2.4 GHz); SQ_INSTS_VALU per launch from the committed PMC pass of this same command
+            bound_ms = valu_insts * 4 / (1024 * 2.4e9) * 1e3
+            out["roofline"]["valu_issue"] = {"valu_insts_per_launch": valu_insts, "cycles_per_inst": 4, "simds": 1024,
+                                             "clock_ghz": 2.4, "issue_bound_ms": bound_ms, "kernel_ms": kernel_ms,
+                                             "frac": bound_ms / kernel_ms}
         if not args.no_cpu:
             cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, args.reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
