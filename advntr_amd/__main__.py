@@ -46,23 +46,34 @@ def genotype(args):
                                      loc.get("gene_name"), loc.get("annotation"), len(loc["repeat_segments"]))
             v.init_from_xml(loc["repeat_segments"], loc["left"], loc["right"])
             loc["vntr"] = v
-    from . import genome_analyzer
-    if args.outfmt == "bed":
-        sys.stdout.write(genome_analyzer.bed_header(args.haploid))
-    elif args.outfmt == "vcf":
-        sys.stdout.write(genome_analyzer.vcf_header([loc["vntr"] for loc in loci], args.reads))
+    from . import genome_analyzer, sharding
+    rank = _init_distributed()
+    if rank == 0 and not args.frameshift:
+        if args.outfmt == "bed":
+            sys.stdout.write(genome_analyzer.bed_header(args.haploid))
+        elif args.outfmt == "vcf":
+            sys.stdout.write(genome_analyzer.vcf_header([loc["vntr"] for loc in loci], args.reads))
 
-    def emit(loc, result):
-        sys.stdout.write(genome_analyzer.genotype_row(args.outfmt, loc["vntr"], loc["id"], result, False, args.haploid))
+    def row(loc, result):
+        return genome_analyzer.genotype_row(args.outfmt, loc["vntr"], loc["id"], result, False, args.haploid)
+
+    def finish(rows):          # rows of all loci are back on rank 0, in locus order
+        if rows is not None:
+            sys.stdout.write("".join(rows))
+        return 0
     names, seqs = _read_fasta(args.reads)
     settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
     if args.pacbio:
-        for loc in loci:
-            geno, prob = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
-                loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], [s.upper() for s in seqs],
-                accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
-            emit(loc, vntr_finder.GenotypeResult(geno, len(seqs), len(seqs), 0, prob))
-        return 0
+        def pacbio_job(indices):
+            out = []
+            for i in indices:
+                loc = loci[i]
+                geno, prob = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
+                    loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], [s.upper() for s in seqs],
+                    accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
+                out.append(row(loc, vntr_finder.GenotypeResult(geno, len(seqs), len(seqs), 0, prob)))
+            return out
+        return finish(sharding.run_sharded([len(loc["pattern"]) for loc in loci], pacbio_job))
     # Illumina: prefilter every read (both strands) against all loci at once
     fasta = "".join(">%d\n%s\n" % (i, s.upper()) for i, s in enumerate(seqs))
     keywords = {int(loc["id"]): filtering.get_keywords_for_filtering(loc["left"], loc["repeat_segments"], loc["right"],
@@ -72,34 +83,81 @@ def genotype(args):
                  for i, s in enumerate(seqs))
     _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
     read_length = int(np.median([len(s) for s in seqs[:5]])) if seqs else 150     # vntr_finder.py:714-718
-    if args.frameshift:        # genome_analyzer.py:260-271: the id, then the frameshift state label or None
-        for loc in loci:
-            vid = int(loc["id"])
-            picked = sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))
-            copies = vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))
-            model = hmm_utils.get_read_matcher_model(loc["left"][-read_length:], loc["right"][:read_length],
-                                                     loc["repeat_segments"], copies)
-            result = vntr_finder.find_frameshift(model, len(loc["pattern"]), sum(len(x) for x in loc["repeat_segments"]),
-                                                 [seqs[i] for i in picked], loc.get("scaled_score"))
-            sys.stdout.write("%s\n%s\n" % (loc["id"], result))
-        return 0
-    # all models in one native build, all (read, strand, locus) calls in one engine batch
-    specs, cands = [], []
-    for loc in loci:
+    def candidates(loc):
         vid = int(loc["id"])
-        picked = sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))
-        cands.append([seqs[i] for i in picked])
-        specs.append((loc["left"][-read_length:], loc["right"][:read_length], loc["repeat_segments"],
-                      vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))))
-    models = hmm_utils.build_read_matcher_models(specs)
-    scored_all = vntr_finder.score_reads_multi(models, cands, [loc.get("scaled_score") for loc in loci], True)
-    for loc, scored in zip(loci, scored_all):
-        scored = [s for s in scored if s is not None]
-        selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
-        res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
-                                                                is_haploid=args.haploid)
-        emit(loc, res)
-    return 0
+        return [seqs[i] for i in sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))]
+
+    cands = [candidates(loc) for loc in loci]
+    # whole loci go to ranks by estimated work (calls x states); one process per GPU under
+    # torch.distributed.run, a plain loop over everything otherwise
+    work = [max(1, len(c)) * (6 * read_length + 3 * vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"])) *
+                              (len(loc["repeat_segments"][0]) + 1) + 18) for loc, c in zip(loci, cands)]
+    if args.frameshift:        # genome_analyzer.py:260-271: the id, then the frameshift state label or None
+        def frameshift_job(indices):
+            out = []
+            for i in indices:
+                out.append(_frameshift_row(loci[i], cands[i], read_length, hmm_utils, vntr_finder))
+            return out
+        return finish(sharding.run_sharded(work, frameshift_job))
+    def genotype_job(indices):
+        # all models of this rank's share in one native build, all (read, strand, locus) calls in one engine batch
+        specs = [(loci[i]["left"][-read_length:], loci[i]["right"][:read_length], loci[i]["repeat_segments"],
+                  vntr_finder.get_copies_for_hmm(read_length, len(loci[i]["pattern"]))) for i in indices]
+        built = hmm_utils.build_read_matcher_models(specs)
+        scored_all = vntr_finder.score_reads_multi(built, [cands[i] for i in indices],
+                                                   [loci[i].get("scaled_score") for i in indices], True)
+        out = []
+        for i, scored in zip(indices, scored_all):
+            scored = [s for s in scored if s is not None]
+            selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
+            res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
+                                                                    is_haploid=args.haploid)
+            out.append(row(loci[i], res))
+        return out
+    return finish(sharding.run_sharded(work, genotype_job))
+
+
+def _frameshift_row(loc, cand, read_length, hmm_utils, vntr_finder):
+    copies = vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"]))
+    model = hmm_utils.get_read_matcher_model(loc["left"][-read_length:], loc["right"][:read_length],
+                                             loc["repeat_segments"], copies)
+    result = vntr_finder.find_frameshift(model, len(loc["pattern"]), sum(len(x) for x in loc["repeat_segments"]), cand,
+                                         loc.get("scaled_score"))
+    return "%s\n%s\n" % (loc["id"], result)
+
+
+def _init_distributed():
+    """Under torch.distributed.run (one process per GPU): join the process group over RCCL and bind this rank's GPU.
+    Returns the rank (0 when run as a single process)."""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return 0
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    # one rank per GPU; ADVNTR_DIST_BACKEND=gloo lets several ranks share a GPU (single-GPU test boxes), where RCCL
+    # would refuse two ranks on one device
+    backend = os.environ.get("ADVNTR_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    _lib.check(_lib.load().advntr_set_device(local))
+    return dist.get_rank()
+
+
+def _shutdown_distributed():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    except ImportError:
+        pass
 
 
 def main(argv=None):
@@ -123,7 +181,10 @@ def main(argv=None):
                    help="result rows as the reference writes them (genome_analyzer.py:28-170)")
     args = ap.parse_args(argv)
     if args.cmd == "genotype":
-        return genotype(args)
+        try:
+            return genotype(args)
+        finally:
+            _shutdown_distributed()
     ap.print_help()
     return 2
 

@@ -62,3 +62,32 @@ def gather_records(read_ids, logp, summary, dst=0, device=None):
     all_sm = torch.cat([bufs[2][k][:counts[k]] for k in range(world)]).cpu().numpy()
     order = np.argsort(all_ids, kind="stable")
     return all_ids[order], all_lp[order], all_sm[order]
+
+
+def run_sharded(work, fn, dst=0):
+    """Locus-sharded execution of a per-locus job: every rank takes its LPT share of range(len(work)), calls
+    fn(indices) -> list of picklable results (one per index, same order) and the results come back to rank `dst` in
+    index order (None elsewhere).  One gather of Python objects at the end; with no process group (single process) it
+    just runs fn over everything.  This is how `python -m advntr_amd genotype` runs under torch.distributed.run."""
+    n = len(work)
+    try:
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        active = False
+    if not active:
+        return list(fn(list(range(n))))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = [int(i) for i in partition_loci(work, world)[rank]]
+    results = list(fn(mine))
+    if len(results) != len(mine):
+        raise ValueError("run_sharded: fn returned %d results for %d indices" % (len(results), len(mine)))
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(list(zip(mine, results)), gathered, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * n
+    for part in gathered:
+        for i, r in part:
+            out[i] = r
+    return out

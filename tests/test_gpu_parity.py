@@ -638,3 +638,38 @@ def test_bulk_uploaded_models_equal_single_uploads():
     one, off1 = _lib.encode_reads(reads)
     c = _lib.viterbi_batch([keep.device_model()], one, off1, np.zeros(len(reads), np.int32))
     assert np.array_equal(c[0], a[0][2 * len(reads):3 * len(reads)])
+
+
+@pytest.mark.gpu
+def test_cli_sharded_over_two_ranks_equals_single_process(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m advntr_amd genotype ...`: loci split over two ranks (gloo
+    here, so that both can share the one GPU of the test box; RCCL on a multi-GPU node), rows gathered to rank 0 --
+    identical stdout to the single-process run."""
+    import json
+    import subprocess
+    import sys
+    from advntr_amd import workloads, vntr_finder
+    from conftest import ROOT
+    rng = np.random.default_rng(99)
+    loci, reads = [], []
+    for vid, alleles in ((31, (3, 5)), (32, (4, 4)), (33, (2, 6)), (34, (5, 7)), (35, (3, 3))):
+        pattern = workloads.rand_seq(rng, int(rng.integers(10, 30)))
+        left, right = workloads.rand_seq(rng, 150), workloads.rand_seq(rng, 150)
+        loci.append({"id": vid, "left": left, "right": right, "pattern": pattern, "repeat_segments": [pattern],
+                     "scaled_score": None, "chromosome": "chr2", "start_point": 1000 * vid})
+        for copies in alleles:
+            allele = left + pattern * copies + right
+            for _ in range(25):
+                st = int(rng.integers(40, 100))
+                s = allele[st:st + 150]
+                reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
+    (tmp_path / "loci.json").write_text(json.dumps(loci))
+    (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+    args = ["genotype", "--loci", str(tmp_path / "loci.json"), "--reads", str(tmp_path / "reads.fa"), "--outfmt", "bed"]
+    single = subprocess.run([sys.executable, "-m", "advntr_amd"] + args, cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout
+    env = dict(os.environ, ADVNTR_DIST_BACKEND="gloo")
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29577", "-m", "advntr_amd"] + args,
+                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+    assert single.decode().count("\n") == 6 and b"\t3\t5\n" in single
+    assert multi == single
