@@ -48,6 +48,7 @@ SYMBOLS = {
     "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "advntr_build_read_matchers": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _i32, _u32, _vp]),
     "advntr_align_repeats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp]),
+    "advntr_flank_align": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "advntr_built_info": (ctypes.c_int, [_vp, _vp]),
     "advntr_built_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "advntr_built_upload": (_vp, [_vp]),
@@ -400,3 +401,27 @@ class DeviceBatch(object):
             self.close()
         except Exception:
             pass
+
+
+def flank_align(reads, flanks, pair_read, pair_flank):
+    """advntr_flank_align: local alignment (1, -1, -1, -1) of flanks[pair_flank[p]] to reads[pair_read[p]].  Returns
+    (score, begin, end) int32 arrays and the kernel time in ms.  Symbols outside ACGT match nothing."""
+    L = load()
+    require_gpu()
+    code = _CODE.copy()
+    code[code == 255] = 4
+    def enc(seqs, off_dtype):
+        off = np.zeros(len(seqs) + 1, off_dtype)
+        np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), out=off[1:])
+        raw = np.frombuffer("".join(seqs).upper().encode("latin-1", "replace"), dtype=np.uint8)
+        return np.ascontiguousarray(code[raw]), off
+    rb, roff = enc(list(reads), np.int64)
+    fb, foff = enc(list(flanks), np.int32)
+    pr = np.ascontiguousarray(pair_read, np.int32)
+    pf = np.ascontiguousarray(pair_flank, np.int32)
+    n = len(pr)
+    score, begin, end = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    ms = ctypes.c_float(0)
+    check(L.advntr_flank_align(ptr(rb), ptr(roff), len(reads), ptr(fb), ptr(foff), len(flanks), ptr(pr), ptr(pf), n,
+                               ptr(score), ptr(begin), ptr(end), ctypes.byref(ms)))
+    return score, begin, end, ms.value

@@ -547,3 +547,46 @@ def find_frameshift(model, pattern_length, vntr_length, sequences, scaled_score=
     if not selected:
         return None
     return find_frameshift_from_selected_reads(pattern_length, vntr_length, selected)
+
+
+# ------------------------------------------------------------------------------------------------
+# PacBio spanning-read extraction (vntr_finder.py:324-371): which long reads cover the whole VNTR, and where
+# ------------------------------------------------------------------------------------------------
+def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, flanking_region_size=100):
+    """check_if_pacbio_read_spans_vntr for a batch of long reads: both strands of every read are tested with
+    check_if_flanking_regions_align_to_str -- local alignment (1, -1, -1, -1) of the last `flanking_region_size` bases
+    of the left flank and the first of the right flank; both must reach len(flank) * (1 - MAX_ERROR_RATE) and the right
+    one must not begin before the left one.  The four alignments per read run as one advntr_flank_align call (the
+    reference calls Bio.pairwise2 once per alignment, in Python).  Returns (spanning, length_distribution):
+    spanning = [(trimmed sequence = read[left_begin : right_begin + flank size], read index, is_reverse_strand)],
+    length_distribution = [right_begin - (left_begin + flank size)].  PARITY UNPINNED with respect to biopython
+    (absent from the image): scores are plain Smith-Waterman; `begin` follows pairwise2's documented conventions."""
+    from . import settings
+    left = left_flanking_region[-flanking_region_size:]
+    right = right_flanking_region[:flanking_region_size]
+    strands = []
+    for s in reads:
+        up = str(s).upper()
+        strands.append(up)
+        strands.append(up.translate(_COMP_STR)[::-1])
+    if not strands:
+        return [], []
+    n = len(strands)
+    pair_read = np.repeat(np.arange(n, dtype=np.int32), 2)
+    pair_flank = np.tile(np.array([0, 1], np.int32), n)
+    score, begin, _, _ = _lib.flank_align(strands, [left, right], pair_read, pair_flank)
+    spanning, lengths = [], []
+    for k, seq in enumerate(strands):
+        ls, lb, rs, rb = int(score[2 * k]), int(begin[2 * k]), int(score[2 * k + 1]), int(begin[2 * k + 1])
+        if ls <= 0 or ls < len(left) * (1 - settings.MAX_ERROR_RATE):
+            continue
+        if rs <= 0 or rs < len(right) * (1 - settings.MAX_ERROR_RATE):
+            continue
+        if rb < lb:
+            continue
+        spanning.append((seq[lb:rb + flanking_region_size], k // 2, bool(k & 1)))
+        lengths.append(rb - (lb + flanking_region_size))
+    return spanning, lengths
+
+
+_COMP_STR = str.maketrans("ACGTN", "TGCAN")

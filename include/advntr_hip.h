@@ -179,6 +179,18 @@ advntr_hmm *advntr_built_upload(const advntr_built *built);
 int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out);
 void advntr_built_destroy(advntr_built *built);
 
+/* ---- flank alignment for long reads (the stage upstream of the PacBio scoring path) ---------------------------
+ * Replaces the two Bio.pairwise2.align.localms(read, flank, 1, -1, -1, -1) calls per read and strand of
+ * VNTRFinder.check_if_flanking_regions_align_to_str (/root/reference/advntr/vntr_finder.py:324-365): local alignment
+ * (match +1, mismatch -1, gap -1 per base) of flank pair_flank[p] (<= 128 bases) against read pair_read[p], n_pairs at
+ * once, one per wavefront.  Reads / flanks as base codes 0..3 (anything else matches nothing), concatenated with
+ * offsets.  out_score[p] = best local score (0 = no positive-scoring alignment), out_begin[p] = the `begin` of the
+ * first alignment pairwise2 would return (max of the two start indices; -1 if none), out_end[p] = read index of its
+ * last aligned base.  PARITY UNPINNED with respect to biopython (absent from the image), see csrc/flank_align.h.     */
+int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_reads, const uint8_t *flank_bases,
+                       const int32_t *flank_off, int32_t n_flanks, const int32_t *pair_read, const int32_t *pair_flank,
+                       int32_t n_pairs, int32_t *out_score, int32_t *out_begin, int32_t *out_end, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

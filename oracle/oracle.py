@@ -237,3 +237,21 @@ def recruit_read(logp, names, min_score, sequence, left_flank, right_flank):  # 
     if min_score is None and matches >= 0.9 * read_length and logp > -read_length:
         return True
     return False
+
+
+# ---------------------------------------------------------------------------------------------
+# flank alignment (flank_align_oracle.c) -- PARITY UNPINNED with respect to biopython, see the C file
+# ---------------------------------------------------------------------------------------------
+def flank_align(read, flank):
+    """(score, begin, end) of the local alignment (1, -1, -1, -1) the reference asks pairwise2 for."""
+    L = lib()
+    L.oracle_flank_align.restype = None
+    L.oracle_flank_align.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
+    code = np.full(256, 4, np.uint8)
+    for i, c in enumerate("ACGT"):
+        code[ord(c)] = i
+    r = np.ascontiguousarray(code[np.frombuffer(read.upper().encode("latin-1", "replace"), np.uint8)])
+    f = np.ascontiguousarray(code[np.frombuffer(flank.upper().encode("latin-1", "replace"), np.uint8)])
+    out = (ctypes.c_int * 3)()
+    L.oracle_flank_align(r.ctypes.data, len(r), f.ctypes.data, len(f), ctypes.byref(out, 0), ctypes.byref(out, 4), ctypes.byref(out, 8))
+    return int(out[0]), int(out[1]), int(out[2])

@@ -1,0 +1,110 @@
+"""Flank alignment for long reads (csrc/flank_align.h) against its CPU restatement (oracle/flank_align_oracle.c).
+PARITY UNPINNED with respect to biopython's pairwise2 (absent from the image): these tests pin the kernel on the
+restatement -- full score matrix and explicit walk-back, a different formulation from the kernel's forward start
+propagation -- and on hand-checked cases."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_restatement_hand_checked_cases():
+    assert O.flank_align("TTTTACGTACGTTTTT", "ACGTACGT") == (8, 4, 11)
+    assert O.flank_align("TTTTACGTTCGTTTTT", "ACGTACGT") == (6, 4, 11)            # one mismatch inside: 7 - 1
+    assert O.flank_align("GGGG", "ACAC") == (0, -1, -1)
+    assert O.flank_align("", "ACGT") == (0, -1, -1)
+    # the flank occurs twice: the first alignment pairwise2 returns ends at the LAST best cell
+    assert O.flank_align("ACGTACGTGGGGGACGTACGT", "ACGTACGT") == (8, 13, 20)
+    # alignment starts inside the flank (flank index 3 > read index 0): begin = max of the two start indices
+    assert O.flank_align("TACGT", "GGGTACGT") == (5, 3, 4)
+    # one base missing from the read: 10 matches, one gap
+    assert O.flank_align("CCCCACGTAGTACCCCC", "ACGTACGTAC")[0] == 8
+    # N matches nothing
+    assert O.flank_align("TTTTACGNACGTTTTT", "ACGTACGT")[0] == 6
+
+
+def _noisy(rng, s, rate):
+    out = []
+    for ch in s:
+        x = rng.random()
+        if x < rate / 3:
+            continue
+        if x < 2 * rate / 3:
+            out.append("ACGT"[int(rng.integers(0, 4))])
+        if 2 * rate / 3 <= x < rate:
+            ch = "ACGT"[int(rng.integers(0, 4))]
+        out.append(ch)
+    return "".join(out)
+
+
+@pytest.mark.gpu
+def test_kernel_equals_restatement_on_random_pairs():
+    from advntr_amd import _lib, workloads
+    rng = np.random.default_rng(2024)
+    reads, flanks, pr, pf = [], [], [], []
+    for f in range(12):
+        flanks.append(workloads.rand_seq(rng, int(rng.choice([1, 7, 63, 64, 65, 100, 100, 100, 128]))))
+    for r in range(60):
+        n = int(rng.choice([0, 1, 5, 64, 200, 1500, 4000]))
+        body = workloads.rand_seq(rng, n)
+        if n >= 200:                                   # plant noisy copies of some flanks (once or twice)
+            for _ in range(int(rng.integers(1, 4))):
+                f = flanks[int(rng.integers(0, len(flanks)))]
+                at = int(rng.integers(0, max(1, n - len(f))))
+                c = _noisy(rng, f, float(rng.choice([0.0, 0.05, 0.15])))
+                body = body[:at] + c + body[at + len(c):]
+        if r % 9 == 0 and n > 10:
+            body = body[:5] + "N" + body[6:]
+        reads.append(body)
+    for r in range(len(reads)):
+        for f in range(len(flanks)):
+            pr.append(r)
+            pf.append(f)
+    # low-complexity pairs provoke ties in score and in the walk-back
+    reads += ["ACACACACACACACACACAC", "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", "ACGTACGTACGTACGTACGTACGT"]
+    flanks += ["ACACAC", "AAAAAAAA", "ACGTACGT", "CACACACA"]
+    for r in range(len(reads) - 3, len(reads)):
+        for f in range(len(flanks) - 4, len(flanks)):
+            pr.append(r)
+            pf.append(f)
+    score, begin, end, ms = _lib.flank_align(reads, flanks, pr, pf)
+    for p in range(len(pr)):
+        want = O.flank_align(reads[pr[p]], flanks[pf[p]])
+        assert (int(score[p]), int(begin[p]), int(end[p])) == want, (p, pr[p], pf[p], len(reads[pr[p]]), len(flanks[pf[p]]))
+    assert (score > 50).sum() > 20
+
+
+@pytest.mark.gpu
+def test_extract_spanning_reads():
+    """Long reads that span, half-span or miss a VNTR, on either strand: the spanning ones come back trimmed to the
+    flanks, as check_if_flanking_regions_align_to_str does (vntr_finder.py:324-365)."""
+    from advntr_amd import settings, vntr_finder, workloads
+    rng = np.random.default_rng(7)
+    left, right, pattern = workloads.rand_seq(rng, 500), workloads.rand_seq(rng, 500), workloads.rand_seq(rng, 30)
+    settings.MAX_ERROR_RATE = 0.3
+    try:
+        reads, truth = [], []
+        for k in range(24):
+            copies = int(rng.integers(3, 30))
+            core = left[-100:] + pattern * copies + right[:100]
+            kind = k % 4
+            if kind == 0:                                   # spans, forward
+                s = workloads.rand_seq(rng, 800) + _noisy(rng, left[:-100][-300:] + core + right[100:][:300], 0.1) + workloads.rand_seq(rng, 500)
+            elif kind == 1:                                 # spans, reverse strand
+                s = vntr_finder.reverse_complement(workloads.rand_seq(rng, 300) + _noisy(rng, core, 0.1) + workloads.rand_seq(rng, 900))
+            elif kind == 2:                                 # only the left flank
+                s = workloads.rand_seq(rng, 700) + _noisy(rng, left[-100:] + pattern * copies, 0.1)
+            else:                                           # unrelated
+                s = workloads.rand_seq(rng, 2500)
+            reads.append(s)
+            truth.append((kind, copies))
+        spanning, lengths = vntr_finder.extract_spanning_reads(left, right, reads)
+        got = {idx: (seq, rev) for seq, idx, rev in spanning}
+        assert sorted(got) == [k for k, (kind, _) in enumerate(truth) if kind in (0, 1)]
+        for (seq, idx, rev), ln in zip(spanning, lengths):
+            kind, copies = truth[idx]
+            assert rev == (kind == 1)
+            assert abs(ln - copies * 30) <= 0.25 * copies * 30 + 12            # the VNTR part, up to the planted noise
+            assert abs(len(seq) - (ln + 200)) <= 1
+    finally:
+        settings.MAX_ERROR_RATE = 0.05
