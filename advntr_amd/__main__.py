@@ -68,10 +68,13 @@ def genotype(args):
             out = []
             for i in indices:
                 loc = loci[i]
+                spanning = [s.upper() for s in seqs]
+                if args.extract_spanning:       # untrimmed long reads: keep the ones that span the VNTR, trimmed to its flanks
+                    spanning = [t[0] for t in vntr_finder.extract_spanning_reads(loc["left"], loc["right"], seqs)[0]]
                 geno, prob = vntr_finder.get_dominant_copy_numbers_from_spanning_reads(
-                    loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], [s.upper() for s in seqs],
+                    loc["left"], loc["right"], loc["repeat_segments"], loc["pattern"], spanning,
                     accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
-                out.append(row(loc, vntr_finder.GenotypeResult(geno, len(seqs), len(seqs), 0, prob)))
+                out.append(row(loc, vntr_finder.GenotypeResult(geno, len(spanning), len(spanning), 0, prob)))
             return out
         return finish(sharding.run_sharded([len(loc["pattern"]) for loc in loci], pacbio_job))
     # Illumina: prefilter every read (both strands) against all loci at once
@@ -172,6 +175,9 @@ def main(argv=None):
                    help="align repeat segments of unequal length with the built-in aligner (instead of refusing them)")
     g.add_argument("--reads", required=True)
     g.add_argument("--pacbio", action="store_true", help="reads are trimmed spanning long reads (error rate 0.3)")
+    g.add_argument("--extract-spanning", action="store_true",
+                   help="with --pacbio: the reads are whole long reads; find the ones that span each VNTR by aligning its "
+                        "flanks (vntr_finder.py:324-371; GPU Smith-Waterman, parity with biopython unpinned) and trim them")
     g.add_argument("--haploid", action="store_true")
     g.add_argument("--accuracy-filter", action="store_true")
     g.add_argument("--min-matches", type=int, default=5)

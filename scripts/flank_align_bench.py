@@ -1,0 +1,52 @@
+"""Throughput of the flank alignment (advntr_flank_align) on PacBio-sized input: reads of 5-15 kb, two 100-base flanks,
+both strands = 4 alignments per read.  One JSON line: alignments/s, DP cells/s, HBM roofline by algorithmic bytes (each
+alignment streams its read once: n bytes), CPU restatement on a bounded sample.
+    python scripts/flank_align_bench.py [n_reads]"""
+import json, sys, time
+import numpy as np
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+e.build()
+from advntr_amd import _lib, workloads, vntr_finder
+from oracle import oracle as O
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+rng = np.random.default_rng(11)
+left, right, pattern = workloads.rand_seq(rng, 100), workloads.rand_seq(rng, 100), workloads.rand_seq(rng, 40)
+reads = []
+for k in range(n_reads):
+    n = int(rng.integers(5000, 15001))
+    s = workloads.rand_seq(rng, n)
+    if k % 3 == 0:
+        core = workloads.noisy_copy(rng, left + pattern * int(rng.integers(3, 20)) + right, 0.12)
+        at = int(rng.integers(0, n - len(core)))
+        s = s[:at] + core + s[at + len(core):]
+    reads.append(s)
+strands = []
+for s in reads:
+    strands += [s, vntr_finder.reverse_complement(s)]
+pr = np.repeat(np.arange(len(strands), dtype=np.int32), 2)
+pf = np.tile(np.array([0, 1], np.int32), len(strands))
+_lib.flank_align(strands[:8], [left, right], pr[:16], pf[:16])                      # warm-up
+t0 = time.perf_counter()
+score, begin, end, ms = _lib.flank_align(strands, [left, right], pr, pf)
+wall = time.perf_counter() - t0
+cells = float(sum(len(strands[r]) for r in pr)) * 100
+bytes_alg = float(sum(len(strands[r]) for r in pr))
+n_cpu = 24
+t0 = time.perf_counter()
+for p in range(n_cpu):
+    got = O.flank_align(strands[pr[p]], [left, right][pf[p]])
+    assert got == (int(score[p]), int(begin[p]), int(end[p])), p
+cpu = n_cpu / (time.perf_counter() - t0)
+print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read, Smith-Waterman 1/-1/-1)",
+                  "value": len(pr) / (ms * 1e-3), "unit": "alignments/s", "n_gpus": 1, "dtype": "i32", "data": "synthetic",
+                  "config": {"workload": "%d reads of 5-15 kb x 2 strands x 2 flanks" % n_reads, "alignments": int(len(pr)),
+                             "cells_per_s": cells / (ms * 1e-3), "kernel_ms": ms, "call_ms_incl_pcie_and_host": wall * 1e3,
+                             "spanning_found": int(((score[0::2] >= 70) & (score[1::2] >= 70) & (begin[1::2] >= begin[0::2])).sum())},
+                  "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": bytes_alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                               "note": "algorithmic bytes = one pass over the read per alignment; the recurrence is VALU-bound"},
+                  "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
+                                             "unpinned); results equal to the GPU's" % n_cpu}}))

@@ -99,8 +99,19 @@ def test_extract_spanning_reads():
             reads.append(s)
             truth.append((kind, copies))
         spanning, lengths = vntr_finder.extract_spanning_reads(left, right, reads)
-        got = {idx: (seq, rev) for seq, idx, rev in spanning}
-        assert sorted(got) == [k for k, (kind, _) in enumerate(truth) if kind in (0, 1)]
+        # the same decisions from the CPU restatement, read by read and strand by strand
+        want, want_len = [], []
+        for idx, s in enumerate(reads):
+            for rev, strand in ((False, s.upper()), (True, vntr_finder.reverse_complement(s.upper()))):
+                ls, lb, _ = O.flank_align(strand, left[-100:])
+                rs, rb, _ = O.flank_align(strand, right[:100])
+                if ls >= 70 and rs >= 70 and rb >= lb:
+                    want.append((strand[lb:rb + 100], idx, rev))
+                    want_len.append(rb - (lb + 100))
+        assert spanning == want and lengths == want_len
+        found = {idx for _, idx, _ in spanning}
+        planted = [k for k, (kind, _) in enumerate(truth) if kind in (0, 1)]
+        assert found <= set(planted) and len(found) >= 8            # 10 % noise puts a few flanks under the 0.7 threshold
         for (seq, idx, rev), ln in zip(spanning, lengths):
             kind, copies = truth[idx]
             assert rev == (kind == 1)
@@ -108,3 +119,29 @@ def test_extract_spanning_reads():
             assert abs(len(seq) - (ln + 200)) <= 1
     finally:
         settings.MAX_ERROR_RATE = 0.05
+
+
+@pytest.mark.gpu
+def test_cli_pacbio_from_whole_long_reads(tmp_path):
+    """--pacbio --extract-spanning: whole long reads in, spanning reads found and trimmed on the GPU, RU genotype out."""
+    import json
+    import subprocess
+    import sys
+    from advntr_amd import workloads, vntr_finder
+    from conftest import ROOT
+    rng = np.random.default_rng(5150)
+    left, right, pattern = workloads.rand_seq(rng, 300), workloads.rand_seq(rng, 300), workloads.rand_seq(rng, 25)
+    reads = []
+    for k in range(24):
+        copies = 6 if k % 2 else 9
+        s = workloads.rand_seq(rng, int(rng.integers(500, 2000))) + workloads.noisy_copy(rng, left + pattern * copies + right, 0.05) + \\
+            workloads.rand_seq(rng, int(rng.integers(500, 2000)))
+        reads.append(s if k % 3 else vntr_finder.reverse_complement(s))
+    reads += [workloads.rand_seq(rng, 3000) for _ in range(6)]
+    loci = [{"id": 9, "left": left, "right": right, "pattern": pattern, "repeat_segments": [pattern], "scaled_score": None}]
+    (tmp_path / "loci.json").write_text(json.dumps(loci))
+    (tmp_path / "reads.fa").write_text("".join(">r%d\\n%s\\n" % (i, s) for i, s in enumerate(reads)))
+    out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"), "--reads",
+                          str(tmp_path / "reads.fa"), "--pacbio", "--extract-spanning"], cwd=ROOT, stdout=subprocess.PIPE,
+                         check=True).stdout.decode()
+    assert out == "9\\n6/9\\n"
