@@ -134,14 +134,14 @@ def test_cli_pacbio_from_whole_long_reads(tmp_path):
     reads = []
     for k in range(24):
         copies = 6 if k % 2 else 9
-        s = workloads.rand_seq(rng, int(rng.integers(500, 2000))) + workloads.noisy_copy(rng, left + pattern * copies + right, 0.05) + \\
+        s = workloads.rand_seq(rng, int(rng.integers(500, 2000))) + workloads.noisy_copy(rng, left + pattern * copies + right, 0.05) + \
             workloads.rand_seq(rng, int(rng.integers(500, 2000)))
         reads.append(s if k % 3 else vntr_finder.reverse_complement(s))
     reads += [workloads.rand_seq(rng, 3000) for _ in range(6)]
     loci = [{"id": 9, "left": left, "right": right, "pattern": pattern, "repeat_segments": [pattern], "scaled_score": None}]
     (tmp_path / "loci.json").write_text(json.dumps(loci))
-    (tmp_path / "reads.fa").write_text("".join(">r%d\\n%s\\n" % (i, s) for i, s in enumerate(reads)))
+    (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
     out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"), "--reads",
                           str(tmp_path / "reads.fa"), "--pacbio", "--extract-spanning"], cwd=ROOT, stdout=subprocess.PIPE,
                          check=True).stdout.decode()
-    assert out == "9\\n6/9\\n"
+    assert out == "9\n6/9\n"
