@@ -4,7 +4,8 @@ alignment streams its read once: n bytes), CPU restatement on a bounded sample.
     python scripts/flank_align_bench.py [n_reads]"""
 import json, sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 e.build()
 from advntr_amd import _lib, workloads, vntr_finder
