@@ -104,10 +104,11 @@ def get_suffix_matcher_hmm(pattern):
 # ------------------------------------------------------------------------------------------------
 def get_constant_number_of_repeats_matcher_hmm(patterns, copies, vpaths=None):
     model = Model(name="Repeating Pattern Matcher HMM Model")
-    if vpaths:
-        raise NotImplementedError("re-estimation from observed Viterbi paths (hmm_utils.py:428-430) is only used by "
-                                  "the reference's iterative model update, which is out of scope (DESIGN.md)")
-    transitions, emissions = build_profile_hmm_for_repeats(patterns, settings.MAX_ERROR_RATE)
+    if vpaths:          # re-estimation from observed paths (hmm_utils.py:427-429): the units the paths cut out of the reads,
+        alignment = get_multiple_alignment_of_repeats_from_reads(vpaths)     # aligned column-wise by profile position
+        transitions, emissions = build_profile_hmm_pseudocounts_for_alignment(settings.MAX_ERROR_RATE, alignment)
+    else:
+        transitions, emissions = build_profile_hmm_for_repeats(patterns, settings.MAX_ERROR_RATE)
     L = len([k for k in emissions.keys() if k.startswith('M')])
     add = model.add_transition
     last_end = None
@@ -196,8 +197,10 @@ def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns
     """hmm_utils.py:553-595.  native=True (default) builds the model in the library's C++ builder
     (csrc/model_builder.h, ~1 ms); native=False assembles it call by call through advntr_amd.pomegranate, the way the
     reference does through its pomegranate (~50 ms).  Both give the same arrays (tests/test_native_builder.py)."""
-    if native and not vpaths:
-        return build_read_matcher_models([(left_flanking_region, right_flanking_region, patterns, copies)],
+    if native:
+        # with vpaths the aligned repeat units come from the paths (hmm_utils.py:427-429) instead of `patterns`
+        rows = get_multiple_alignment_of_repeats_from_reads(vpaths) if vpaths else patterns
+        return build_read_matcher_models([(left_flanking_region, right_flanking_region, rows, copies)],
                                          threads=1, exp=exp)[0]
     return _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies, vpaths)
 

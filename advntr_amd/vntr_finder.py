@@ -590,3 +590,26 @@ def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, f
 
 
 _COMP_STR = str.maketrans("ACGTN", "TGCAN")
+
+
+# ------------------------------------------------------------------------------------------------
+# Model update from the sample's own reads (vntr_finder.py:667-697, the `update` mode of genotyping)
+# ------------------------------------------------------------------------------------------------
+def update_model_from_reads(model, left_flanking_region, right_flanking_region, repeat_segments, pattern, selected_sequences,
+                            read_length=None):
+    """One re-estimation step of VNTRFinder.iteratively_update_model: the selected reads and the reference repeat units
+    are scored with PATH output, the repeat units their paths cut out are aligned by profile position and a new
+    read-matcher model is built from that alignment (hmm_utils.py:424-431).  The reference wraps this in a loop of up
+    to 1000 steps that stops when the fitness improves by less than 1 -- and computes the fitness from the unchanged
+    first selection (vntr_finder.py:692), so the loop always ends after this one step; re-selecting reads with the
+    returned model (score_reads) is what the caller does next, as select_illumina_reads(..., hmm) does there."""
+    from .hmm_utils import get_read_matcher_model
+    selected_sequences = [s.upper() for s in selected_sequences]
+    read_length = read_length or len(selected_sequences[0])
+    sequences = selected_sequences + [str(r).upper() for r in repeat_segments]
+    logp, _, paths = model.viterbi_batch(sequences, want_paths=True, want_summary=False)
+    states = model.states
+    vpaths = [(seq, [(i, states[i]) for i in path]) for seq, path in zip(sequences, paths) if path is not None]
+    copies = get_copies_for_hmm(read_length, len(pattern))
+    return get_read_matcher_model(left_flanking_region[-read_length:], right_flanking_region[:read_length], None, copies,
+                                  vpaths)

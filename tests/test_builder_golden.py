@@ -105,3 +105,24 @@ def test_reference_fixture_known_answers_host():
     assert hmm_utils.get_number_of_repeat_bp_matches_in_vpath(vpath) == a["repeat_bp"]
     assert hmm_utils.get_left_flanking_region_size_in_vpath(vpath) == a["left_bp"]
     assert hmm_utils.get_right_flanking_region_size_in_vpath(vpath) == a["right_bp"]
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["native", "stepwise"])
+def test_model_reestimated_from_viterbi_paths(native):
+    """get_read_matcher_model(left, right, None, copies, vpaths) (hmm_utils.py:424-431, the model update of
+    vntr_finder.py:667-697): the golden holds the (sequence, path) pairs the reference scored and the model it rebuilt
+    from them (tests/golden/make_update_golden.py)."""
+    from advntr_amd.pomegranate import State
+    from oracle.oracle import OracleModel
+    g = load_golden("model_update")
+    vpaths = [(seq, [(0, State(None, n)) for n in names]) for seq, names in g["vpaths"]]
+    assert hmm_utils.get_multiple_alignment_of_repeats_from_reads(vpaths) == g["alignment"]
+    m = hmm_utils.get_read_matcher_model(g["left"], g["right"], None, g["copies"], vpaths, native=native)
+    gm = g["model"]
+    assert [s.name for s in m.states] == gm["state_names"]
+    assert (m.silent_start, m.start_index, m.end_index) == (gm["silent_start"], gm["start_index"], gm["end_index"])
+    a = m.baked_arrays()
+    assert np.array_equal(a["emis_logp"], np.array([e["logp"] for e in gm["emissions"]]))
+    in_ptr, in_src, in_logp, _ = OracleModel.from_golden(g).csr()
+    assert np.array_equal(a["in_ptr"], in_ptr) and np.array_equal(a["in_src"], in_src)
+    _close(a["in_logp"], in_logp)

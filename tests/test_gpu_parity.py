@@ -676,3 +676,24 @@ def test_cli_sharded_over_two_ranks_equals_single_process(tmp_path):
     import re
     rows = lambda out: [l for l in re.sub(rb"\[Gloo\][^\n]*", b"", out).split(b"\n") if l]     # minus gloo's connection banner
     assert rows(multi) == rows(single)
+
+
+@pytest.mark.gpu
+def test_model_update_from_reads_equals_the_reference_model():
+    """vntr_finder.update_model_from_reads: the GPU's paths for the golden's reads give the alignment, and therefore the
+    re-estimated model, the reference produced (tests/golden/model_update.json.gz)."""
+    from advntr_amd import hmm_utils, vntr_finder
+    from oracle.oracle import OracleModel
+    g = load_golden("model_update")
+    n_ref = 4
+    seqs = [s for s, _ in g["vpaths"]]
+    pattern = seqs[-1]
+    model = hmm_utils.get_read_matcher_model(g["left"], g["right"], [pattern] * n_ref, g["copies"])
+    new = vntr_finder.update_model_from_reads(model, g["left"], g["right"], seqs[-n_ref:], pattern, seqs[:-n_ref], read_length=100)
+    gm = g["model"]
+    assert [s.name for s in new.states] == gm["state_names"]
+    a = new.baked_arrays()
+    in_ptr, in_src, in_logp, _ = OracleModel.from_golden(g).csr()
+    assert np.array_equal(a["in_ptr"], in_ptr) and np.array_equal(a["in_src"], in_src)
+    assert np.all(np.abs(a["in_logp"] - in_logp)[np.isfinite(in_logp)] <= 4 * np.spacing(np.abs(in_logp[np.isfinite(in_logp)])))
+    assert np.array_equal(a["emis_logp"], np.array([e["logp"] for e in gm["emissions"]]))
