@@ -7,7 +7,7 @@
 // values of the previous step (previous row), fetched with a wavefront shift (DPP wave_shr:1).  There
 // is no same-row serial chain left: the delete chain that serialises a row-major sweep runs ALONG the
 // step axis here.  Model parameters are staged once per workgroup in LDS as small class tables
-// (column_program.h); per step a lane reads its column's 16-B info word, the 96-B transition class and
+// (column_program.h); per step a lane reads its column's 16-B info word, the 88-B transition class and
 // two emission log-probs.  The arithmetic is the reference's, operation for operation:
 // (v + t) + e in fp64, candidates compared in the reference's in-edge order with strict '>'
 // (/root/reference/pomegranate/hmm.pyx:2026-2083), so scores and back-pointers are bit-identical.
@@ -15,8 +15,8 @@
 // Back-pointers: one byte per (row, column) cell = the outcomes of the cell's six comparisons (relax_bit), written
 // in diagonal-major order so that a chunk stores 64 consecutive bytes per step.  The last row's values are
 // also written to a small per-wave buffer from which the "tail" states (prefix_end_prefix, model end:
-// fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  Lane 0 then walks
-// the pointers back and the wave summarises the path (path_summary.h).
+// fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  The wave then walks the
+// pointers back cooperatively (col_traceback) and summarises the path (path_summary.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
