@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
         for (int k = 0; k < FA_K; ++k) {
             const int j = 64 * k + lane;
             b[k] = j < lf ? (int)flank[j] : 255;
+            if (b[k] == 4) b[k] = 5;                                   // a non-ACGT flank symbol matches nothing, not even a read's N
             H[k] = S[k] = dH[k] = dS[k] = best[k] = bS[k] = 0;
             bi[k] = -1;
             // read bases of steps 0 and 1 (row i = s - j; rows outside the read are masked below)
@@ -82,14 +83,17 @@ __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
                 const int lH = k == 0 ? fa_shr1(H[0], 0) : fa_shr1_from(H[k], H[k - 1]);
                 const int lS = k == 0 ? fa_shr1(S[0], 0) : fa_shr1_from(S[k], S[k - 1]);
                 const bool active = i >= 0 && i < n && j < lf;
-                const int m = (ai == b[k] && ai < 4) ? 1 : -1;
+                const int m = ai == b[k] ? 1 : -1;           // codes > 3 never compare equal (host: read N = 4, flank N = 5, pad = 255)
                 const int d = dH[k] + m, u = H[k] - 1, l = lH - 1;
                 int h = max(max(d, u), max(l, 0));
                 // the start the walk-back reaches: horizontal first, then diagonal (a diagonal step out of a cell whose
                 // score is not positive begins the alignment here), then vertical
                 int st = l == h ? lS : (d == h ? (dH[k] > 0 ? dS[k] : ((i << 8) | j)) : S[k]);
                 if (!active || h <= 0) { h = 0; st = 0; }
-                if (h > 0 && h >= best[k]) { best[k] = h; bi[k] = i; bS[k] = st; }   // later rows win ties
+                const bool upd = h > 0 && h >= best[k];                              // later rows win ties
+                best[k] = upd ? h : best[k];
+                bi[k] = upd ? i : bi[k];
+                bS[k] = upd ? st : bS[k];
                 dH[k] = lH;
                 dS[k] = lS;
                 nH[k] = h;
