@@ -22,10 +22,32 @@ import numpy as np
 
 
 def _read_fasta(path):
-    lines = open(path).read().split("\n")
-    if lines and lines[-1] == "":
-        lines.pop()
-    return [lines[k][1:] for k in range(0, len(lines) - 1, 2)], [lines[k + 1] for k in range(0, len(lines) - 1, 2)]
+    """Names and sequences of a FASTA file (sequence lines may be wrapped) or a four-line FASTQ file."""
+    names, seqs = [], []
+    with open(path) as fh:
+        first = fh.readline()
+        if first.startswith("@"):                                   # FASTQ: name, sequence, '+', qualities
+            line = first
+            while line:
+                names.append(line[1:].rstrip("\n"))
+                seqs.append(fh.readline().rstrip("\n"))
+                fh.readline()
+                fh.readline()
+                line = fh.readline()
+            return names, seqs
+        chunks = None
+        for line in [first] + fh.readlines():
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if chunks is not None:
+                    seqs.append("".join(chunks))
+                names.append(line[1:])
+                chunks = []
+            elif chunks is not None and line:
+                chunks.append(line)
+        if chunks is not None:
+            seqs.append("".join(chunks))
+    return names, seqs
 
 
 def genotype(args):
