@@ -1,0 +1,85 @@
+// column_launch.h -- host side of the column-kernel launches (bucketed, stream, forward).
+#pragma once
+#include "viterbi_columns.h"
+#include "forward_columns.h"
+#include "viterbi_columns_stream.h"
+
+// ------------------------------------------------------------------------------------------------
+// host side of the launch
+// ------------------------------------------------------------------------------------------------
+struct ColumnLaunch {
+    int grid = 0;
+    int waves_per_block = COL_WAVES;
+    int nc_max = 0;
+    int sink_stride = COL_MAX_READ + 1;
+    size_t lds_bytes = 0;
+    int lds_level = 2;
+    int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
+    bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
+    int ring = 2;
+    std::vector<ColTile> tiles[5];          // per chunk count K = 1..4, [4] = row-tiled long reads
+    ColTile *d_tiles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_tile_counters = nullptr;     // 5 counters
+    double *d_rown = nullptr;
+    int32_t *d_aux = nullptr;
+    uint8_t *d_bp = nullptr;
+};
+
+template <int K, bool LONG>
+static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+{
+    const int slot = LONG ? 4 : K - 1;
+    if (cl.tiles[slot].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
+    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
+    g.sink_stride = cl.sink_stride;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+}
+
+template <int K>
+static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+{
+    if (cl.tiles[0].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[0];
+    g.n_tiles = (int32_t)cl.tiles[0].size();
+    g.tile_counter = cl.d_tile_counters;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
+    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
+    g.sink_stride = cl.sink_stride;
+    g.ring = cl.ring;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
+    hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
+}
+
+template <int K, bool LONG>
+static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream)
+{
+    const int slot = LONG ? 4 : K - 1;
+    if (cl.tiles[slot].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g);
+}
+

@@ -18,6 +18,7 @@
 #include "column_program.h"
 #include "viterbi_generic.h"
 #include "viterbi_columns.h"
+#include "column_launch.h"
 #include "forward_generic.h"
 #include "keyword_filter.h"
 #include "model_builder.h"

@@ -762,328 +762,3 @@ viterbi_columns_kernel(ColArgs g, uint32_t flags)
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Sum-product (Model.log_probability) on the column program: the same sweep with pair_lse instead of max, no
-// back-pointers, no traceback.  Tail states: fold over the emitting-sourced in-edges, fold over the silent-sourced
-// ones, lse of the two (hmm.pyx:1446-1480), wave-parallel (the fold order inside each group differs from the
-// reference's, so results agree to rounding; tests allow 1e-9 relative, the north star 1e-4).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double col_tail_forward(const ColProgram *__restrict__ cp, double *__restrict__ rown, const int NC,
-                                                   const int lane)
-{
-    const uint8_t *base = (const uint8_t *)cp;
-    const int32_t *tptr = (const int32_t *)(base + cp->off_tail_ptr);
-    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
-    double *tailv = rown + 3 * NC;
-    double result = -INFINITY;
-    for (int i = 0; i < cp->n_tail; ++i) {
-        double pe = -INFINITY, ps = -INFINITY;
-        for (int e = tptr[i] + lane; e < tptr[i + 1]; e += 64) {
-            const TailEdge ed = edges[e];
-            if (ed.loc >= 0) {
-                const double v = rown[(ed.loc >> 2) * 3 + (ed.loc & 3)] + ed.logp;
-                if ((ed.loc & 3) < 2) pe = lse2(pe, v); else ps = lse2(ps, v);
-            } else {
-                ps = lse2(ps, tailv[-ed.loc - 1] + ed.logp);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            pe = lse2(pe, __shfl_xor(pe, o, 64));
-            ps = lse2(ps, __shfl_xor(ps, o, 64));
-        }
-        const double v = lse2(pe, ps);
-        if (lane == 0) tailv[i] = v;
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        if (i == cp->end_tail) result = v;
-    }
-    return result;
-}
-
-template <int K, bool LONG>
-__global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int TPAD = 64 * K;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
-    int32_t *tile_slot = (int32_t *)lds;
-    uint8_t *tables = lds + 16;
-    double *rown = g.rown + gw * g.rown_stride;
-    int cur_model = -1;
-    bool padded = false;
-    LdsTables L{};
-    const ColProgram *cp = nullptr;
-    DevModel M{};
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
-        __syncthreads();
-        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);    // wave-uniform => scalar loop bounds downstream
-        if (ti >= g.n_tiles) break;
-        const ColTile tile = g.tiles[ti];
-        if (tile.model != cur_model) {
-            cur_model = tile.model;
-            M = g.a.models[cur_model];
-            cp = M.cols;
-            padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
-        }
-        const int NC = cp->n_cols;
-        for (int j = wave; j < tile.count; j += COL_WAVES) {
-            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
-            const uint8_t *seq = g.a.bases + g.a.read_off[r];
-            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
-            TileCtx C;
-            C.NC = NC; C.sink_stride = 0; C.sinkbp = nullptr; C.bp = nullptr;
-            C.fwd = (const double *)((const uint8_t *)cp + cp->off_fwd);
-            double *final_row = rown;
-            if (!LONG) {
-                C.n_tile = n; C.row0 = 0; C.cap = rown; C.seam = nullptr;
-                col_sweep<K, 0, true>(L, padded, C, seq, lane);
-            } else {
-                double *buf[2] = {rown, rown + 3 * (int64_t)NC + COL_MAX_TAIL};
-                const int n_tiles = (n + TPAD - 1) / TPAD;
-                for (int i = 0; i < n_tiles; ++i) {
-                    C.row0 = i * TPAD;
-                    C.n_tile = min(TPAD, n - C.row0);
-                    C.cap = buf[(i + 1) & 1];
-                    C.seam = buf[i & 1];
-                    if (i == 0) col_sweep<K, 0, true>(L, padded, C, seq, lane);
-                    else col_sweep<K, 1, true>(L, padded, C, seq + i * TPAD, lane);
-                    __threadfence_block();
-                    __builtin_amdgcn_wave_barrier();
-                }
-                final_row = buf[n_tiles & 1];
-            }
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
-            const double logp = col_tail_forward(cp, final_row, NC, lane);
-            if (lane == 0) g.a.out_logp[r] = logp;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Stream kernel: a wavefront packs its reads back to back along the row axis and sweeps the stream in row
-// tiles of 64*K rows, so every lane carries a useful row (a 150-base read otherwise fills 150 of 192 lanes).
-// Read boundaries inside a tile are per-lane flags (first row: previous row := the model's row 0, entry edges
-// live; last row: captured for the tail states); a read that straddles two tiles continues through the seam
-// row exactly like a long read.  Back-pointer slabs form a ring so a straddling read can still be traced back.
-// ------------------------------------------------------------------------------------------------
-#ifndef COL_STREAM_WAVES_PER_SIMD
-#define COL_STREAM_WAVES_PER_SIMD 4
-#endif
-#define COL_STREAM_K 3           // chunks per row tile of the stream kernel (192 rows)
-#define COL_STREAM_READS 16      // reads per wavefront per tile of work
-#define COL_STREAM_CAPS 4        // reads that may END inside one row tile (capture buffers)
-
-struct StreamRead {
-    int32_t r, n, U, pad;        // read index, length, stream row of its first base
-};
-
-template <int K>
-__global__ void __launch_bounds__(COL_WAVES * 64, COL_STREAM_WAVES_PER_SIMD)
-viterbi_columns_stream_kernel(ColArgs g, uint32_t flags)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int TPAD = 64 * K;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
-    int32_t *tile_slot = (int32_t *)lds;
-    uint8_t *tables = lds + 16;
-    StreamRead *mine = (StreamRead *)(lds + 16 + g.lds_tables) + wave * COL_STREAM_READS;
-    uint8_t *bp = g.bp + gw * g.bp_stride;
-    double *rbase = g.rown + gw * g.rown_stride;
-    int32_t *aux = g.aux + gw * g.aux_stride;
-    int32_t *tailwin = aux, *sinkbp = aux + COL_MAX_TAIL;
-    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
-    const int ring = g.ring, W = g.ring * TPAD;
-    int cur_model = -1;
-    bool padded = false;
-    LdsTables L{};
-    const ColProgram *cp = nullptr;
-    DevModel M{};
-
-    for (;;) {
-        __syncthreads();
-        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
-        __syncthreads();
-        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);    // wave-uniform => scalar loop bounds downstream
-        if (ti >= g.n_tiles) break;
-        const ColTile tile = g.tiles[ti];
-        if (tile.model != cur_model) {
-            cur_model = tile.model;
-            M = g.a.models[cur_model];
-            cp = M.cols;
-            padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
-        }
-        const int NC = cp->n_cols;
-        const int64_t slab = (int64_t)(TPAD + NC) * TPAD;
-        const int64_t cap_stride = 3 * (int64_t)NC + COL_MAX_TAIL;
-        double *seam_buf[2] = {rbase, rbase + 3 * (int64_t)NC};
-        double *capbuf = rbase + 6 * (int64_t)NC;
-
-        // ---- lay this wave's reads out along the stream (wave-uniform arithmetic, lane 0 writes LDS)
-        int nr = 0, U = 0, last_te = -1, cnt = 0;
-        for (int j = wave; j < tile.count && nr < COL_STREAM_READS; j += COL_WAVES) {
-            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
-            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
-            int te = (U + n - 1) / TPAD;
-            if (te == last_te && cnt >= COL_STREAM_CAPS) {          // too many reads would end in that tile
-                U = (te + 1) * TPAD;
-                te = (U + n - 1) / TPAD;
-            }
-            if (te != last_te) { last_te = te; cnt = 0; }
-            ++cnt;
-            if (lane == 0) mine[nr] = StreamRead{r, n, U, 0};
-            U += n;
-            ++nr;
-        }
-        const int Utot = U;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-
-        const int n_tiles = (Utot + TPAD - 1) / TPAD;
-        for (int i = 0; i < n_tiles; ++i) {
-            const int u0 = i * TPAD;
-            int slot_x[K], slot_flag[K];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { slot_x[k] = 0; slot_flag[k] = 0; }
-            int ends[COL_STREAM_CAPS];
-#pragma unroll
-            for (int e = 0; e < COL_STREAM_CAPS; ++e) ends[e] = -1;
-            int ncap = 0;
-            for (int q = 0; q < nr; ++q) {
-                const StreamRead rd = mine[q];
-                const int rU = __builtin_amdgcn_readfirstlane(rd.U), rn = __builtin_amdgcn_readfirstlane(rd.n);
-                const int e = rU + rn - 1;
-                if (e < u0 || rU >= u0 + TPAD) continue;
-                const bool ends_here = e < u0 + TPAD;
-                const uint8_t *seq = g.a.bases + g.a.read_off[__builtin_amdgcn_readfirstlane(rd.r)];
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const int u = u0 + 64 * k + lane;
-                    if (u >= rU && u <= e) {
-                        slot_x[k] = seq[u - rU];
-                        slot_flag[k] = (u == rU ? 1 : 0) | (u == e ? 2 : 0) | (ncap << 8);
-                    }
-                }
-                if (ends_here) {
-#pragma unroll
-                    for (int c2 = 0; c2 < COL_STREAM_CAPS; ++c2)
-                        if (c2 == ncap) ends[c2] = q;
-                    ++ncap;
-                }
-            }
-            unsigned hasfirst = 0, haslast = 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (__ballot(slot_flag[k] & 1)) hasfirst |= 1u << k;
-                if (__ballot(slot_flag[k] & 2)) haslast |= 1u << k;
-            }
-            TileCtx C;
-            C.NC = NC; C.sink_stride = g.sink_stride; C.sinkbp = sinkbp;
-            C.n_tile = min(TPAD, Utot - u0);
-            C.row0 = u0 % W;
-            C.bp = bp + (i % ring) * slab;
-            C.cap = capbuf; C.cap_stride = cap_stride;
-            C.seam = seam_buf[i & 1]; C.seam_out = seam_buf[(i + 1) & 1];
-            C.hasfirst = hasfirst; C.haslast = haslast;
-            col_sweep<K, 2>(L, padded, C, nullptr, lane, slot_x, slot_flag);
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < COL_STREAM_CAPS; ++e) {
-                if (ends[e] < 0) continue;
-                const StreamRead rd = mine[ends[e]];
-                const int r = __builtin_amdgcn_readfirstlane(rd.r), n = __builtin_amdgcn_readfirstlane(rd.n);
-                const uint8_t *seq = g.a.bases + g.a.read_off[r];
-                col_finish_read<K>(g, flags, cp, L, M, r, seq, n, capbuf + e * cap_stride, bp, slab, tailwin, sinkbp, rev,
-                                   lane, __builtin_amdgcn_readfirstlane(rd.U), ring, W);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// host side of the launch
-// ------------------------------------------------------------------------------------------------
-struct ColumnLaunch {
-    int grid = 0;
-    int waves_per_block = COL_WAVES;
-    int nc_max = 0;
-    int sink_stride = COL_MAX_READ + 1;
-    size_t lds_bytes = 0;
-    int lds_level = 2;
-    int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
-    bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
-    int ring = 2;
-    std::vector<ColTile> tiles[5];          // per chunk count K = 1..4, [4] = row-tiled long reads
-    ColTile *d_tiles[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int32_t *d_tile_counters = nullptr;     // 5 counters
-    double *d_rown = nullptr;
-    int32_t *d_aux = nullptr;
-    uint8_t *d_bp = nullptr;
-};
-
-template <int K, bool LONG>
-static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
-{
-    const int slot = LONG ? 4 : K - 1;
-    if (cl.tiles[slot].empty()) return;
-    ColArgs g{};
-    g.a = a;
-    g.tiles = cl.d_tiles[slot];
-    g.n_tiles = (int32_t)cl.tiles[slot].size();
-    g.tile_counter = cl.d_tile_counters + slot;
-    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
-    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
-    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
-    g.lds_tables = (int32_t)cl.lds_bytes;
-    g.lds_level = cl.lds_level;
-    g.sink_stride = cl.sink_stride;
-    const int grid = std::min(cl.grid, g.n_tiles);
-    hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
-}
-
-template <int K>
-static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
-{
-    if (cl.tiles[0].empty()) return;
-    ColArgs g{};
-    g.a = a;
-    g.tiles = cl.d_tiles[0];
-    g.n_tiles = (int32_t)cl.tiles[0].size();
-    g.tile_counter = cl.d_tile_counters;
-    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
-    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
-    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
-    g.lds_tables = (int32_t)cl.lds_bytes;
-    g.lds_level = cl.lds_level;
-    g.sink_stride = cl.sink_stride;
-    g.ring = cl.ring;
-    const int grid = std::min(cl.grid, g.n_tiles);
-    const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
-    hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
-}
-
-template <int K, bool LONG>
-static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream)
-{
-    const int slot = LONG ? 4 : K - 1;
-    if (cl.tiles[slot].empty()) return;
-    ColArgs g{};
-    g.a = a;
-    g.tiles = cl.d_tiles[slot];
-    g.n_tiles = (int32_t)cl.tiles[slot].size();
-    g.tile_counter = cl.d_tile_counters + slot;
-    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
-    g.lds_tables = (int32_t)cl.lds_bytes;
-    g.lds_level = cl.lds_level;
-    const int grid = std::min(cl.grid, g.n_tiles);
-    hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g);
-}
