@@ -1,0 +1,71 @@
+// abi_flank_align.h -- C-ABI entry point of the flank alignment (advntr_flank_align)
+// Included by engine.hip (same translation unit: uses its error helpers, device caches and HIP_TRY).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Flank alignment (flank_align.h) behind the C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_reads, const uint8_t *flank_bases,
+                                  const int32_t *flank_off, int32_t n_flanks, const int32_t *pair_read, const int32_t *pair_flank,
+                                  int32_t n_pairs, int32_t *out_score, int32_t *out_begin, int32_t *out_end, float *kernel_ms)
+{
+    if (n_reads < 0 || n_flanks < 0 || n_pairs < 0 || !read_off || !flank_off ||
+        (n_pairs && (!pair_read || !pair_flank || !out_score || !out_begin || !out_end)))
+        return fail(ADVNTR_ERR_ARG, "advntr_flank_align: bad argument");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_pairs == 0) return ADVNTR_OK;
+    for (int f = 0; f < n_flanks; ++f)
+        if (flank_off[f + 1] - flank_off[f] < 0 || flank_off[f + 1] - flank_off[f] > 64 * FA_K)
+            return fail(ADVNTR_ERR_TOO_LARGE, "advntr_flank_align: flank %d has %d bases (limit %d)", f,
+                        flank_off[f + 1] - flank_off[f], 64 * FA_K);
+    for (int p = 0; p < n_pairs; ++p)
+        if (pair_read[p] < 0 || pair_read[p] >= n_reads || pair_flank[p] < 0 || pair_flank[p] >= n_flanks)
+            return fail(ADVNTR_ERR_ARG, "advntr_flank_align: pair %d out of range", p);
+    const int64_t total = read_off[n_reads];
+    const int32_t ftotal = flank_off[n_flanks];
+    const int dev = current_device();
+    void *d_bases = nullptr, *d_off = nullptr, *d_fb = nullptr, *d_fo = nullptr, *d_pr = nullptr, *d_pf = nullptr, *d_out = nullptr;
+    hipEvent_t e0 = g_cache.get_event(dev), e1 = g_cache.get_event(dev);
+    auto cleanup = [&]() {
+        for (void *q : {d_bases, d_off, d_fb, d_fo, d_pr, d_pf, d_out}) (void)hipFree(q);
+        if (e0) g_cache.put_event(dev, e0);
+        if (e1) g_cache.put_event(dev, e1);
+    };
+    int rc = [&]() -> int {
+        if (!e0 || !e1) return fail(ADVNTR_ERR_DEVICE, "advntr_flank_align: event creation failed");
+        HIP_TRY(hipMalloc(&d_bases, (size_t)total + 16));
+        HIP_TRY(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
+        HIP_TRY(hipMalloc(&d_fb, (size_t)ftotal + 16));
+        HIP_TRY(hipMalloc(&d_fo, ((size_t)n_flanks + 1) * 4));
+        HIP_TRY(hipMalloc(&d_pr, (size_t)n_pairs * 4));
+        HIP_TRY(hipMalloc(&d_pf, (size_t)n_pairs * 4));
+        HIP_TRY(hipMalloc(&d_out, (size_t)n_pairs * 12));
+        if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+        if (ftotal) HIP_TRY(hipMemcpy(d_fb, flank_bases, (size_t)ftotal, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_fo, flank_off, ((size_t)n_flanks + 1) * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_pr, pair_read, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_pf, pair_flank, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+        FaArgs a{};
+        a.bases = (const uint8_t *)d_bases; a.read_off = (const int64_t *)d_off;
+        a.flank_bases = (const uint8_t *)d_fb; a.flank_off = (const int32_t *)d_fo;
+        a.pair_read = (const int32_t *)d_pr; a.pair_flank = (const int32_t *)d_pf; a.n_pairs = n_pairs;
+        a.out_score = (int32_t *)d_out; a.out_begin = a.out_score + n_pairs; a.out_end = a.out_begin + n_pairs;
+        const int grid = std::max(1, std::min((n_pairs + FA_WAVES - 1) / FA_WAVES, device_cus() * 4));
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(flank_align_kernel, dim3(grid), dim3(FA_WAVES * 64), 0, nullptr, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
+        HIP_TRY(hipMemcpy(out_score, a.out_score, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_begin, a.out_begin, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_end, a.out_end, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+        return ADVNTR_OK;
+    }();
+    std::string keep = g_err;
+    cleanup();
+    g_err = keep;
+    return rc;
+}
+

@@ -1,0 +1,189 @@
+// abi_model_builder.h -- C-ABI entry points of the native model builder and of the bulk model upload (advntr_build_read_matchers, advntr_built_*, advntr_align_repeats)
+// Included by engine.hip (same translation unit: uses its error helpers, device caches and HIP_TRY).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Native model builder (model_builder.h) behind the C ABI
+// ------------------------------------------------------------------------------------------------
+struct advntr_built {
+    mb::Built b;
+};
+
+// Host threads for the per-locus jobs (model build, table preparation).  These jobs are allocation-heavy (thousands of
+// small vectors and strings per locus); measured on a 256-thread host, 6 719 loci: 32 threads 0.31-0.37 s for the
+// build and 0.30 s for the upload preparation, 256 threads 0.65 s and 1.3 s (allocator contention) -- hence the cap.
+static int default_host_threads() { return (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())); }
+
+extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
+                                          const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
+                                          double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
+                                          uint32_t flags, advntr_built **out)
+{
+    if (n_loci < 0 || (n_loci && (!left_flank || !right_flank || !repeats || !repeat_off || !copies || !out)))
+        return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: bad argument");
+    for (int i = 0; i < n_loci; ++i) out[i] = nullptr;
+    if (n_threads <= 0) n_threads = default_host_threads();
+    n_threads = std::min<int>(n_threads, std::max(1, n_loci));
+
+    struct Shared {
+        std::mutex exp_mu, err_mu;
+        advntr_exp_fn fn;
+        void *user;
+        int first_bad = -1;
+        std::string msg;
+    } sh;
+    sh.fn = exp_fn;
+    sh.user = user;
+    // serialise the caller's exp (a Python callback holds the interpreter lock anyway)
+    auto locked_exp = [](const double *in, double *o, int64_t n, void *u) {
+        Shared *s = (Shared *)u;
+        std::lock_guard<std::mutex> lk(s->exp_mu);
+        s->fn(in, o, n, s->user);
+    };
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_loci) return;
+            try {
+                if (!left_flank[i] || !right_flank[i]) throw std::invalid_argument("null flanking region");
+                std::vector<std::string> rows;
+                for (int r = repeat_off[i]; r < repeat_off[i + 1]; ++r) rows.emplace_back(repeats[r] ? repeats[r] : "");
+                if (flags & ADVNTR_BUILD_ALIGN_REPEATS) {
+                    bool ragged = false;
+                    for (const std::string &r : rows) ragged |= r.size() != rows[0].size();
+                    if (ragged) rows = msa::align_units(rows);
+                }
+                advntr_built *B = new advntr_built;
+                B->b = mb::build_read_matcher(left_flank[i], right_flank[i], rows, copies[i], max_error_rate,
+                                              exp_fn ? (mb::ExpFn)locked_exp : nullptr, &sh);
+                out[i] = B;
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lk(sh.err_mu);
+                if (sh.first_bad < 0 || i < sh.first_bad) { sh.first_bad = i; sh.msg = e.what(); }
+            }
+        }
+    };
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    if (sh.first_bad >= 0) return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: locus %d: %s", sh.first_bad, sh.msg.c_str());
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_built_info(const advntr_built *B, int32_t *info)
+{
+    if (!B || !info) return fail(ADVNTR_ERR_ARG, "advntr_built_info: null argument");
+    info[0] = B->b.m; info[1] = B->b.silent_start; info[2] = B->b.start_index; info[3] = B->b.end_index;
+    info[4] = (int32_t)B->b.in_src.size(); info[5] = (int32_t)B->b.names.size();
+    return ADVNTR_OK;
+}
+
+extern "C" int advntr_built_export(const advntr_built *B, int32_t *in_ptr, int32_t *in_src, double *in_logp,
+                                   double *emis_logp, uint16_t *state_class, char *names)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_built_export: null model");
+    const mb::Built &b = B->b;
+    if (in_ptr) memcpy(in_ptr, b.in_ptr.data(), b.in_ptr.size() * sizeof(int32_t));
+    if (in_src) memcpy(in_src, b.in_src.data(), b.in_src.size() * sizeof(int32_t));
+    if (in_logp) memcpy(in_logp, b.in_logp.data(), b.in_logp.size() * sizeof(double));
+    if (emis_logp) memcpy(emis_logp, b.emis.data(), b.emis.size() * sizeof(double));
+    if (state_class) memcpy(state_class, b.state_class.data(), b.state_class.size() * sizeof(uint16_t));
+    if (names) memcpy(names, b.names.data(), b.names.size());
+    return ADVNTR_OK;
+}
+
+extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
+{
+    if (!B) { fail(ADVNTR_ERR_ARG, "advntr_built_upload: null model"); return nullptr; }
+    const mb::Built &b = B->b;
+    return advntr_hmm_create(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
+                             b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data());
+}
+
+extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out)
+{
+    if (n < 0 || (n && (!built || !out))) return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: bad argument");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    if (n == 0) return ADVNTR_OK;
+    if (n_threads <= 0) n_threads = default_host_threads();
+    n_threads = std::min(n_threads, n);
+    std::mutex err_mu;
+    int first_bad = -1;
+    std::string msg;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            std::string err = "null model";
+            advntr_hmm *H = nullptr;
+            if (built[i]) {
+                const mb::Built &b = built[i]->b;
+                H = hmm_prepare(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
+                                b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data(), err);
+            }
+            if (H) out[i] = H;
+            else {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (first_bad < 0 || i < first_bad) { first_bad = i; msg = err; }
+            }
+        }
+    };
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    auto drop_all = [&]() {
+        for (int i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
+    };
+    if (first_bad >= 0) {
+        drop_all();
+        return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
+    }
+    // one slab, 256-B aligned sub-blobs, one copy
+    std::vector<size_t> at(n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { at[i] = total; total += (out[i]->blob_bytes + 255) & ~size_t(255); }
+    std::vector<uint8_t> staging(total);
+    for (int i = 0; i < n; ++i) memcpy(staging.data() + at[i], out[i]->host_blob.data(), out[i]->blob_bytes);
+    ModelSlab *slab = new ModelSlab;
+    if (hipMalloc(&slab->d, total) != hipSuccess || hipMemcpy(slab->d, staging.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+        if (slab->d) (void)hipFree(slab->d);
+        delete slab;
+        drop_all();
+        return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
+    }
+    slab->refs = n;
+    for (int i = 0; i < n; ++i) {
+        out[i]->slab = slab;
+        hmm_bind(out[i], (const uint8_t *)slab->d + at[i]);
+    }
+    return ADVNTR_OK;
+}
+
+extern "C" void advntr_built_destroy(advntr_built *B) { delete B; }
+
+extern "C" int advntr_align_repeats(const char *const *units, int32_t n, char *out, int64_t capacity, int32_t *width)
+{
+    if (n < 0 || (n && !units) || !width) return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: bad argument");
+    try {
+        std::vector<std::string> in;
+        for (int i = 0; i < n; ++i) in.emplace_back(units[i] ? units[i] : "");
+        const std::vector<std::string> rows = msa::align_units(in);
+        *width = rows.empty() ? 0 : (int32_t)rows[0].size();
+        if ((int64_t)n * *width > capacity || (n && !out))
+            return fail(ADVNTR_ERR_TOO_LARGE, "advntr_align_repeats: need %lld bytes", (long long)n * *width);
+        for (int i = 0; i < n; ++i) memcpy(out + (size_t)i * *width, rows[i].data(), (size_t)*width);
+    } catch (const std::exception &e) {
+        return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: %s", e.what());
+    }
+    return ADVNTR_OK;
+}
+
+

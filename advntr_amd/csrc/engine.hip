@@ -918,419 +918,6 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
     return rc;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Keyword prefilter
-// ------------------------------------------------------------------------------------------------
-struct advntr_kwfilter {
-    KwfDevice dev{};
-    std::vector<void *> allocs;
-    int64_t n_keys = 0;
-};
-
-extern "C" void advntr_kwfilter_destroy(advntr_kwfilter *F)
-{
-    if (!F) return;
-    for (void *p : F->allocs) (void)hipFree(p);
-    delete F;
-}
-
-extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, const int64_t *kw_off,
-                                                   const int32_t *kw_vntr, int32_t n_keywords)
-{
-    if (n_keywords < 0 || (n_keywords && (!kw_bases || !kw_off || !kw_vntr))) {
-        fail(ADVNTR_ERR_ARG, "advntr_kwfilter_create: bad argument");
-        return nullptr;
-    }
-    // group keyword strings: packed key -> owners (in keyword order)
-    std::map<uint64_t, std::vector<int32_t>> groups;
-    std::vector<int> lengths;
-    for (int w = 0; w < n_keywords; ++w) {
-        const int64_t L = kw_off[w + 1] - kw_off[w];
-        if (L < 1 || L > 29) {
-            fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: keyword %d has length %lld (supported: 1..29)", w, (long long)L);
-            return nullptr;
-        }
-        uint64_t key = 0;
-        for (int64_t i = kw_off[w]; i < kw_off[w + 1]; ++i) {
-            if (kw_bases[i] > 3) {
-                fail(ADVNTR_ERR_SYMBOL, "advntr_kwfilter_create: keyword %d holds a non-ACGT symbol", w);
-                return nullptr;
-            }
-            key = (key << 2) | kw_bases[i];
-        }
-        key |= (uint64_t)L << 58;
-        groups[key].push_back(kw_vntr[w]);
-        if (std::find(lengths.begin(), lengths.end(), (int)L) == lengths.end()) lengths.push_back((int)L);
-    }
-    if ((int)lengths.size() > KWF_MAX_LENGTHS) {
-        fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: %zu distinct keyword lengths (max %d)", lengths.size(), KWF_MAX_LENGTHS);
-        return nullptr;
-    }
-    std::sort(lengths.begin(), lengths.end());
-    size_t slots = 1024;
-    while (slots < groups.size() * 4) slots <<= 1;
-    std::vector<uint64_t> keys(slots, KWF_EMPTY);
-    std::vector<uint32_t> vals(slots, 0), bitset(KWF_BITSET_BITS / 32, 0);
-    size_t fp_slots = 4096;
-    while (fp_slots < groups.size() * 3 && fp_slots < (1u << 20)) fp_slots <<= 1;     // <= 2 MiB of uint16
-    std::vector<uint16_t> fps(fp_slots, 0);
-    std::vector<int32_t> ids;
-    for (auto &kv : groups) {
-        if (kv.second.size() > 255 || ids.size() > 0xffffffu) {
-            fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: keyword shared by more than 255 VNTRs");
-            return nullptr;
-        }
-        const uint64_t h = kwf_hash(kv.first);
-        const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
-        bitset[b >> 5] |= 1u << (b & 31);
-        const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
-        bitset[b2 >> 5] |= 1u << (b2 & 31);
-        size_t fs = kwf_fp_slot(h, (uint32_t)(fp_slots - 1));
-        while (fps[fs] != 0) fs = (fs + 1) & (fp_slots - 1);
-        fps[fs] = kwf_fp(h);
-        size_t s = (h & 0xffffffffull) & (slots - 1);
-        while (keys[s] != KWF_EMPTY) s = (s + 1) & (slots - 1);
-        keys[s] = kv.first;
-        vals[s] = (uint32_t)ids.size() | ((uint32_t)kv.second.size() << 24);
-        ids.insert(ids.end(), kv.second.begin(), kv.second.end());
-    }
-    advntr_kwfilter *F = new advntr_kwfilter();
-    F->n_keys = (int64_t)groups.size();
-    auto up = [&](const void *src, size_t bytes) -> void * {
-        void *d = nullptr;
-        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
-        F->allocs.push_back(d);
-        if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        return d;
-    };
-    void *dk = up(keys.data(), keys.size() * 8), *dv = up(vals.data(), vals.size() * 4);
-    void *di = up(ids.data(), ids.size() * 4), *db = up(bitset.data(), bitset.size() * 4);
-    void *df = up(fps.data(), fps.size() * 2);
-    if (!dk || !dv || !di || !db || !df) {
-        fail(ADVNTR_ERR_DEVICE, "advntr_kwfilter_create: device upload failed");
-        advntr_kwfilter_destroy(F);
-        return nullptr;
-    }
-    KwfDevice &D = F->dev;
-    D.n_lengths = (int32_t)lengths.size();
-    for (size_t i = 0; i < lengths.size(); ++i) {
-        D.length[i] = lengths[i];
-        D.mask[i] = lengths[i] >= 32 ? ~0ull : ((1ull << (2 * lengths[i])) - 1ull);
-    }
-    D.table_mask = slots - 1;
-    D.keys = (const uint64_t *)dk; D.vals = (const uint32_t *)dv; D.ids = (const int32_t *)di; D.bitset = (const uint32_t *)db;
-    D.fps = (const uint16_t *)df; D.fp_mask = (uint32_t)(fp_slots - 1);
-    return F;
-}
-
-extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, const int64_t *read_off, int32_t n_reads,
-                                    int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity,
-                                    int64_t *n_out, float *kernel_ms)
-{
-    if (!F || !read_off || n_reads < 0 || !n_out || capacity < 0 || (capacity && (!out_read || !out_vntr || !out_count)))
-        return fail(ADVNTR_ERR_ARG, "advntr_kwfilter_scan: bad argument");
-    *n_out = 0;
-    if (n_reads == 0) return ADVNTR_OK;
-    const int64_t total = read_off[n_reads];
-    uint8_t *d_bases = nullptr;
-    int64_t *d_off = nullptr;
-    int32_t *d_r = nullptr, *d_v = nullptr, *d_c = nullptr;
-    unsigned long long *d_n = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_bases); (void)hipFree(d_off); (void)hipFree(d_r); (void)hipFree(d_v); (void)hipFree(d_c); (void)hipFree(d_n);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    };
-    int rc = [&]() -> int {
-        HIP_TRY(hipMalloc(&d_bases, (size_t)total + 16));
-        HIP_TRY(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
-        HIP_TRY(hipMalloc(&d_r, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_v, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_c, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_n, 8));
-        HIP_TRY(hipMemset(d_n, 0, 8));
-        if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        KwfArgs a{};
-        a.f = F->dev; a.bases = d_bases; a.read_off = d_off; a.n_reads = n_reads;
-        a.out_read = d_r; a.out_vntr = d_v; a.out_count = d_c; a.n_out = d_n; a.capacity = capacity;
-        const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus()));
-        HIP_TRY(hipFuncSetAttribute((const void *)keyword_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
-        unsigned long long n = 0;
-        HIP_TRY(hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
-        *n_out = (int64_t)n;
-        if ((int64_t)n > capacity) return fail(ADVNTR_ERR_TOO_LARGE, "advntr_kwfilter_scan: %llu records, capacity %lld", n, (long long)capacity);
-        if (n) {
-            HIP_TRY(hipMemcpy(out_read, d_r, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(out_vntr, d_v, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(out_count, d_c, n * 4, hipMemcpyDeviceToHost));
-        }
-        return ADVNTR_OK;
-    }();
-    std::string keep = g_err;
-    cleanup();
-    g_err = keep;
-    return rc;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Native model builder (model_builder.h) behind the C ABI
-// ------------------------------------------------------------------------------------------------
-struct advntr_built {
-    mb::Built b;
-};
-
-// Host threads for the per-locus jobs (model build, table preparation).  These jobs are allocation-heavy (thousands of
-// small vectors and strings per locus); measured on a 256-thread host, 6 719 loci: 32 threads 0.31-0.37 s for the
-// build and 0.30 s for the upload preparation, 256 threads 0.65 s and 1.3 s (allocator contention) -- hence the cap.
-static int default_host_threads() { return (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency())); }
-
-extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
-                                          const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
-                                          double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
-                                          uint32_t flags, advntr_built **out)
-{
-    if (n_loci < 0 || (n_loci && (!left_flank || !right_flank || !repeats || !repeat_off || !copies || !out)))
-        return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: bad argument");
-    for (int i = 0; i < n_loci; ++i) out[i] = nullptr;
-    if (n_threads <= 0) n_threads = default_host_threads();
-    n_threads = std::min<int>(n_threads, std::max(1, n_loci));
-
-    struct Shared {
-        std::mutex exp_mu, err_mu;
-        advntr_exp_fn fn;
-        void *user;
-        int first_bad = -1;
-        std::string msg;
-    } sh;
-    sh.fn = exp_fn;
-    sh.user = user;
-    // serialise the caller's exp (a Python callback holds the interpreter lock anyway)
-    auto locked_exp = [](const double *in, double *o, int64_t n, void *u) {
-        Shared *s = (Shared *)u;
-        std::lock_guard<std::mutex> lk(s->exp_mu);
-        s->fn(in, o, n, s->user);
-    };
-    std::atomic<int> next(0);
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n_loci) return;
-            try {
-                if (!left_flank[i] || !right_flank[i]) throw std::invalid_argument("null flanking region");
-                std::vector<std::string> rows;
-                for (int r = repeat_off[i]; r < repeat_off[i + 1]; ++r) rows.emplace_back(repeats[r] ? repeats[r] : "");
-                if (flags & ADVNTR_BUILD_ALIGN_REPEATS) {
-                    bool ragged = false;
-                    for (const std::string &r : rows) ragged |= r.size() != rows[0].size();
-                    if (ragged) rows = msa::align_units(rows);
-                }
-                advntr_built *B = new advntr_built;
-                B->b = mb::build_read_matcher(left_flank[i], right_flank[i], rows, copies[i], max_error_rate,
-                                              exp_fn ? (mb::ExpFn)locked_exp : nullptr, &sh);
-                out[i] = B;
-            } catch (const std::exception &e) {
-                std::lock_guard<std::mutex> lk(sh.err_mu);
-                if (sh.first_bad < 0 || i < sh.first_bad) { sh.first_bad = i; sh.msg = e.what(); }
-            }
-        }
-    };
-    if (n_threads == 1) work();
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
-        for (auto &t : pool) t.join();
-    }
-    if (sh.first_bad >= 0) return fail(ADVNTR_ERR_ARG, "advntr_build_read_matchers: locus %d: %s", sh.first_bad, sh.msg.c_str());
-    return ADVNTR_OK;
-}
-
-extern "C" int advntr_built_info(const advntr_built *B, int32_t *info)
-{
-    if (!B || !info) return fail(ADVNTR_ERR_ARG, "advntr_built_info: null argument");
-    info[0] = B->b.m; info[1] = B->b.silent_start; info[2] = B->b.start_index; info[3] = B->b.end_index;
-    info[4] = (int32_t)B->b.in_src.size(); info[5] = (int32_t)B->b.names.size();
-    return ADVNTR_OK;
-}
-
-extern "C" int advntr_built_export(const advntr_built *B, int32_t *in_ptr, int32_t *in_src, double *in_logp,
-                                   double *emis_logp, uint16_t *state_class, char *names)
-{
-    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_built_export: null model");
-    const mb::Built &b = B->b;
-    if (in_ptr) memcpy(in_ptr, b.in_ptr.data(), b.in_ptr.size() * sizeof(int32_t));
-    if (in_src) memcpy(in_src, b.in_src.data(), b.in_src.size() * sizeof(int32_t));
-    if (in_logp) memcpy(in_logp, b.in_logp.data(), b.in_logp.size() * sizeof(double));
-    if (emis_logp) memcpy(emis_logp, b.emis.data(), b.emis.size() * sizeof(double));
-    if (state_class) memcpy(state_class, b.state_class.data(), b.state_class.size() * sizeof(uint16_t));
-    if (names) memcpy(names, b.names.data(), b.names.size());
-    return ADVNTR_OK;
-}
-
-extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
-{
-    if (!B) { fail(ADVNTR_ERR_ARG, "advntr_built_upload: null model"); return nullptr; }
-    const mb::Built &b = B->b;
-    return advntr_hmm_create(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
-                             b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data());
-}
-
-extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out)
-{
-    if (n < 0 || (n && (!built || !out))) return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: bad argument");
-    for (int i = 0; i < n; ++i) out[i] = nullptr;
-    if (n == 0) return ADVNTR_OK;
-    if (n_threads <= 0) n_threads = default_host_threads();
-    n_threads = std::min(n_threads, n);
-    std::mutex err_mu;
-    int first_bad = -1;
-    std::string msg;
-    std::atomic<int> next(0);
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n) return;
-            std::string err = "null model";
-            advntr_hmm *H = nullptr;
-            if (built[i]) {
-                const mb::Built &b = built[i]->b;
-                H = hmm_prepare(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
-                                b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data(), err);
-            }
-            if (H) out[i] = H;
-            else {
-                std::lock_guard<std::mutex> lk(err_mu);
-                if (first_bad < 0 || i < first_bad) { first_bad = i; msg = err; }
-            }
-        }
-    };
-    if (n_threads == 1) work();
-    else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
-        for (auto &t : pool) t.join();
-    }
-    auto drop_all = [&]() {
-        for (int i = 0; i < n; ++i) { delete out[i]; out[i] = nullptr; }
-    };
-    if (first_bad >= 0) {
-        drop_all();
-        return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
-    }
-    // one slab, 256-B aligned sub-blobs, one copy
-    std::vector<size_t> at(n);
-    size_t total = 0;
-    for (int i = 0; i < n; ++i) { at[i] = total; total += (out[i]->blob_bytes + 255) & ~size_t(255); }
-    std::vector<uint8_t> staging(total);
-    for (int i = 0; i < n; ++i) memcpy(staging.data() + at[i], out[i]->host_blob.data(), out[i]->blob_bytes);
-    ModelSlab *slab = new ModelSlab;
-    if (hipMalloc(&slab->d, total) != hipSuccess || hipMemcpy(slab->d, staging.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
-        if (slab->d) (void)hipFree(slab->d);
-        delete slab;
-        drop_all();
-        return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
-    }
-    slab->refs = n;
-    for (int i = 0; i < n; ++i) {
-        out[i]->slab = slab;
-        hmm_bind(out[i], (const uint8_t *)slab->d + at[i]);
-    }
-    return ADVNTR_OK;
-}
-
-extern "C" void advntr_built_destroy(advntr_built *B) { delete B; }
-
-extern "C" int advntr_align_repeats(const char *const *units, int32_t n, char *out, int64_t capacity, int32_t *width)
-{
-    if (n < 0 || (n && !units) || !width) return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: bad argument");
-    try {
-        std::vector<std::string> in;
-        for (int i = 0; i < n; ++i) in.emplace_back(units[i] ? units[i] : "");
-        const std::vector<std::string> rows = msa::align_units(in);
-        *width = rows.empty() ? 0 : (int32_t)rows[0].size();
-        if ((int64_t)n * *width > capacity || (n && !out))
-            return fail(ADVNTR_ERR_TOO_LARGE, "advntr_align_repeats: need %lld bytes", (long long)n * *width);
-        for (int i = 0; i < n; ++i) memcpy(out + (size_t)i * *width, rows[i].data(), (size_t)*width);
-    } catch (const std::exception &e) {
-        return fail(ADVNTR_ERR_ARG, "advntr_align_repeats: %s", e.what());
-    }
-    return ADVNTR_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Flank alignment (flank_align.h) behind the C ABI
-// ------------------------------------------------------------------------------------------------
-extern "C" int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_reads, const uint8_t *flank_bases,
-                                  const int32_t *flank_off, int32_t n_flanks, const int32_t *pair_read, const int32_t *pair_flank,
-                                  int32_t n_pairs, int32_t *out_score, int32_t *out_begin, int32_t *out_end, float *kernel_ms)
-{
-    if (n_reads < 0 || n_flanks < 0 || n_pairs < 0 || !read_off || !flank_off ||
-        (n_pairs && (!pair_read || !pair_flank || !out_score || !out_begin || !out_end)))
-        return fail(ADVNTR_ERR_ARG, "advntr_flank_align: bad argument");
-    if (kernel_ms) *kernel_ms = 0.f;
-    if (n_pairs == 0) return ADVNTR_OK;
-    for (int f = 0; f < n_flanks; ++f)
-        if (flank_off[f + 1] - flank_off[f] < 0 || flank_off[f + 1] - flank_off[f] > 64 * FA_K)
-            return fail(ADVNTR_ERR_TOO_LARGE, "advntr_flank_align: flank %d has %d bases (limit %d)", f,
-                        flank_off[f + 1] - flank_off[f], 64 * FA_K);
-    for (int p = 0; p < n_pairs; ++p)
-        if (pair_read[p] < 0 || pair_read[p] >= n_reads || pair_flank[p] < 0 || pair_flank[p] >= n_flanks)
-            return fail(ADVNTR_ERR_ARG, "advntr_flank_align: pair %d out of range", p);
-    const int64_t total = read_off[n_reads];
-    const int32_t ftotal = flank_off[n_flanks];
-    const int dev = current_device();
-    void *d_bases = nullptr, *d_off = nullptr, *d_fb = nullptr, *d_fo = nullptr, *d_pr = nullptr, *d_pf = nullptr, *d_out = nullptr;
-    hipEvent_t e0 = g_cache.get_event(dev), e1 = g_cache.get_event(dev);
-    auto cleanup = [&]() {
-        for (void *q : {d_bases, d_off, d_fb, d_fo, d_pr, d_pf, d_out}) (void)hipFree(q);
-        if (e0) g_cache.put_event(dev, e0);
-        if (e1) g_cache.put_event(dev, e1);
-    };
-    int rc = [&]() -> int {
-        if (!e0 || !e1) return fail(ADVNTR_ERR_DEVICE, "advntr_flank_align: event creation failed");
-        HIP_TRY(hipMalloc(&d_bases, (size_t)total + 16));
-        HIP_TRY(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
-        HIP_TRY(hipMalloc(&d_fb, (size_t)ftotal + 16));
-        HIP_TRY(hipMalloc(&d_fo, ((size_t)n_flanks + 1) * 4));
-        HIP_TRY(hipMalloc(&d_pr, (size_t)n_pairs * 4));
-        HIP_TRY(hipMalloc(&d_pf, (size_t)n_pairs * 4));
-        HIP_TRY(hipMalloc(&d_out, (size_t)n_pairs * 12));
-        if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        if (ftotal) HIP_TRY(hipMemcpy(d_fb, flank_bases, (size_t)ftotal, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_fo, flank_off, ((size_t)n_flanks + 1) * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_pr, pair_read, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_pf, pair_flank, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
-        FaArgs a{};
-        a.bases = (const uint8_t *)d_bases; a.read_off = (const int64_t *)d_off;
-        a.flank_bases = (const uint8_t *)d_fb; a.flank_off = (const int32_t *)d_fo;
-        a.pair_read = (const int32_t *)d_pr; a.pair_flank = (const int32_t *)d_pf; a.n_pairs = n_pairs;
-        a.out_score = (int32_t *)d_out; a.out_begin = a.out_score + n_pairs; a.out_end = a.out_begin + n_pairs;
-        const int grid = std::max(1, std::min((n_pairs + FA_WAVES - 1) / FA_WAVES, device_cus() * 4));
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(flank_align_kernel, dim3(grid), dim3(FA_WAVES * 64), 0, nullptr, a);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
-        HIP_TRY(hipMemcpy(out_score, a.out_score, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out_begin, a.out_begin, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out_end, a.out_end, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
-        return ADVNTR_OK;
-    }();
-    std::string keep = g_err;
-    cleanup();
-    g_err = keep;
-    return rc;
-}
+#include "abi_keyword_filter.h"
+#include "abi_model_builder.h"
+#include "abi_flank_align.h"
