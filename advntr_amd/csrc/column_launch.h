@@ -42,6 +42,9 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     const int grid = std::min(cl.grid, g.n_tiles);
+    if (cl.lds_bytes + 16 > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)viterbi_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(cl.lds_bytes + 16));
     hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
 }
 
@@ -63,13 +66,17 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     g.ring = cl.ring;
     const int grid = std::min(cl.grid, g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)viterbi_columns_stream_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
 }
 
+// slot: which tile list (0..3 = reads of 1..4 chunks, 4 = long reads).  The sum-product sweep works in the linear domain
+// with a per-row scale of 16, which bounds a row tile to 192 rows: reads of 193-256 rows (slot 3) go through the
+// row-tiled kernel like the long ones.
 template <int K, bool LONG>
-static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream)
+static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int slot)
 {
-    const int slot = LONG ? 4 : K - 1;
     if (cl.tiles[slot].empty()) return;
     ColArgs g{};
     g.a = a;
@@ -80,6 +87,9 @@ static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a,
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     const int grid = std::min(cl.grid, g.n_tiles);
-    hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g);
+    const size_t lds = ((cl.lds_bytes + 15) & ~size_t(15)) + 16 + 16 * (size_t)cl.nc_max + 16;      // + linear row-0 table
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)forward_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g);
 }
 

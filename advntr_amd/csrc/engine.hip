@@ -897,11 +897,11 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 BatchArgs a = make_args(B);
                 a.n_reads = B->n_col;
                 a.order = B->d_order;
-                column_launch_fwd<1, false>(B->col, a, B->stream);
-                column_launch_fwd<2, false>(B->col, a, B->stream);
-                column_launch_fwd<3, false>(B->col, a, B->stream);
-                column_launch_fwd<4, false>(B->col, a, B->stream);
-                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream);
+                column_launch_fwd<1, false>(B->col, a, B->stream, 0);
+                column_launch_fwd<2, false>(B->col, a, B->stream, 1);
+                column_launch_fwd<3, false>(B->col, a, B->stream, 2);
+                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3);      // 193-256 rows: two row tiles
+                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4);
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

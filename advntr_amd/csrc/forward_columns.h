@@ -70,6 +70,18 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
             M = g.a.models[cur_model];
             cp = M.cols;
             padded = stage_model<K>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+            // to the linear domain, in place: transition classes -> probabilities, emission records -> probability times
+            // the per-row scale 16 (an exact power of two; with it a row tile of <= 192 rows neither overflows, (0.97 *
+            // 16)^192 = 1e228, nor underflows on any read, (0.25 * 0.02 * 16)^192 = 2e-211), and the row-0 / entry terms
+            // of every column into an LDS table of their own behind the staged tables
+            double *cls = (double *)L.classes, *em = (double *)L.emis;
+            for (int i = tid; i < cp->n_tclass * (int)(sizeof(ColClass) / 8); i += COL_WAVES * 64) cls[i] = exp(cls[i]);
+            for (int i = tid; i < cp->n_eclass * COL_EMIS_STRIDE; i += COL_WAVES * 64) em[i] = exp(em[i]) * 16.0;
+            double *lin = (double *)(tables + ((g.lds_tables + 15) & ~15));
+            const double *fw = (const double *)((const uint8_t *)cp + cp->off_fwd);
+            for (int i = tid; i < 2 * cp->n_cols; i += COL_WAVES * 64) lin[i] = exp(fw[i]);
+            L.fwd_lin = lds_addr(lin);
+            __syncthreads();
         }
         const int NC = cp->n_cols;
         for (int j = wave; j < tile.count; j += COL_WAVES) {
@@ -79,6 +91,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
             TileCtx C;
             C.NC = NC; C.sink_stride = 0; C.sinkbp = nullptr; C.bp = nullptr;
             C.fwd = (const double *)((const uint8_t *)cp + cp->off_fwd);
+            C.seam_off = 0.0;
             double *final_row = rown;
             if (!LONG) {
                 C.n_tile = n; C.row0 = 0; C.cap = rown; C.seam = nullptr;
@@ -91,6 +104,14 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
                     C.n_tile = min(TPAD, n - C.row0);
                     C.cap = buf[(i + 1) & 1];
                     C.seam = buf[i & 1];
+                    C.seam_off = 0.0;
+                    if (i > 0) {                       // renormalise: the tile works relative to its seam row's maximum
+                        double mx = -INFINITY;
+                        for (int q = lane; q < 3 * NC; q += 64) mx = fmax(mx, C.seam[q]);
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+                        C.seam_off = mx == -INFINITY ? 0.0 : mx;
+                    }
                     if (i == 0) col_sweep<K, 0, true>(L, padded, C, seq, lane);
                     else col_sweep<K, 1, true>(L, padded, C, seq + i * TPAD, lane);
                     __threadfence_block();

@@ -173,6 +173,8 @@ __device__ __forceinline__ uint2 lds_uint2(const unsigned addr)
 
 struct LdsTables {
     unsigned class_base, emis_base;   // LDS byte addresses of the two tables
+    unsigned fwd_lin;                 // sum-product kernel: LDS byte address of {row-0 value of b_c, entry term of M_c} per
+                                      // column, in the linear domain (forward_columns.h)
     unsigned pinfo;                   // LDS byte address of the padded info copy (record c + 64K; 0 if it does not fit):
                                       // {v0b, class address | flags << 16, emM address | emI address << 16}
     const ColClass *classes;
@@ -210,7 +212,9 @@ struct TileCtx {
     double *seam_out;          // last row of a full tile -> next tile's seam
     int64_t cap_stride;        // doubles between the capture buffers of the reads that end in this tile
     unsigned hasfirst, haslast; // bit k: chunk k holds a first / last row of some read
-    const double *fwd;         // sum-product kernel: per column {row-0 forward value of b_c, entry term of M_c}
+    const double *fwd;         // sum-product kernel: per column {row-0 forward value of b_c, entry term of M_c} (log domain)
+    double seam_off;           // sum-product kernel: log-domain offset of this row tile (its seam row was divided by
+                               // exp(seam_off) when it was loaded); 0 for the first tile
 };
 
 __device__ __forceinline__ double shift_up1_from(double v, double prev_chunk)
@@ -257,11 +261,11 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         if (MODE == 0 && k == 0) { v0b = R.v0b0; R.v0b0 = *(LdsDouble *)(size_t)(L.pinfo + (unsigned)(cc + 1) * 16u); }
     }
     LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
-    double fwd_mX = -INFINITY;
+    double fwd_mX = 0.0;
     if (FWD && MODE == 0 && k == 0) {            // row 0 / entry terms of the sum-product recursion (lane 0 only)
         const int cq = min(max(c, 0), NC - 1);
-        v0b = C.fwd[2 * cq];
-        fwd_mX = C.fwd[2 * cq + 1];
+        v0b = *(LdsDouble *)(size_t)(L.fwd_lin + (unsigned)cq * 16u);
+        fwd_mX = *(LdsDouble *)(size_t)(L.fwd_lin + (unsigned)cq * 16u + 8u);
     }
     // previous row, same column: the neighbouring lane's values of the previous step
     double nI, nM, nB;
@@ -294,16 +298,18 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     int bits;                     // the cell's back-pointer byte, one comparison outcome per bit (relax_bit)
     if (FWD) {
         bits = 0;
-        // sum-product: pair_lse folds in the reference's in-edge order (hmm.pyx:1429-1480), emission added last
-        vI = lse2(lse2(nI + T->iI, nM + T->iM), nB + T->iD) + eI;
-        double accM = lse2(R.pI[k] + T->mI, R.pM[k] + T->mM);
-        if (MODE == 0 && k == 0) accM = lse2(accM, (t == 1) ? fwd_mX : -INFINITY);
-        vM = lse2(accM, R.pB[k] + T->mD) + eM;
-        vB = lse2(lse2(R.I[k] + T->dI, R.M[k] + T->dM), R.B[k] + T->dD);
+        // sum-product in the LINEAR domain (forward_columns.h): the class and emission tables in LDS hold probabilities
+        // (emissions times the per-row scale 16), values are probabilities times 16^row (times the tile's offset), so a
+        // cell is a dozen multiply-adds instead of the fourteen exp/log calls of pair_lse folding
+        vI = ((nI * T->iI + nM * T->iM) + nB * T->iD) * eI;
+        double accM = R.pI[k] * T->mI + R.pM[k] * T->mM;
+        if (MODE == 0 && k == 0) accM = accM + ((t == 1) ? fwd_mX : 0.0);
+        vM = (accM + R.pB[k] * T->mD) * eM;
+        vB = (R.I[k] * T->dI + R.M[k] * T->dM) + R.B[k] * T->dD;
         const unsigned flf = meta.x >> 16;
         if (__ballot((flf & 3u) != 0)) {
-            if (flf & COL_FLAG_SINK) { vB = R.er[k]; R.er[k] = -INFINITY; }
-            if (flf & COL_FLAG_FEED) R.er[k] = lse2(R.er[k], vB + T->erw);
+            if (flf & COL_FLAG_SINK) { vB = R.er[k]; R.er[k] = 0.0; }
+            if (flf & COL_FLAG_FEED) R.er[k] = R.er[k] + vB * T->erw;
         }
     } else {
     // I_c(t) <- [I_c, M_c, b_c](t-1)
@@ -361,16 +367,23 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         }
     } else if (MODE == 0 ? (k == K - 1) : true) {                    // single tile: row n lives in the last chunk
         if (t == C.n_tile && c >= 0 && c < NC) {
-            C.cap[c * 3 + 0] = vI;
-            C.cap[c * 3 + 1] = vM;
-            C.cap[c * 3 + 2] = vB;
+            if (FWD) {          // back to the log domain: value = probability * 16^t * exp(-seam_off)
+                const double back = C.seam_off - (double)t * 2.772588722239781;       // t * log(16)
+                C.cap[c * 3 + 0] = log(vI) + back;
+                C.cap[c * 3 + 1] = log(vM) + back;
+                C.cap[c * 3 + 2] = log(vB) + back;
+            } else {
+                C.cap[c * 3 + 0] = vI;
+                C.cap[c * 3 + 1] = vM;
+                C.cap[c * 3 + 2] = vB;
+            }
         }
     }
 }
 
 // seam values for the column lane 0 works on at step s (row-tiled reads only): registers hold 64 columns,
 // the next 64 are prefetched one block ahead
-template <int K>
+template <int K, bool FWD = false>
 __device__ __forceinline__ void seam_fetch(ColRegs<K> &R, const TileCtx &C, const int s, const int lane, double &injI,
                                            double &injM, double &injB)
 {
@@ -381,6 +394,9 @@ __device__ __forceinline__ void seam_fetch(ColRegs<K> &R, const TileCtx &C, cons
         R.tI = C.seam[cn * 3 + 0];
         R.tM = C.seam[cn * 3 + 1];
         R.tB = C.seam[cn * 3 + 2];
+        if (FWD) {              // the seam is kept in the log domain; the tile works on exp(seam - seam_off) <= 1
+            R.tI = exp(R.tI - C.seam_off); R.tM = exp(R.tM - C.seam_off); R.tB = exp(R.tB - C.seam_off);
+        }
     }
     injI = readlane_f64(R.sI, j);
     injM = readlane_f64(R.sM, j);
@@ -400,7 +416,7 @@ __device__ __forceinline__ void col_phase(ColRegs<K> &R, const int s0, const int
     }
     auto step = [&](const int s) {
         double injI = 0, injM = 0, injB = 0;
-        if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
+        if (MODE != 0) seam_fetch<K, FWD>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
         for (int k = KHI; k >= KLO; --k) col_cell<K, false, MODE, FWD>(R, k, L, C, s, lane, injI, injM, injB);
     };
@@ -422,9 +438,10 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
 {
     const int NC = __builtin_amdgcn_readfirstlane(C.NC), n = __builtin_amdgcn_readfirstlane(C.n_tile);   // scalar loop bounds
     ColRegs<K> R;
+    const double NONE = FWD ? 0.0 : -INFINITY;      // "impossible": probability 0 in the linear sum-product sweep
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        R.I[k] = R.M[k] = R.B[k] = R.pI[k] = R.pM[k] = R.pB[k] = R.er[k] = -INFINITY;
+        R.I[k] = R.M[k] = R.B[k] = R.pI[k] = R.pM[k] = R.pB[k] = R.er[k] = NONE;
         R.erwin[k] = 0;
         const int t = 64 * k + lane + 1;
         if (MODE == 2) {
@@ -435,13 +452,14 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
             R.sflag[k] = 0;
         }
     }
-    R.sI = R.sM = R.sB = R.tI = R.tM = R.tB = -INFINITY;
-    R.n0I = R.n0M = -INFINITY;
+    R.sI = R.sM = R.sB = R.tI = R.tM = R.tB = NONE;
+    R.n0I = R.n0M = NONE;
     if (MODE != 0) {                                // columns 0..63 of the seam; seam_fetch rotates at s = 1
         const int cn = min(lane, NC - 1);
         R.tI = C.seam[cn * 3 + 0];
         R.tM = C.seam[cn * 3 + 1];
         R.tB = C.seam[cn * 3 + 2];
+        if (FWD) { R.tI = exp(R.tI - C.seam_off); R.tM = exp(R.tM - C.seam_off); R.tB = exp(R.tB - C.seam_off); }
     }
     const int s_end = n + NC - 1;
     if (padded && NC + 63 >= 64 * (K - 1) + 1) {
@@ -457,7 +475,7 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
     } else {
         for (int s = 1; s <= s_end; ++s) {
             double injI = 0, injM = 0, injB = 0;
-            if (MODE != 0) seam_fetch<K>(R, C, s, lane, injI, injM, injB);
+            if (MODE != 0) seam_fetch<K, FWD>(R, C, s, lane, injI, injM, injB);
 #pragma unroll
             for (int k = K - 1; k >= 0; --k) {
                 if (s < 64 * k + 1 || s > 64 * k + 64 + NC - 1) continue;      // wave-uniform

@@ -697,3 +697,37 @@ def test_model_update_from_reads_equals_the_reference_model():
     assert np.array_equal(a["in_ptr"], in_ptr) and np.array_equal(a["in_src"], in_src)
     assert np.all(np.abs(a["in_logp"] - in_logp)[np.isfinite(in_logp)] <= 4 * np.spacing(np.abs(in_logp[np.isfinite(in_logp)])))
     assert np.array_equal(a["emis_logp"], np.array([e["logp"] for e in gm["emissions"]]))
+
+
+@pytest.mark.gpu
+def test_sum_product_linear_domain_ranges():
+    """Model.log_probability on the column program works in the linear domain (probabilities times 16^row, row tiles
+    renormalised at their seams): long reads on a PacBio-parameter model, reads at every bucket / tile boundary and
+    worst-case reads that match nothing, against the oracle's log-domain forward (hmm.pyx:1371-1484)."""
+    from advntr_amd import settings, workloads
+    from oracle.oracle import OracleModel
+
+    def oracle_of(model):
+        a = model.baked_arrays()
+        edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k])) for l in range(a["m"])
+                 for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        return OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+
+    rng = np.random.default_rng(3)
+    loc = workloads.make_locus(rng, 100, 25, 30, error_rate=0.3)
+    O = oracle_of(loc.model)
+    reads = [workloads.noisy_copy(rng, loc.left[-100:] + loc.units[0] * int(rng.integers(2, 28)) + loc.right[:100], 0.12)
+             for _ in range(8)]
+    reads += [workloads.rand_seq(rng, n) for n in (1, 2, 63, 64, 65, 150, 192, 193, 200, 256, 257, 384, 385, 700, 1500)]
+    got = loc.model.log_probability_batch(reads)
+    for r, g in zip(reads, got):
+        want = O.forward(r)
+        assert abs(g - want) <= 1e-9 * max(1.0, abs(want)), (len(r), g, want)
+    ref = workloads.ref150()
+    O = oracle_of(ref.model)
+    hard = ["A" * 150, "ACGT" * 48, "T" * 192, "G" * 256, "C" * 400]
+    got = ref.model.log_probability_batch(hard)
+    for r, g in zip(hard, got):
+        want = O.forward(r)
+        assert np.isfinite(g) and abs(g - want) <= 1e-9 * abs(want), (len(r), g, want)
+    assert min(got) < -800                                     # far below exp(-709): the scaling keeps it representable
