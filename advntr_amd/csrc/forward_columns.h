@@ -42,8 +42,19 @@ __device__ __forceinline__ double col_tail_forward(const ColProgram *__restrict_
     return result;
 }
 
+// The last row of a tile was captured as probabilities * 16^rows * exp(-seam_off): back to the log domain.
+__device__ __forceinline__ void col_row_to_log(double *__restrict__ row, const int NC, const int rows, const double seam_off,
+                                               const int lane)
+{
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    const double back = seam_off - (double)rows * 2.772588722239781;          // rows * log(16)
+    for (int q = lane; q < 3 * NC; q += 64) row[q] = log(row[q]) + back;
+}
+
 template <int K, bool LONG>
-__global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColArgs g)
+__global__ void __launch_bounds__(COL_WAVES * 64, (K >= 4 ? (LONG ? COL_LONG4_WAVES : 3) : (LONG ? COL_LONG_WAVES : COL_MIN_WAVES_PER_SIMD)))
+forward_columns_kernel(ColArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int TPAD = 64 * K;
@@ -96,6 +107,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
             if (!LONG) {
                 C.n_tile = n; C.row0 = 0; C.cap = rown; C.seam = nullptr;
                 col_sweep<K, 0, true>(L, padded, C, seq, lane);
+                col_row_to_log(C.cap, NC, n, 0.0, lane);
             } else {
                 double *buf[2] = {rown, rown + 3 * (int64_t)NC + COL_MAX_TAIL};
                 const int n_tiles = (n + TPAD - 1) / TPAD;
@@ -114,6 +126,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64, 2) forward_columns_kernel(ColA
                     }
                     if (i == 0) col_sweep<K, 0, true>(L, padded, C, seq, lane);
                     else col_sweep<K, 1, true>(L, padded, C, seq + i * TPAD, lane);
+                    col_row_to_log(C.cap, NC, C.n_tile, C.seam_off, lane);
                     __threadfence_block();
                     __builtin_amdgcn_wave_barrier();
                 }

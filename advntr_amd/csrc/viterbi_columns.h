@@ -367,16 +367,11 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         }
     } else if (MODE == 0 ? (k == K - 1) : true) {                    // single tile: row n lives in the last chunk
         if (t == C.n_tile && c >= 0 && c < NC) {
-            if (FWD) {          // back to the log domain: value = probability * 16^t * exp(-seam_off)
-                const double back = C.seam_off - (double)t * 2.772588722239781;       // t * log(16)
-                C.cap[c * 3 + 0] = log(vI) + back;
-                C.cap[c * 3 + 1] = log(vM) + back;
-                C.cap[c * 3 + 2] = log(vB) + back;
-            } else {
-                C.cap[c * 3 + 0] = vI;
-                C.cap[c * 3 + 1] = vM;
-                C.cap[c * 3 + 2] = vB;
-            }
+            // (the sum-product kernel captures probabilities here and takes their logarithms after the sweep, wave-parallel:
+            // a log inside this branch would run on one active lane at every step)
+            C.cap[c * 3 + 0] = vI;
+            C.cap[c * 3 + 1] = vM;
+            C.cap[c * 3 + 2] = vB;
         }
     }
 }

@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e; e.build()
 from advntr_amd import _lib, workloads
 loc = workloads.ref150()
