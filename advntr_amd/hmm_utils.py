@@ -457,3 +457,80 @@ def get_emitted_basepair_from_visited_states(state, visited_states, sequence):
         if is_emitting_state(name):
             at += 1
     return None
+
+
+# ------------------------------------------------------------------------------------------------
+# Repeat finder for a reference region (hmm_utils.py:598-680): used when a VNTR is added to the model database
+# ------------------------------------------------------------------------------------------------
+def build_reference_repeat_finder_hmm(patterns, copies=1):
+    """`copies` profile units of the first pattern (match emits 0.97 / 0.01, fixed 0.98 / 0.01 / 0.01 transitions) between
+    two random-sequence states; baked with bake()'s default merge='All' like the reference.  This model has no column
+    program (its random-match states emit): it is scored by the generic-CSR kernel."""
+    pattern = patterns[0]
+    L = len(pattern)
+    model = Model(name="HMM Model")
+    uniform = DiscreteDistribution({'A': 0.25, 'C': 0.25, 'G': 0.25, 'T': 0.25})
+    start_random = State(uniform, name='start_random_matches')
+    end_random = State(uniform, name='end_random_matches')
+    model.add_states([start_random, end_random])
+    add = model.add_transition
+    last_end = None
+    for repeat in range(copies):
+        ins = [State(uniform, name='I%s_%s' % (i, repeat)) for i in range(L + 1)]
+        mat = []
+        for i in range(L):
+            dist = dict({'A': 0.01, 'C': 0.01, 'G': 0.01, 'T': 0.01})
+            dist[pattern[i]] = 0.97
+            mat.append(State(DiscreteDistribution(dist), name='M%s_%s' % (str(i + 1), repeat)))
+        dele = [State(None, name='D%s_%s' % (str(i + 1), repeat)) for i in range(L)]
+        unit_start = State(None, name='unit_start_%s' % repeat)
+        unit_end = State(None, name='unit_end_%s' % repeat)
+        model.add_states(ins + mat + dele + [unit_start, unit_end])
+        last = L - 1
+        if repeat > 0:
+            add(last_end, unit_start, 0.5)
+        else:
+            add(model.start, unit_start, 0.5)
+            add(model.start, start_random, 0.5)
+            add(start_random, unit_start, 0.5)
+            add(start_random, start_random, 0.5)
+        add(unit_end, end_random, 0.5)
+        if repeat == copies - 1:
+            add(unit_end, model.end, 0.5)
+            add(end_random, end_random, 0.5)
+            add(end_random, model.end, 0.5)
+        add(unit_start, mat[0], 0.98)
+        add(unit_start, dele[0], 0.01)
+        add(unit_start, ins[0], 0.01)
+        add(ins[0], ins[0], 0.01)
+        add(ins[0], dele[0], 0.01)
+        add(ins[0], mat[0], 0.98)
+        add(dele[last], unit_end, 0.99)
+        add(dele[last], ins[last + 1], 0.01)
+        add(mat[last], unit_end, 0.99)
+        add(mat[last], ins[last + 1], 0.01)
+        add(ins[last + 1], ins[last + 1], 0.01)
+        add(ins[last + 1], unit_end, 0.99)
+        for i in range(L):
+            add(mat[i], ins[i + 1], 0.01)
+            add(dele[i], ins[i + 1], 0.01)
+            add(ins[i + 1], ins[i + 1], 0.01)
+            if i < L - 1:
+                add(ins[i + 1], mat[i + 1], 0.98)
+                add(ins[i + 1], dele[i + 1], 0.01)
+                add(mat[i], mat[i + 1], 0.98)
+                add(mat[i], dele[i + 1], 0.01)
+                add(dele[i], dele[i + 1], 0.01)
+                add(dele[i], mat[i + 1], 0.98)
+        last_end = unit_end
+    model.bake()
+    return model
+
+
+def find_repeat_segments(pattern, estimated_repeats, region_in_ref):
+    """ReferenceVNTR.find_repeat_segments (reference_vntr.py:80-87): Viterbi path of the region through the repeat finder,
+    cut at the unit boundaries."""
+    model = build_reference_repeat_finder_hmm([pattern], copies=estimated_repeats)
+    logp, path = model.viterbi(region_in_ref)
+    visited_states = [state.name for _, state in path[1:-1]]
+    return get_repeat_segments_from_visited_states_and_region(visited_states, region_in_ref)

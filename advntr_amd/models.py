@@ -135,3 +135,20 @@ def delete_vntr_from_database(vntr_id, db_file=None):
     db.execute("DELETE FROM vntrs WHERE id=?", (int(vntr_id),))
     db.commit()
     db.close()
+
+
+def init_from_vntrseek_data(vntr, chromosome_sequence, flanking_region_size=500):
+    """ReferenceVNTR.init_from_vntrseek_data (reference_vntr.py:42-48) with the chromosome passed in: the region the
+    VNTRseek estimate covers (cut at the first N) is segmented into repeat units by the repeat-finder HMM on the GPU
+    (hmm_utils.find_repeat_segments), then the flanking regions are taken around the segmented VNTR."""
+    from .hmm_utils import find_repeat_segments
+    estimated_length = int(len(vntr.pattern) * vntr.estimated_repeats)
+    region = chromosome_sequence[vntr.start_point:vntr.start_point + estimated_length].upper()
+    if region.find('N') != -1:
+        region = region[:region.find('N')]
+    vntr.repeat_segments = find_repeat_segments(vntr.pattern, vntr.estimated_repeats, region)
+    end_of_repeats = vntr.start_point + vntr.get_length()
+    vntr.left_flanking_region = chromosome_sequence[vntr.start_point - flanking_region_size:vntr.start_point].upper()
+    vntr.right_flanking_region = chromosome_sequence[end_of_repeats:end_of_repeats + flanking_region_size].upper()
+    vntr.chromosome_sequence = None
+    return vntr

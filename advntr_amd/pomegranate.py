@@ -104,6 +104,14 @@ class _Graph(object):
     def nodes(self):
         return list(self.succ)
 
+    def remove_node(self, n):
+        del self.succ[n]
+        for nbrs in self.succ.values():
+            nbrs.pop(n, None)
+
+    def remove_edge(self, a, b):
+        del self.succ[a][b]
+
     def edges(self):
         for a, nbrs in self.succ.items():
             for b, lp in nbrs.items():
@@ -231,9 +239,10 @@ class HiddenMarkovModel(object):
     # ---- bake ------------------------------------------------------------------------------
     def bake(self, verbose=False, merge="All"):
         merge = merge.lower() if merge else None
-        if merge is not None:
-            raise NotImplementedError("bake(merge=%r): adVNTR only bakes with merge=None "
-                                      "(hmm_utils.py:351,418,494,548,559,594); graph merging is out of scope" % merge)
+        if merge not in (None, "none", "partial", "all"):
+            raise ValueError("merge must be None, 'Partial' or 'All'")
+        if merge in ("partial", "all"):
+            self._merge(merge)
         states = self.graph.nodes()
         self.n_states = len(states)
         self.n_edges = self.graph.n_edges()
@@ -293,6 +302,56 @@ class HiddenMarkovModel(object):
         self.start_index = indices[self.start]
         self.end_index = indices[self.end]
         self._release_device()
+
+    def _merge(self, merge):
+        """The graph rewriting bake() does before numbering the states when merge is 'All' (the default of bake() and what
+        hmm_utils.build_reference_repeat_finder_hmm and from_json get) or 'Partial' (hmm.pyx:725-823): orphan removal,
+        normalisation of out-edges, folding of silent states that have a probability-1 transition."""
+        g = self.graph
+        if merge == "all":
+            # hmm.pyx:725-757.  The two counters are allocated once for the initial node count and keep accumulating over
+            # the passes while the node positions shift after every removal -- mirrored as is.
+            n0 = len(g.nodes())
+            in_count, out_count = [0] * n0, [0] * n0
+            while True:
+                removed = 0
+                pre = g.nodes()
+                index = {st: i for i, st in enumerate(pre)}
+                for a, b, _ in list(g.edges()):
+                    out_count[index[a]] += 1
+                    in_count[index[b]] += 1
+                for i, st in enumerate(pre):
+                    if st is self.start or st is self.end:
+                        continue
+                    if in_count[i] == 0 or out_count[i] == 0:
+                        removed += 1
+                        g.remove_node(st)
+                if removed == 0:
+                    break
+        # hmm.pyx:760-776: out-edges that do not sum to 1 (to 8 decimals) are normalised, except those of the end state
+        for st in g.nodes():
+            total = round(sum(np.e ** lp for lp in g.succ[st].values()), 8)
+            if total != 1. and st is not self.end:
+                for b in g.succ[st]:
+                    g.succ[st][b] = g.succ[st][b] - _log(total)
+        # hmm.pyx:779-814: a silent state with a probability-1 edge to b ('Partial': to a silent b) hands its in-edges to b
+        while True:
+            merged = 0
+            for a, b, lp in list(g.edges()):
+                if a not in g.succ or b not in g.succ:
+                    continue
+                if a is self.start or b is self.end:
+                    continue
+                lp = g.succ[a].get(b, lp)                 # the edge's current value (normalisation shares the record)
+                if lp == 0.0 and a.is_silent() and (merge == "all" or b.is_silent()):
+                    for x, y, d in list(g.edges()):
+                        if y is a:
+                            merged += 1
+                            g.remove_edge(x, y)
+                            g.add_edge(x, b, d)
+                    g.remove_node(a)
+            if merged == 0:
+                break
 
     def dense_transition_matrix(self):
         m = len(self.states)
@@ -452,6 +511,56 @@ class _BuiltHiddenMarkovModel(HiddenMarkovModel):
 
     def set_flank_bases(self, mapping):
         raise NotImplementedError("the native builder already encodes the flank bases in the state classes")
+
+    def _merge(self, merge):
+        """The graph rewriting bake() does before numbering the states when merge is 'All' (the default of bake() and what
+        hmm_utils.build_reference_repeat_finder_hmm and from_json get) or 'Partial' (hmm.pyx:725-823): orphan removal,
+        normalisation of out-edges, folding of silent states that have a probability-1 transition."""
+        g = self.graph
+        if merge == "all":
+            # hmm.pyx:725-757.  The two counters are allocated once for the initial node count and keep accumulating over
+            # the passes while the node positions shift after every removal -- mirrored as is.
+            n0 = len(g.nodes())
+            in_count, out_count = [0] * n0, [0] * n0
+            while True:
+                removed = 0
+                pre = g.nodes()
+                index = {st: i for i, st in enumerate(pre)}
+                for a, b, _ in list(g.edges()):
+                    out_count[index[a]] += 1
+                    in_count[index[b]] += 1
+                for i, st in enumerate(pre):
+                    if st is self.start or st is self.end:
+                        continue
+                    if in_count[i] == 0 or out_count[i] == 0:
+                        removed += 1
+                        g.remove_node(st)
+                if removed == 0:
+                    break
+        # hmm.pyx:760-776: out-edges that do not sum to 1 (to 8 decimals) are normalised, except those of the end state
+        for st in g.nodes():
+            total = round(sum(np.e ** lp for lp in g.succ[st].values()), 8)
+            if total != 1. and st is not self.end:
+                for b in g.succ[st]:
+                    g.succ[st][b] = g.succ[st][b] - _log(total)
+        # hmm.pyx:779-814: a silent state with a probability-1 edge to b ('Partial': to a silent b) hands its in-edges to b
+        while True:
+            merged = 0
+            for a, b, lp in list(g.edges()):
+                if a not in g.succ or b not in g.succ:
+                    continue
+                if a is self.start or b is self.end:
+                    continue
+                lp = g.succ[a].get(b, lp)                 # the edge's current value (normalisation shares the record)
+                if lp == 0.0 and a.is_silent() and (merge == "all" or b.is_silent()):
+                    for x, y, d in list(g.edges()):
+                        if y is a:
+                            merged += 1
+                            g.remove_edge(x, y)
+                            g.add_edge(x, b, d)
+                    g.remove_node(a)
+            if merged == 0:
+                break
 
     def dense_transition_matrix(self):
         a = self.baked_arrays()

@@ -71,10 +71,46 @@ def test_unaligned_repeats_are_refused(native):
         hmm_utils.get_read_matcher_model("ACGTACGT", "TTGACCAA", ["ACGTT", "ACGT"], 2, native=native)
 
 
-def test_bake_merge_other_than_none_is_refused():
-    from advntr_amd import HiddenMarkovModel
-    with pytest.raises(NotImplementedError):
-        HiddenMarkovModel("x").bake()
+def _baked_equals(m, gm):
+    assert [s.name for s in m.states] == gm["state_names"]
+    assert (m.silent_start, m.start_index, m.end_index) == (gm["silent_start"], gm["start_index"], gm["end_index"])
+    idx = {s: i for i, s in enumerate(m.states)}
+    edges = [(idx[a], idx[b], lp) for a, b, lp in m.graph.edges()]
+    assert [(a, b) for a, b, _ in edges] == [(a, b) for a, b, _ in gm["edges"]]
+    got, want = np.array([e[2] for e in edges]), np.array([e[2] for e in gm["edges"]])
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    fin = np.isfinite(want)
+    assert np.all(np.abs(got[fin] - want[fin]) <= 4 * np.spacing(np.abs(want[fin]))) and np.mean(got == want) > 0.99
+    assert np.array_equal(m.baked_arrays()["emis_logp"], np.array([e["logp"] for e in gm["emissions"]]).reshape(-1, 4))
+
+
+def test_bake_with_merging_equals_the_reference():
+    """bake(merge='All' / 'Partial') (hmm.pyx:725-823: orphan removal, normalisation, folding of probability-1 silent
+    states) on the 61 random models the reference's pomegranate baked (tests/golden/make_merge_golden.py)."""
+    from advntr_amd import HiddenMarkovModel, State, DiscreteDistribution
+    g = load_golden("bake_merge")
+    seen = set()
+    for case in g["cases"]:
+        spec = case["spec"]
+        m = HiddenMarkovModel("rnd")
+        states = [State(DiscreteDistribution(dict(zip("ACGT", spec["dists"][i]))) if i < spec["n_emit"] else None, name=nm)
+                  for i, nm in enumerate(spec["names"])]
+        m.add_states(states)
+        n = len(states)
+        for a, b, p in spec["edges"]:
+            m.add_transition(m.start if a == -1 else states[a], m.end if b == n else states[b], p)
+        before = len(m.graph.nodes())
+        m.bake(merge=case["merge"])
+        _baked_equals(m, case["model"])
+        seen.add((case["merge"], len(m.states) < before))
+    assert seen == {("All", True), ("All", False), ("Partial", True), ("Partial", False)} or len(seen) >= 3
+
+
+def test_repeat_finder_model_equals_the_reference():
+    g = load_golden("bake_merge")
+    for f in g["repeat_finder"]:
+        m = hmm_utils.build_reference_repeat_finder_hmm([f["pattern"]], copies=f["copies"])
+        _baked_equals(m, f["model"])
 
 
 def test_host_path_summaries_on_goldens():

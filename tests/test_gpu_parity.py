@@ -731,3 +731,30 @@ def test_sum_product_linear_domain_ranges():
         want = O.forward(r)
         assert np.isfinite(g) and abs(g - want) <= 1e-9 * abs(want), (len(r), g, want)
     assert min(got) < -800                                     # far below exp(-709): the scaling keeps it representable
+
+
+@pytest.mark.gpu
+def test_repeat_finder_segmentation_equals_the_reference():
+    """ReferenceVNTR.find_repeat_segments (reference_vntr.py:80-87): the repeat-finder HMM (default bake with merging,
+    emitting random-match states => generic-CSR kernel) segments a reference region; log-prob, path and segments are
+    the reference's (tests/golden/bake_merge.json.gz)."""
+    from advntr_amd import hmm_utils, models
+    g = load_golden("bake_merge")
+    for f in g["repeat_finder"]:
+        m = hmm_utils.build_reference_repeat_finder_hmm([f["pattern"]], copies=f["copies"])
+        assert not m.device_model().has_column_program()
+        for r in f["regions"]:
+            logp, path = m.viterbi(r["region"])
+            assert logp == r["logp"] and [i for i, _ in path] == r["path"]
+            assert hmm_utils.find_repeat_segments(f["pattern"], f["copies"], r["region"]) == r["segments"]
+    # init_from_vntrseek_data on a synthetic chromosome: the planted units come back as the repeat segments
+    f = g["repeat_finder"][0]
+    units = f["regions"][0]["segments"]
+    rng = np.random.default_rng(1)
+    left = "".join("ACGT"[i] for i in rng.integers(0, 4, 700))
+    right = "".join("ACGT"[i] for i in rng.integers(0, 4, 700))
+    chrom = left + "".join(units) + right
+    v = models.ReferenceVNTR(1, f["pattern"], 700, "chr1", None, None, estimated_repeats=len(units))
+    models.init_from_vntrseek_data(v, chrom)
+    assert "".join(v.repeat_segments) == "".join(units)[:len(f["pattern"]) * len(units)][:len("".join(v.repeat_segments))]
+    assert v.left_flanking_region == left[-500:] and v.right_flanking_region == chrom[700 + v.get_length():][:500]
