@@ -14,7 +14,8 @@ adVNTR's path.  Reference lines (relative to /root/reference/pomegranate):
   log_probability            hmm.pyx:1258-1298
 
 What is NOT here: everything adVNTR never calls (fit, backward, sampling, plotting, other
-distributions, bake's merge="All"/"Partial" graph rewriting) -- see DESIGN.md "out of scope".
+distributions) -- see DESIGN.md "out of scope".  bake() supports merge=None (the read matchers) and the
+default merge="All" / "Partial" (hmm.pyx:725-823; the repeat finder of hmm_utils.py:598-680 is baked that way).
 
 The graph container is a plain insertion-ordered adjacency map.  bake() derives the same state
 numbering and in-edge order as the reference does on networkx 1.11 under Python >= 3.7 (emitting states

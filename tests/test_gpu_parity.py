@@ -756,5 +756,6 @@ def test_repeat_finder_segmentation_equals_the_reference():
     chrom = left + "".join(units) + right
     v = models.ReferenceVNTR(1, f["pattern"], 700, "chr1", None, None, estimated_repeats=len(units))
     models.init_from_vntrseek_data(v, chrom)
-    assert "".join(v.repeat_segments) == "".join(units)[:len(f["pattern"]) * len(units)][:len("".join(v.repeat_segments))]
+    assert len(v.repeat_segments) == len(units) and "".join(v.repeat_segments) == chrom[700:700 + v.get_length()]
+    assert v.repeat_segments[:3] == units[:3]
     assert v.left_flanking_region == left[-500:] and v.right_flanking_region == chrom[700 + v.get_length():][:500]
