@@ -397,6 +397,67 @@ class HiddenMarkovModel(object):
         """A baked model around a model of the native builder (_lib.BuiltModel)."""
         return _BuiltHiddenMarkovModel(built, name)
 
+    # ---- JSON (hmm.pyx:3023-3143; the format of the reference's stored HMMs, vntr_finder.py:124-137) ---------
+    def to_json(self, separators=(',', ' : '), indent=4):
+        import json
+        if self.d == 0:
+            raise ValueError("must bake model before serialising it")
+
+        def state_json(st):
+            dist = None
+            if not st.is_silent():
+                dist = {'class': 'Distribution', 'name': 'DiscreteDistribution',
+                        'parameters': [{str(k): v for k, v in st.distribution.dist.items()}], 'frozen': st.distribution.frozen}
+            return {'class': 'State', 'distribution': dist, 'name': st.name, 'weight': st.weight}
+        index = {st: i for i, st in enumerate(self.states)}
+        if self.graph is not None:
+            triples = [(index[a], index[b], lp) for a, b, lp in self.graph.edges()]
+        else:                                   # a model of the native builder: edges in CSR order
+            a = self.baked_arrays()
+            dst = np.repeat(np.arange(a["m"]), np.diff(a["in_ptr"]))
+            triples = list(zip(a["in_src"].tolist(), dst.tolist(), a["in_logp"].tolist()))
+        edges = [(s_, e_, math.e ** lp, math.e ** lp, None) for s_, e_, lp in triples]
+        model = {'class': 'HiddenMarkovModel', 'name': self.name, 'start': state_json(self.start), 'end': state_json(self.end),
+                 'states': [state_json(st) for st in self.states], 'end_index': self.end_index,
+                 'start_index': self.start_index, 'silent_index': self.silent_start, 'edges': edges,
+                 'distribution ties': []}
+        return json.dumps(model, separators=separators, indent=indent)
+
+    @classmethod
+    def from_json(cls, s, verbose=False):
+        """A model from the reference's JSON (a string, or the name of a file holding one).  As in the reference the
+        loaded graph is baked with the DEFAULT merge ('All'): the probabilities go through one more log, orphan states
+        (among them the fresh model's own start and end) disappear, probability-1 silent states are folded."""
+        import json
+        try:
+            d = json.loads(s)
+        except ValueError:
+            try:
+                with open(s, 'r') as infile:
+                    d = json.load(infile)
+            except (IOError, OSError, ValueError):
+                raise IOError("String must be properly formatted JSON or filename of properly formatted JSON.")
+        model = cls(str(d['name']))
+        states = []
+        for j in d['states']:
+            if j['class'] != 'State':
+                raise IOError("State object attempting to decode {} object".format(j['class']))
+            dist = None
+            if j['distribution'] is not None:
+                if j['distribution'].get('name') != 'DiscreteDistribution':
+                    raise NotImplementedError("only DiscreteDistribution emissions are on adVNTR's path")
+                dist = DiscreteDistribution(j['distribution']['parameters'][0], j['distribution'].get('frozen', False))
+            states.append(State(dist, str(j['name']), j['weight']))
+        for i, j in d.get('distribution ties', []):
+            states[i].tie(states[j])
+        model.add_states(states)
+        model.start = states[d['start_index']]
+        model.end = states[d['end_index']]
+        for start, end, probability, pseudocount, group in d['edges']:
+            model.add_transition(states[start], states[end], probability, pseudocount, group)
+        model.bake(verbose=verbose)
+        return model
+
     # ---- device residency --------------------------------------------------------------------
     def baked_arrays(self):
         """The arrays the C ABI takes (advntr_hmm_create)."""

@@ -113,6 +113,23 @@ def test_repeat_finder_model_equals_the_reference():
         _baked_equals(m, f["model"])
 
 
+def test_model_json_round_trip_equals_the_reference():
+    """HiddenMarkovModel.from_json / to_json (hmm.pyx:3023-3143): the JSON text the reference wrote loads into the model
+    the reference loads from it (default bake: merge='All' folds 11 states of the read matcher), and the mirror's own
+    to_json goes the same way."""
+    from advntr_amd import HiddenMarkovModel
+    g = load_golden("model_json")
+    for case in g["cases"]:
+        m = HiddenMarkovModel.from_json(case["json"])
+        _baked_equals(m, case["loaded"])
+        again = HiddenMarkovModel.from_json(m.to_json())
+        assert [s.name for s in again.states] == case["loaded"]["state_names"]
+    spec = g["cases"][0]["spec"]
+    for native in (True, False):
+        fresh = hmm_utils.get_read_matcher_model(spec["left"], spec["right"], [spec["pattern"]], spec["copies"], native=native)
+        _baked_equals(HiddenMarkovModel.from_json(fresh.to_json()), g["cases"][0]["loaded"])
+
+
 def test_host_path_summaries_on_goldens():
     from advntr_amd.pomegranate import State
     for name in READ_MATCHER_GOLDENS:

@@ -759,3 +759,15 @@ def test_repeat_finder_segmentation_equals_the_reference():
     assert len(v.repeat_segments) == len(units) and "".join(v.repeat_segments) == chrom[700:700 + v.get_length()]
     assert v.repeat_segments[:3] == units[:3]
     assert v.left_flanking_region == left[-500:] and v.right_flanking_region == chrom[700 + v.get_length():][:500]
+
+
+@pytest.mark.gpu
+def test_models_loaded_from_json_score_like_the_reference():
+    """The stored-HMM path (vntr_finder.py:124-137): a model loaded from the reference's JSON scores reads as the
+    reference's loaded model does."""
+    from advntr_amd import HiddenMarkovModel
+    g = load_golden("model_json")
+    for case in g["cases"]:
+        m = HiddenMarkovModel.from_json(case["json"])
+        for r, want in zip(case["reads"], case["logp"]):
+            assert m.viterbi(r)[0] == want, (case["name"], r)
