@@ -7,3 +7,5 @@ MAX_ERROR_RATE = 0.05
 # that way are NOT claimed to equal a muscle-based build.
 ALIGN_REPEATS = False
 TRAINED_MODELS_DB = None        # path of the sqlite `vntrs` database (advntr/settings.py:10); see advntr_amd/models.py
+USE_TRAINED_HMMS = False        # advntr/settings.py:9: load / store per-locus HMMs as JSON (vntr_finder.py:116-138)
+TRAINED_HMMS_DIR = 'vntr_data/'

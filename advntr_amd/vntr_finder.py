@@ -340,10 +340,24 @@ def get_dominant_copy_numbers_from_spanning_reads(left_flanking_region, right_fl
 # reference_vntr: an object with the fields of advntr_amd.models.ReferenceVNTR.
 # ------------------------------------------------------------------------------------------------
 def get_vntr_matcher_hmm(reference_vntr, read_length):
-    """vntr_finder.py:116-138 without the on-disk HMM cache: flanks of read_length bases, copies for that length."""
+    """vntr_finder.py:116-138: flanks of read_length bases, copies for that length.  With settings.USE_TRAINED_HMMS the
+    model is loaded from / stored to `<TRAINED_HMMS_DIR><id>_<read_length>.json` in the reference's JSON format (a loaded
+    model is baked with merging, as in the reference: hmm.pyx:3143)."""
+    import os
+    from . import settings
+    from .pomegranate import HiddenMarkovModel
+    stored = None
+    if getattr(settings, "USE_TRAINED_HMMS", False):
+        stored = settings.TRAINED_HMMS_DIR + str(reference_vntr.id) + '_' + str(read_length) + '.json'
+        if os.path.isfile(stored):
+            return HiddenMarkovModel.from_json(stored)
     copies = get_copies_for_hmm(read_length, len(reference_vntr.pattern))
-    return build_vntr_matcher_hmm(reference_vntr.left_flanking_region, reference_vntr.right_flanking_region,
-                                  reference_vntr.get_repeat_segments(), copies, flanking_region_size=read_length)
+    model = build_vntr_matcher_hmm(reference_vntr.left_flanking_region, reference_vntr.right_flanking_region,
+                                   reference_vntr.get_repeat_segments(), copies, flanking_region_size=read_length)
+    if stored is not None:
+        with open(stored, 'w') as outfile:
+            outfile.write(model.to_json())
+    return model
 
 
 def simulate_true_reads(reference_vntr, read_length):
