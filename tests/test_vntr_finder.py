@@ -93,3 +93,22 @@ def test_recruit_mask_equals_scalar_rule():
         want = summ[i, _lib.SUM_PATH_LEN] > 2 and vntr_finder.recruit_read(float(logp[i]), summ[i], ms, int(lens[i]))
         assert bool(got[i]) == bool(want), i
     assert 0.05 < got.mean() < 0.95
+
+
+def test_reference_genotyping_unit_tests_replayed():
+    """/root/reference/tests/test_genotyping.py, its five cases with their expected values (the reference's own asserts
+    compare against the (genotype, probability) pair the function returns nowadays; the genotypes are what is pinned)."""
+    import numpy as np
+    from advntr_amd import vntr_finder
+
+    def genotype(observed, haploid=False):
+        g = vntr_finder.find_genotype_based_on_observed_repeats(observed, haploid)[0]
+        return tuple(sorted(g))
+    assert genotype([3, 3, 3, 3, 3]) == (3, 3)
+    assert genotype([2, 3, 3, 3, 3], haploid=True) == (3, 3)
+    assert genotype([2, 2, 3, 3, 3]) == (2, 3)
+    assert genotype([4, 5, 5, 5, 7, 8, 8, 8, 9]) == (5, 8)
+    # test_recruit_read_for_positive_read: an empty path has flank match rate 1, the score clears the threshold
+    empty = np.zeros(8, np.int32)
+    assert vntr_finder.recruit_read(-20, empty, -50, 100) is True
+    assert vntr_finder.recruit_read(-60, empty, -50, 100) is False
