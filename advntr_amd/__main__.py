@@ -18,7 +18,6 @@ import argparse
 import json
 import sys
 
-import numpy as np
 
 
 def _read_fasta(path):
@@ -74,7 +73,7 @@ def genotype(args):
         if args.outfmt == "bed":
             sys.stdout.write(genome_analyzer.bed_header(args.haploid))
         elif args.outfmt == "vcf":
-            sys.stdout.write(genome_analyzer.vcf_header([loc["vntr"] for loc in loci], args.reads))
+            sys.stdout.write(genome_analyzer.vcf_header([loc["vntr"] for loc in loci], args.reads or args.alignment))
 
     def row(loc, result):
         return genome_analyzer.genotype_row(args.outfmt, loc["vntr"], loc["id"], result, False, args.haploid)
@@ -83,7 +82,13 @@ def genotype(args):
         if rows is not None:
             sys.stdout.write("".join(rows))
         return 0
-    names, seqs = _read_fasta(args.reads)
+    names, seqs = _read_fasta(args.reads) if args.reads else ([], [])
+    samfile = None
+    if args.alignment:     # SAM text (`samtools view -h`): mapped reads are selected per locus, unmapped ones join --reads
+        from . import sam_utils
+        with open(args.alignment) as fh:
+            samfile = sam_utils.parse_sam(fh.read())
+        seqs = seqs + [r.seq for r in samfile.reads if r.is_unmapped]
     settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
     if args.pacbio:
         def pacbio_job(indices):
@@ -107,7 +112,8 @@ def genotype(args):
     rc = "".join(">%d\n%s\n" % (i, vntr_finder.reverse_complement(s.upper()) if "N" not in s.upper() else s.upper())
                  for i, s in enumerate(seqs))
     _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
-    read_length = int(np.median([len(s) for s in seqs[:5]])) if seqs else 150     # vntr_finder.py:714-718
+    head = [len(r.seq) for r in samfile.head(5)] if samfile is not None else [len(s) for s in seqs[:5]]
+    read_length = sorted(head)[len(head) // 2] if head else 150                   # vntr_finder.py:714-718
     def candidates(loc):
         vid = int(loc["id"])
         return [seqs[i] for i in sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))]
@@ -129,6 +135,14 @@ def genotype(args):
         specs = [(loci[i]["left"][-read_length:], loci[i]["right"][:read_length], loci[i]["repeat_segments"],
                   vntr_finder.get_copies_for_hmm(read_length, len(loci[i]["pattern"]))) for i in indices]
         built = hmm_utils.build_read_matcher_models(specs)
+        if samfile is not None:     # vntr_finder.py:701-767: mapped reads over the locus + the filtered unmapped ones
+            for i in indices:
+                loci[i]["vntr"].scaled_score = loci[i].get("scaled_score")
+            picked, _ = vntr_finder.select_illumina_reads_multi([loci[i]["vntr"] for i in indices], samfile,
+                                                                [cands[i] for i in indices], models=built)
+            return [row(loci[i], vntr_finder.find_repeat_count_from_selected_reads(
+                [s.summary for s in sel], accuracy_filter=args.accuracy_filter, is_haploid=args.haploid))
+                for i, sel in zip(indices, picked)]
         scored_all = vntr_finder.score_reads_multi(built, [cands[i] for i in indices],
                                                    [loci[i].get("scaled_score") for i in indices], True)
         out = []
@@ -195,7 +209,9 @@ def main(argv=None):
     g.add_argument("--vntr-id", type=int, action="append", help="with --models: genotype only these ids")
     g.add_argument("--align-repeats", action="store_true",
                    help="align repeat segments of unequal length with the built-in aligner (instead of refusing them)")
-    g.add_argument("--reads", required=True)
+    g.add_argument("--reads", help="FASTA / FASTQ of extracted reads")
+    g.add_argument("--alignment", help="SAM text of the sample (e.g. `samtools view -h sample.bam`): mapped reads over each "
+                                       "VNTR are selected as vntr_finder.py:701-750 does, unmapped records are added to --reads")
     g.add_argument("--pacbio", action="store_true", help="reads are trimmed spanning long reads (error rate 0.3)")
     g.add_argument("--extract-spanning", action="store_true",
                    help="with --pacbio: the reads are whole long reads; find the ones that span each VNTR by aligning its "
@@ -209,6 +225,10 @@ def main(argv=None):
                    help="result rows as the reference writes them (genome_analyzer.py:28-170)")
     args = ap.parse_args(argv)
     if args.cmd == "genotype":
+        if not args.reads and not args.alignment:
+            ap.error("genotype needs --reads and/or --alignment")
+        if args.alignment and (args.pacbio or args.frameshift):
+            ap.error("--alignment is the Illumina copy-number path")
         try:
             return genotype(args)
         finally:

@@ -9,3 +9,8 @@ ALIGN_REPEATS = False
 TRAINED_MODELS_DB = None        # path of the sqlite `vntrs` database (advntr/settings.py:10); see advntr_amd/models.py
 USE_TRAINED_HMMS = False        # advntr/settings.py:9: load / store per-locus HMMs as JSON (vntr_finder.py:116-138)
 TRAINED_HMMS_DIR = 'vntr_data/'
+# read filters of the mapped-read loop (advntr/settings.py:24-27,34)
+QUALITY_SCORE_CUTOFF = 20
+LOW_QUALITY_BP_TO_DISCARD_READ = 0.10
+MAPQ_CUTOFF = 0
+MIN_READ_LENGTH = None

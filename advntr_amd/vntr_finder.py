@@ -627,3 +627,89 @@ def update_model_from_reads(model, left_flanking_region, right_flanking_region, 
     copies = get_copies_for_hmm(read_length, len(pattern))
     return get_read_matcher_model(left_flanking_region[-read_length:], right_flanking_region[:read_length], None, copies,
                                   vpaths)
+
+
+# ------------------------------------------------------------------------------------------------
+# Read selection from an alignment file (vntr_finder.py:701-767): mapped reads over the locus + filtered unmapped reads
+# ------------------------------------------------------------------------------------------------
+class SelectedRead(object):
+    """vntr_finder.py:46-53 (the Viterbi path is replaced by the kernel's summary record; reference_start is kept, the
+    reference only keeps whether there was one)."""
+    __slots__ = ("sequence", "logp", "summary", "mapq", "reference_start", "query_name", "is_mapped")
+
+    def __init__(self, sequence, logp, summary, mapq=None, reference_start=None, query_name=None):
+        self.sequence, self.logp, self.summary = sequence, logp, summary
+        self.mapq, self.reference_start, self.query_name = mapq, reference_start, query_name
+        self.is_mapped = reference_start is not None
+
+
+def select_illumina_reads(reference_vntr, samfile, unmapped_filtered_reads):
+    """VNTRFinder.select_illumina_reads on a parsed alignment (advntr_amd.sam_utils.SamFile) and the sequences of the
+    keyword-filtered unmapped reads.  Read length = median of the file's first five reads; mapped reads overlapping the
+    VNTR (not unmapped/duplicate, at least 0.9 read lengths long, no N) are scored on the forward strand and kept if
+    they are not low quality (utils.py:20-38) and recruit_read accepts them; unmapped reads of at least the read length
+    go through process_unmapped_read (both strands, > 2 repeat bases).  All of it is ONE engine batch.  Returns
+    (selected reads, the model): mapped reads first, in file order, then the unmapped ones, as the reference appends
+    them."""
+    selected, models = select_illumina_reads_multi([reference_vntr], samfile, [unmapped_filtered_reads])
+    return selected[0], models[0]
+
+
+def select_illumina_reads_multi(reference_vntrs, samfile, unmapped_lists, models=None):
+    """select_illumina_reads for many loci over one alignment: every (read, strand, locus) call of all loci goes to the
+    engine as one batch.  `models` (one per locus, built for the file's read length) are built here when not given.
+    Returns (list of selected-read lists, models)."""
+    from . import settings
+    from .sam_utils import get_reference_genome_of_alignment_file, is_low_quality_read
+    reference = get_reference_genome_of_alignment_file(samfile)
+    lengths = sorted(len(r.seq) for r in samfile.head(5))
+    read_length = lengths[len(lengths) // 2]
+    min_read_length = int(read_length * 0.9) if settings.MIN_READ_LENGTH is None else settings.MIN_READ_LENGTH
+    if models is None:
+        models = [get_vntr_matcher_hmm(v, read_length) for v in reference_vntrs]
+    batch, which, layout = [], [], []
+    for i, (vntr, unmapped_reads) in enumerate(zip(reference_vntrs, unmapped_lists)):
+        vntr_start = vntr.start_point
+        vntr_end = vntr_start + vntr.get_length()
+        chromosome = vntr.chromosome if reference == 'HG19' else vntr.chromosome[3:]
+        mapped = []
+        for read in samfile.fetch(chromosome, vntr_start, vntr_end):
+            if read.is_unmapped or read.is_duplicate or len(read.seq) < min_read_length:
+                continue
+            read_end = read.reference_end if read.reference_end else read.reference_start + len(read.seq)
+            if vntr_start - read_length < read.reference_start < vntr_end or vntr_start < read_end < vntr_end:
+                if read.seq.count('N') <= 0:
+                    mapped.append(read)
+        unmapped = [str(s) for s in unmapped_reads if len(s) >= read_length and str(s).count('N') <= 0]
+        start = len(batch)
+        batch += [r.seq.upper() for r in mapped]
+        fwd = [s.upper() for s in unmapped]
+        batch += fwd
+        batch += [reverse_complement(s) for s in fwd]
+        which += [i] * (len(batch) - start)
+        layout.append((start, mapped, len(unmapped)))
+    out = [[] for _ in reference_vntrs]
+    if not batch:
+        return out, models
+    bases, off = _lib.encode_reads(batch)
+    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, np.asarray(which, np.int32),
+                                       want_paths=False, want_summary=True)
+    for i, (start, mapped, nu) in enumerate(layout):
+        score = get_min_score_to_select_a_read(reference_vntrs[i].scaled_score, read_length)
+        selected = out[i]
+        for k, read in enumerate(mapped):
+            a = start + k
+            if summ[a][_lib.SUM_PATH_LEN] <= 2 or is_low_quality_read(read):
+                continue
+            if recruit_read(float(logp[a]), summ[a], score, len(batch[a])):
+                selected.append(SelectedRead(batch[a], float(logp[a]), summ[a], read.mapq, read.reference_start, read.query_name))
+        first = start + len(mapped)
+        for j in range(nu):
+            a = first + j
+            if logp[a] < logp[first + nu + j]:
+                a = first + nu + j
+            if summ[a][_lib.SUM_PATH_LEN] <= 2:
+                continue
+            if recruit_read(float(logp[a]), summ[a], score, len(batch[a])) and summ[a][_lib.SUM_REPEAT_BP] > 2:
+                selected.append(SelectedRead(batch[a], float(logp[a]), summ[a]))
+    return out, models
