@@ -43,7 +43,7 @@ struct ColClass {             // 11 doubles = 88 B: an odd multiple of 8 B, so r
 
 struct ColInfo {              // 16 B per column (with one dummy column at either end)
     double v0b;               // row-0 value of b_c (read independent)
-    uint16_t tclass, emM, emI, flags;   // flags: COL_FLAG_* | sink index << 4
+    uint16_t tclass, emM, emI, flags;   // flags: COL_FLAG_* | sink index << 4 (sink column) | fed sink's index << 8 (feeder)
 };
 
 struct ColState {             // 16 B per column: state indices for the traceback
@@ -354,7 +354,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
                     if (pos[s] <= lastpos) return fail("silent fan-in not in column order");
                     lastpos = pos[s];
                     if (flags[pos[s]] & COL_FLAG_FEED) return fail("backbone state feeds two fan-in states");
-                    flags[pos[s]] |= COL_FLAG_FEED;
+                    flags[pos[s]] |= COL_FLAG_FEED | (uint16_t)(n_sinks << 8);
                     feed_sink[pos[s]] = n_sinks;
                     percol[pos[s]].erw = in_logp[k];
                 }
@@ -369,7 +369,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         int cur = -1;
         for (int c = 0; c < NC; ++c) {
             if (flags[c] & COL_FLAG_SINK) {
-                const int sidx = flags[c] >> 4;
+                const int sidx = (flags[c] >> 4) & 15;
                 if (cur != -1 && cur != sidx) return fail("interleaved fan-in ranges");
                 cur = -1;
             }
@@ -426,7 +426,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         if (it != emap.end()) return it->second;
         const int id = (int)(out.emis.size() / COL_EMIS_STRIDE);
         out.emis.insert(out.emis.end(), e4, e4 + 4);
-        out.emis.push_back(0.0);
+        out.emis.push_back(NINF);        // 5th slot: the emission of a padding row (viterbi_rows.h)
         emap[key] = id;
         return id;
     };

@@ -468,7 +468,7 @@ struct advntr_batch {
     int64_t *d_path_off = nullptr;
     uint8_t *d_bp_gen = nullptr;
     int32_t *d_pathbuf_gen = nullptr, *d_pathbuf_col = nullptr;
-    int32_t *d_counter = nullptr;       // [0]: generic dequeue head, [4..7]: tile heads per chunk count
+    int32_t *d_counter = nullptr;       // [0]: generic dequeue head, [3..8]: tile heads of the column kernels' lists
     int32_t path_cap = 0;
     int device = 0;
     std::vector<std::pair<void *, size_t>> allocs;
@@ -543,7 +543,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     if (n_reads) HIP_TRY(hipMemcpy(B->d_read_model, read_model, (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_logp, (size_t)n_reads))) return rc;
     if ((rc = B->dmalloc(&B->d_summary, (size_t)n_reads * ADVNTR_SUMMARY_INTS))) return rc;
-    if ((rc = B->dmalloc(&B->d_counter, 8))) return rc;
+    if ((rc = B->dmalloc(&B->d_counter, 12))) return rc;
 
     // split: reads the anti-diagonal kernel can take vs. the generic kernel
     std::vector<int32_t> col_reads, gen_reads;
@@ -560,7 +560,20 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     }
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
     // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read
-    auto kof = [&](int r) { return (int)std::min<int64_t>(5, (read_off[r + 1] - read_off[r] + 63) / 64); };
+    // bucket 0 = short reads of a large batch: row-blocked kernel (viterbi_rows.h), ROWS_G reads per wavefront.  Small
+    // batches (a locus-sized call) stay on the one-read-per-wavefront kernel, which spreads them over more CUs.
+    int64_t n_short = 0, rows_lo = ROWS_MIN_READ;
+    if (const char *e = getenv("ADVNTR_ROWS_MIN_READ")) rows_lo = atoll(e);          // (tests: route every short read)
+    auto rows_len = [&](int64_t n) { return n >= rows_lo && n <= ROWS_MAX_READ; };
+    for (int r : col_reads) n_short += rows_len(read_off[r + 1] - read_off[r]);
+    int64_t rows_min = 4096;
+    if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
+    const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
+    auto kof = [&](int r) {
+        const int64_t n = read_off[r + 1] - read_off[r];
+        if (use_rows && rows_len(n)) return 0;
+        return (int)std::min<int64_t>(5, (n + 63) / 64);
+    };
     {   // one 64-bit key per read (bucket | model | inverted length), index in the low bits keeps the sort stable
         std::vector<std::pair<uint64_t, int32_t>> keyed(col_reads.size());
         for (size_t i = 0; i < col_reads.size(); ++i) {
@@ -610,7 +623,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     if (B->n_col) {
         ColumnLaunch &C = B->col;
         C.stream = (flags & ADVNTR_FLAG_STREAM) != 0;
-        int n_max_col = 0;
+        int n_max_col = 0, rows_groups = 1;
         size_t lds_core = 0, lds_min = 0;
         for (int r : col_reads) {
             const advntr_hmm *H = B->models[read_model[r]];
@@ -658,9 +671,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
+                if (K == 0) cap = std::max<int>(COL_WAVES * ROWS_G, cap * ROWS_G / 2);        // ROWS_G reads per wavefront
                 int j = i;
                 while (j < B->n_col && j - i < cap && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
-                C.tiles[K - 1].push_back(ColTile{mod, i, j - i, 0});
+                C.tiles[K == 0 ? 5 : K - 1].push_back(ColTile{mod, i, j - i, 0});
                 i = j;
             }
             const int kmax = std::min(4, (n_max_col + 63) / 64);
@@ -670,9 +684,15 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             C.bp_stride = (std::max(short_bp, long_bp) + 255) & ~int64_t(255);
             C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
             C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
+            if (!C.tiles[5].empty()) {        // row-blocked kernel: ROWS_G reads per wave, ceil(R/5) dwords per lane and step
+                const int64_t rows_bp = (int64_t)(C.nc_max + 64 / ROWS_G + 1) * 64 * ((ROWS_R + 4) / 5) * 4;
+                C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
+                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_G * (3 * ((int64_t)C.nc_max + 2 * (64 / ROWS_G)) + COL_MAX_TAIL));
+                rows_groups = ROWS_G;
+            }
         }
         size_t n_tiles = 0;
-        for (int k = 0; k < 5; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
+        for (int k = 0; k < 6; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
         // back-pointer scratch of all resident waves: at most 60 % of the free HBM (288 GB per MI355X: 4 096 resident
         // waves x 25 MB for 15-kb reads on a 1 440-column model still fit); beyond that, fewer resident waves
@@ -680,13 +700,13 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
         const int64_t bp_budget = (int64_t)(free_b / 10 * 6) + (int64_t)g_cache.cached[B->device];
         while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > bp_budget) C.grid = (C.grid + 1) / 2;
-        C.aux_stride = COL_MAX_TAIL + (int64_t)COL_MAX_SINKS * C.sink_stride;
+        C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
         if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 6; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
             HIP_TRY(hipMemcpy(C.d_tiles[k], C.tiles[k].data(), C.tiles[k].size() * sizeof(ColTile), hipMemcpyHostToDevice));
@@ -781,7 +801,7 @@ extern "C" int advntr_batch_run(advntr_batch *B)
 {
     if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_run: null batch");
     if (B->n_reads == 0) return ADVNTR_OK;
-    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 8 * sizeof(int32_t), B->stream));
+    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 12 * sizeof(int32_t), B->stream));
     if (B->n_col) {
         BatchArgs a = make_args(B);
         a.n_reads = B->n_col;
@@ -795,6 +815,7 @@ extern "C" int advntr_batch_run(advntr_batch *B)
             column_launch_k<3, false>(B->col, a, B->flags, B->stream);
             column_launch_k<4, false>(B->col, a, B->flags, B->stream);
             column_launch_k<COL_LONG_K, true>(B->col, a, B->flags, B->stream);
+            column_launch_rows(B->col, a, B->flags, B->stream);
         }
     }
     if (B->n_gen) {
@@ -892,7 +913,7 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                          (flags | ADVNTR_FLAG_NO_SUMMARY) & ~(ADVNTR_FLAG_PATH | ADVNTR_FLAG_STREAM));
     if (rc == ADVNTR_OK && n_reads) {
         rc = [&]() -> int {
-            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 8 * sizeof(int32_t), B->stream));
+            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 12 * sizeof(int32_t), B->stream));
             if (B->n_col) {               // reads of models with a column program: sum-product on the anti-diagonal sweep
                 BatchArgs a = make_args(B);
                 a.n_reads = B->n_col;
@@ -902,6 +923,7 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 column_launch_fwd<3, false>(B->col, a, B->stream, 2);
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3);      // 193-256 rows: two row tiles
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4);
+                column_launch_fwd<3, false>(B->col, a, B->stream, 5);               // the row-blocked kernel's list (<= 160 rows)
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

@@ -335,7 +335,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         if (fl & COL_FLAG_SINK) {
             vB = R.er[k];                                            // fan-in column: the traceback reads the winner
                                                                      // from sinkbp whatever the byte's B bits say
-            if (t <= C.n_tile) C.sinkbp[(fl >> 4) * C.sink_stride + C.row0 + t] = R.erwin[k];   // padding rows own no slot
+            if (t <= C.n_tile) C.sinkbp[((fl >> 4) & 15u) * C.sink_stride + C.row0 + t] = R.erwin[k];   // padding rows own no slot
             R.er[k] = -INFINITY;
         }
         if (fl & COL_FLAG_FEED) {
@@ -516,25 +516,18 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 // are dominated by match->match moves, i.e. runs along a trellis diagonal: for those, the 64 lanes gather the
 // back-pointer bytes of (t-i, c-i), i = 0..63, in one round trip, a ballot gives the length of the M->M run
 // and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
-template <int K>
-__device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
-                                             const int start_state, const int P, const uint8_t *__restrict__ bp,
-                                             const int64_t slab, const int sink_stride,
-                                             const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                             int32_t *__restrict__ rev, const int cap, const int lane,
-                                             const int U0 = 0, const int ring = 1 << 30, const int W = 1 << 30)
+// bp_at(t, c) -> back-pointer byte of cell (t, c): the layout of the back-pointer store belongs to the sweep that wrote it
+template <class BpAt>
+__device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
+                                                  const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
+                                                  const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                                  int32_t *__restrict__ rev, const int cap, const int lane,
+                                                  const int U0, const int W)
 {
-    constexpr int TPAD = 64 * K;
     const uint8_t *base = (const uint8_t *)cp;
     const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
     const int32_t *tstate = (const int32_t *)(base + cp->off_tail_state);
     const int32_t *pred0 = (const int32_t *)(base + cp->off_pred0);
-    // read row tt is stream row U0+tt-1; row tiles of 64K rows, slabs reused modulo `ring`
-    auto bp_at = [&](int tt, int cc) -> int {
-        const int u = U0 + tt - 1;
-        const int tile = u / TPAD, lt = u - tile * TPAD + 1;
-        return bp[(tile % ring) * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];
-    };
     int len = 0;
     int ti = cp->end_tail, t = n, c = 0, slot = 0;
     // tail states (all in row n)
@@ -598,7 +591,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
         const int byte = bp_at(t, c);
         {
             const int p = (L.info0[c + 1].flags & COL_FLAG_SINK) ? 3 : bp_ptr_B(byte);
-            if (p == 3) c = sinkbp[(L.info0[c + 1].flags >> 4) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
+            if (p == 3) c = sinkbp[((L.info0[c + 1].flags >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
             else { c -= 1; slot = p; }
         }
     }
@@ -612,6 +605,24 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
     if (lane == 0) rev[len] = start_state;
     ++len;
     return len;
+}
+
+template <int K>
+__device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
+                                             const int start_state, const int P, const uint8_t *__restrict__ bp,
+                                             const int64_t slab, const int sink_stride,
+                                             const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                             int32_t *__restrict__ rev, const int cap, const int lane,
+                                             const int U0 = 0, const int ring = 1 << 30, const int W = 1 << 30)
+{
+    constexpr int TPAD = 64 * K;
+    // read row tt is stream row U0+tt-1; row tiles of 64K rows, slabs reused modulo `ring`
+    auto bp_at = [&](int tt, int cc) -> int {
+        const int u = U0 + tt - 1;
+        const int tile = u / TPAD, lt = u - tile * TPAD + 1;
+        return bp[(tile % ring) * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];
+    };
+    return col_traceback_walk(cp, L, n, start_state, P, bp_at, sink_stride, tailwin, sinkbp, rev, cap, lane, U0, W);
 }
 
 // Copy a model's class tables into LDS and build the padded info table (64*K dummy columns on either side, so a
@@ -661,6 +672,28 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
     return padded;
 }
 
+// summary record and (optionally) the path of one read, from the reversed path in `rev`
+__device__ __forceinline__ void col_emit_outputs(const ColArgs &g, const uint32_t flags, const DevModel &M, const int r,
+                                                 const uint8_t *__restrict__ seq, const int n, const int32_t *__restrict__ rev,
+                                                 const int len, const int lane)
+{
+    if (g.a.out_summary && !(flags & 4u)) {
+        int32_t *out = g.a.out_summary + (int64_t)r * 8;
+        if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);
+        else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
+    }
+    if (g.a.out_path && (flags & 1u)) {
+        const int64_t o0 = g.a.out_path_off[r];
+        const int cap = (int)(g.a.out_path_off[r + 1] - o0);
+        int olen = len;
+        if (len > cap) olen = -2;
+        if (olen > 0)
+            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
+        if (lane == 0) g.a.out_path_len[r] = olen;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Everything after the sweep of one read: tail states, traceback, summaries, outputs.
 template <int K>
 __device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
@@ -684,21 +717,7 @@ __device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t
 #endif
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    if (g.a.out_summary && !(flags & 4u)) {
-        int32_t *out = g.a.out_summary + (int64_t)r * 8;
-        if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);
-        else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
-    }
-    if (g.a.out_path && (flags & 1u)) {
-        const int64_t o0 = g.a.out_path_off[r];
-        const int cap = (int)(g.a.out_path_off[r + 1] - o0);
-        int olen = len;
-        if (len > cap) olen = -2;
-        if (olen > 0)
-            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
-        if (lane == 0) g.a.out_path_len[r] = olen;
-    }
-    __builtin_amdgcn_wave_barrier();
+    col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
 }
 
 // LONG = reads longer than 64*K rows, processed in row tiles of 64*K rows (K = 4).

@@ -1,0 +1,292 @@
+// viterbi_rows.h -- row-blocked variant of the column-program Viterbi sweep for short reads.
+//
+// Same recurrence, same arithmetic and same comparison order as viterbi_columns.h (and therefore as the reference,
+// /root/reference/pomegranate/hmm.pyx:2026-2083); what changes is the mapping of the trellis onto the wavefront:
+//
+//   * a lane owns R CONSECUTIVE rows (t = R*l + 1 .. R*l + R) instead of one row per 64-row chunk, and at step s works
+//     on column c = s - l for all of them.  The previous row of a lane's 2nd..Rth row is the lane's own register, so a
+//     step needs ONE cross-lane shift (3 fp64 = 6 DPP moves) for R cells instead of one (6-12 moves) per cell, and the
+//     column's info word and 88-B transition class are read from LDS once per R cells (the anti-diagonal kernel is
+//     co-limited by VALU issue and LDS reads);
+//   * the skew of the systolic sweep is one column per LANE, not per row: G reads share a wavefront, each in a group of
+//     W = 64/G lanes (G = 4: a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
+//     operand = the row-0 boundary, so groups need no fix-up at all), and a 150-base read costs (NC + 15) steps of 10
+//     cells on 16 lanes: 91 % of the lane-steps do useful work instead of 70 %;
+//   * the six comparison outcomes of a cell are shifted into a running word across the lane's rows (relax_bit's
+//     add-with-carry chain simply continues into the next cell): 5 cells = 30 bits per dword, one 8-byte store per lane
+//     and step instead of one byte store per cell.
+//
+// Reads of a tile go G at a time to a wavefront; after the sweep the wave finishes them one by one (tail states,
+// cooperative traceback, path summary) with the code of viterbi_columns.h.
+#pragma once
+#include "viterbi_columns.h"
+
+// Measured on the bench workload (100 k reads of 150 bases, 453-column model; kernel ms per launch; the anti-diagonal
+// kernel: 16.5):  R = 5, G = 2 at 3 waves/SIMD 11.3 (no spill inside the sweep loop); at 4 waves/SIMD (128 VGPRs) 12.6:
+// the loop then reloads spilled values, and on gfx9 a vector-memory load waits behind the back-pointer stores in the
+// same counter;  R = 10, G = 4 needs 256 VGPRs (2 waves/SIMD) 13.2, with 3 waves it spills 22.3.
+#ifndef ROWS_R
+#define ROWS_R 5                    // rows per lane
+#endif
+#ifndef ROWS_G
+#define ROWS_G 2                    // reads per wavefront
+#endif
+#ifndef ROWS_WAVES_PER_SIMD
+#define ROWS_WAVES_PER_SIMD 3
+#endif
+// longest read the kernel takes (G = 2: the group's last lane stays a padding lane, see rows_sweep)
+#define ROWS_MAX_READ (ROWS_R * (64 / ROWS_G - (ROWS_G == 2 ? 1 : 0)))
+// shorter reads stay on the anti-diagonal kernel: a read of up to 128 bases takes two 64-row chunks there, which costs
+// about what R * 32 lanes cost here; one of up to 64 bases half of that
+#ifndef ROWS_MIN_READ
+#define ROWS_MIN_READ 129
+#endif
+#define ROWS_TILE_READS (8 * ROWS_G)
+
+template <int G>
+__device__ __forceinline__ int rows_shr1(const int old, const int src)
+{
+    // lane i <- src[i-1] inside the read's lane group; the group's first lane keeps `old`
+    if (G >= 4) return __builtin_amdgcn_update_dpp(old, src, 0x111, 0xf, 0xf, false);       // row_shr:1 (16-lane rows)
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);                   // wave_shr:1
+}
+template <int G>
+__device__ __forceinline__ double rows_shift(const double v, const double inject)
+{
+    const int lo = rows_shr1<G>(__double2loint(inject), __double2loint(v));
+    const int hi = rows_shr1<G>(__double2hiint(inject), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// back-pointer byte of cell (t, c) in the row-blocked layout: R rows per lane, ceil(R/5) dwords per lane and step
+template <int R>
+__device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc)
+{
+    constexpr int WORDS = (R + 4) / 5;
+    const int lp = (tt - 1) / R, k = (tt - 1) - lp * R;
+    const int w = k / 5, j = k - 5 * w;
+    const int cnt = (R - 5 * w) < 5 ? (R - 5 * w) : 5;
+    const unsigned word = bpw[((int64_t)(cc + lp) * 64 + lane0 + lp) * WORDS + w];
+    return (int)((word >> (6 * (cnt - 1 - j))) & 63u);
+}
+
+template <int R, int G>
+__device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, const int s_end,
+                                           const uint8_t *__restrict__ seq, const int n, const int lp, const int lane,
+                                           unsigned *__restrict__ bpw, double *__restrict__ rown, const unsigned cap_base,
+                                           int32_t *__restrict__ aux, const unsigned sink_base, const int sink_stride)
+{
+    constexpr int W = 64 / G, WORDS = (R + 4) / 5;
+    double I[R], M[R], B[R], er[R];
+    unsigned xp[(R + 3) / 4];          // byte k: 8 * base code of the lane's kth row (offset into an emission record)
+#pragma unroll
+    for (int q = 0; q < (R + 3) / 4; ++q) xp[q] = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        I[k] = M[k] = B[k] = er[k] = -INFINITY;
+        const int t = R * lp + k + 1;
+        // rows past the read take the emission records' 5th slot, -inf: they stay at -inf in every state, so what the
+        // group's last lane hands to the next group's first (G = 2: wave_shr crosses the boundary) is the row-0 value
+        // of I and M already
+        xp[k / 4] |= (unsigned)((t <= n) ? 8 * (int)seq[t - 1] : 32) << (8 * (k % 4));
+    }
+    auto xof = [&](const int k) { return (xp[k / 4] >> (8 * (k % 4))) & 0xffu; };
+    // the lane that holds the read's last row, and the slot it sits in
+    const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
+    const bool first_lane = lp == 0;
+    const bool fix = G == 2 && lane == 32;
+    // shifted I / M values of the even and the odd steps: a DPP shift writes over its `old` operand, and the previous
+    // step's shifted values are still needed (diagonal inputs of the lane's first row), so the two parities own a
+    // register pair each -- whose group-first lanes hold the row-0 value -inf for the whole sweep, since the shift
+    // never writes them -- and no copy is made
+    double nIa = -INFINITY, nMa = -INFINITY, nIb = -INFINITY, nMb = -INFINITY, pB = -INFINITY;
+    unsigned pa = L.pinfo + (unsigned)(64 - lp) * 16u;          // padded info record of column c = -lp (64 dummies in front)
+    uint2 meta = lds_uint2(pa + 8u);
+    double v0b = *(LdsDouble *)(size_t)pa;
+    // row-n capture of column c at rown[cap_off + 3 * c]; back-pointer words at bpw[bp_off + 64 * WORDS * s]: 32-bit
+    // offsets from wave-uniform bases (scalar base + vector offset addressing, no 64-bit pointer arithmetic per step)
+    unsigned cap_off = cap_base + (unsigned)(W - lp) * 3u;
+    unsigned bp_off = (unsigned)lane * WORDS;
+    int c = -lp;                                                // this lane's column
+    const unsigned win0 = 4u * (sink_base + (unsigned)(R * lp + 1));
+    auto step = [&](double &nIcur, double &nMcur, const double pI, const double pM) {
+        pa += 16u;
+        const uint2 meta_next = lds_uint2(pa + 8u);
+        const double v0b_next = *(LdsDouble *)(size_t)pa;
+        LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
+        const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
+        const unsigned eM0 = meta.y & 0xffffu, eI0 = meta.y >> 16;
+        // last row of the neighbouring lane at the previous step = row above this lane's first row, same column
+        const double nI = nIcur = rows_shift<G>(I[R - 1], nIcur);
+        const double nM = nMcur = rows_shift<G>(M[R - 1], nMcur);
+        double nB = rows_shift<G>(B[R - 1], v0b);                // row 0 is read independent (host precomputed)
+        if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;        // (I and M arrive as -inf from the padding lane)
+        const unsigned fl = meta.x >> 16;
+        const bool anysink = __ballot((fl & COL_FLAG_SINK) != 0) != 0;      // wave-uniform, rare
+        // Fan-in (hmm.pyx order: the first maximum over the feeders, in column order): every row keeps the running
+        // maximum `er`; a feeder that beats it writes its column straight into the sink's back-pointer slot of that row
+        // (later winners overwrite earlier ones), so no winner register is carried.  Lanes that are not on a feeder
+        // column carry weight -inf and never win.
+        const double erw = (fl & COL_FLAG_FEED) ? T->erw : -INFINITY;
+        const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
+        int bits[WORDS];
+        double upI = nI, upM = nM, upB = nB, dgI = pI, dgM = pM, dgB = pB;
+        // emission log-probs are fetched one cell ahead
+        double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
+        double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int w = k / 5;
+            const double eI = eI_next, eM = eM_next;
+            if (k + 1 < R) {
+                eI_next = *(LdsDouble *)(size_t)(eI0 + xof(k + 1));
+                eM_next = *(LdsDouble *)(size_t)(eM0 + xof(k + 1));
+            }
+            const double oI = I[k], oM = M[k], oB = B[k];
+            // I_c(t) <- [I_c, M_c, b_c](t-1)
+            double vI = (upI + iI) + eI;
+            if (k % 5 == 0) relax_bit_first(vI, bits[w], (upM + iM) + eI);
+            else relax_bit(vI, bits[w], (upM + iM) + eI);
+            relax_bit(vI, bits[w], (upB + iD) + eI);
+            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there
+            double vM = (dgI + mI) + eM;
+            double cM = dgM + mM;
+            if (k == 0) cM = first_lane ? T->mX : cM;
+            relax_bit(vM, bits[w], cM + eM);
+            relax_bit(vM, bits[w], (dgB + mD) + eM);
+            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)
+            double vB = oI + dI;
+            relax_bit(vB, bits[w], oM + dM);
+            relax_bit(vB, bits[w], oB + dD);
+            if (anysink) {
+                asm volatile("; fan-in column" ::);              // keeps this a (wave-uniform) branch, not four selects per cell
+                const bool sk = (fl & COL_FLAG_SINK) != 0;
+                vB = sk ? er[k] : vB;
+                er[k] = sk ? -INFINITY : er[k];
+            }
+            {
+                const double cand = vB + erw;
+                const bool won = cand > er[k];
+                asm("v_max_f64 %0, %0, %1" : "+v"(er[k]) : "v"(cand));        // (fmax() adds two canonicalising self-maxima)
+                if (won) *(int32_t *)((char *)aux + (win + 4u * k)) = c;
+            }
+            I[k] = vI; M[k] = vM; B[k] = vB;
+            if (kcap == k) { rown[cap_off] = vI; rown[cap_off + 1] = vM; rown[cap_off + 2] = vB; }
+            upI = vI; upM = vM; upB = vB;
+            dgI = oI; dgM = oM; dgB = oB;
+        }
+        pB = nB;
+#ifndef EXP_NO_BP
+        if (WORDS == 1) bpw[bp_off] = (unsigned)bits[0];
+        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
+        else {
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = (unsigned)bits[w];
+        }
+#endif
+        bp_off += 64 * WORDS;
+        cap_off += 3u;
+        ++c;
+        meta = meta_next;
+        v0b = v0b_next;
+    };
+    // two steps per loop iteration: the rotation of the loop-carried row values (a cell's old values stay live for the
+    // row below while its new ones are produced) becomes register renaming instead of ~3 moves per cell
+    int s = 0;
+    for (; s < s_end; s += 2) { step(nIa, nMa, nIb, nMb); step(nIb, nMb, nIa, nMa); }
+    if (s == s_end) step(nIa, nMa, nIb, nMb);
+}
+
+// tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group
+template <int R>
+__device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
+                                                 const LdsTables &L, const DevModel &M, const int r,
+                                                 const uint8_t *__restrict__ seq, const int n, double *final_row,
+                                                 const unsigned *__restrict__ bpw, const int lane0,
+                                                 int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                                 int32_t *__restrict__ rev, const int lane)
+{
+    const int NC = cp->n_cols;
+    const double logp = col_tail(cp, final_row, tailwin, NC, lane);
+    if (lane == 0) g.a.out_logp[r] = logp;
+    int len = 0;
+    if (logp != -INFINITY) {
+        auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
+        len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
+                                 1 << 30);
+        len = __builtin_amdgcn_readfirstlane(len);
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
+}
+
+template <int R, int G>
+__global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
+viterbi_rows_kernel(ColArgs g, uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int W = 64 / G;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
+    int32_t *tile_slot = (int32_t *)lds;
+    uint8_t *tables = lds + 16;
+    unsigned *bpw = (unsigned *)(g.bp + gw * g.bp_stride);
+    double *rown = g.rown + gw * g.rown_stride;
+    int32_t *aux = g.aux + gw * g.aux_stride;
+    int32_t *tailwin = aux;
+    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
+    const int grp = lane / W, lp = lane - grp * W;
+    int cur_model = -1;
+    bool padded = false;
+    LdsTables L{};
+    const ColProgram *cp = nullptr;
+    DevModel M{};
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
+        __syncthreads();
+        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);
+        if (ti >= g.n_tiles) break;
+        const ColTile tile = g.tiles[ti];
+        if (tile.model != cur_model) {
+            cur_model = tile.model;
+            M = g.a.models[cur_model];
+            cp = M.cols;
+            padded = stage_model<1>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+        }
+        const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
+        const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;          // per read: padded row n + tail values
+        for (int j = wave * G; j < tile.count; j += COL_WAVES * G) {
+            // this lane's read (group grp of the wave)
+            const bool have = j + grp < tile.count;
+            const int r = have ? g.a.order[tile.first + j + grp] : 0;
+            const uint8_t *seq = g.a.bases + g.a.read_off[r];
+            const int n = have ? (int)(g.a.read_off[r + 1] - g.a.read_off[r]) : 0;
+            int nmax = n;
+#pragma unroll
+            for (int o = 32; o >= W; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            const unsigned cap_base = (unsigned)(grp * row_doubles);
+            const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * COL_MAX_SINKS * g.sink_stride);
+            if (!padded || nmax > ROWS_MAX_READ) {                       // the host never routes such a tile here
+                if (have && lp == 0) g.a.out_logp[r] = __longlong_as_double(0x7ff8000000000000ll);
+                continue;
+            }
+            const int s_end = NC - 1 + (nmax - 1) / R;
+            rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride);
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int q = 0; q < G; ++q) {
+                if (j + q >= tile.count) break;
+                const int rq = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j + q]);
+                const uint8_t *sq = g.a.bases + g.a.read_off[rq];
+                const int nq = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[rq + 1] - g.a.read_off[rq]));
+                rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * row_doubles + 3 * W, bpw, q * W, tailwin,
+                                    aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
+            }
+        }
+    }
+}

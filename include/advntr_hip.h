@@ -37,6 +37,8 @@ extern "C" {
 #define ADVNTR_FLAG_NO_SUMMARY    4u  /* skip the path summaries (out_summary untouched)                */
 #define ADVNTR_FLAG_STREAM        8u  /* experimental: pack several reads per wavefront along the row axis (stream kernel)
                                          instead of one read per wavefront bucketed by length */
+#define ADVNTR_FLAG_ANTIDIAGONAL 16u  /* keep short reads of a large batch on the one-read-per-wavefront kernel instead of
+                                         the row-blocked one (several reads per wavefront); results are identical */
 
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8

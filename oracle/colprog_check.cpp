@@ -83,7 +83,7 @@ extern "C" double colprog_viterbi(void *p, const uint8_t *seq, int n, int32_t *p
             { const double c1 = oM + T.dM, c2 = oB + T.dD;
               if (c1 > vB) { vB = c1; pb = 1; } if (c2 > vB) { vB = c2; pb = 2; } }
             const unsigned fl = inf.flags;
-            if (fl & COL_FLAG_SINK) { vB = er; pb = 3; sinkbp[(fl >> 4) * (n + 1) + t] = erwin; er = NINF; }
+            if (fl & COL_FLAG_SINK) { vB = er; pb = 3; sinkbp[((fl >> 4) & 15) * (n + 1) + t] = erwin; er = NINF; }
             if (fl & COL_FLAG_FEED) { const double cand = vB + T.erw; if (cand > er) { er = cand; erwin = c; } }
             cI[c] = vI; cM[c] = vM; cB[c] = vB;
             bp[(size_t)t * NC + c] = (uint8_t)(pi | (pm << 2) | (pb << 4));
@@ -128,7 +128,7 @@ extern "C" double colprog_viterbi(void *p, const uint8_t *seq, int n, int32_t *p
             c -= 1; slot = q == 3 ? 2 : q;
         } else {
             const int q = (byte >> 4) & 3;
-            if (q == 3) c = sinkbp[(g.info[c + 1].flags >> 4) * (n + 1) + t];
+            if (q == 3) c = sinkbp[((g.info[c + 1].flags >> 4) & 15) * (n + 1) + t];
             else { c -= 1; slot = q; }
         }
     }

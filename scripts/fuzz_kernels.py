@@ -1,7 +1,9 @@
-"""Differential fuzz: the anti-diagonal column kernel vs the generic-CSR kernel (two independent implementations of
+"""Differential fuzz: the row-blocked and anti-diagonal column kernels vs the generic-CSR kernel (independent implementations of
 the reference's _viterbi) on random loci and reads; log-probs, all 8 summary ints and (on a sample) paths must agree
 bit for bit.  Usage: python scripts/fuzz_kernels.py [n_loci] [seed]"""
-import sys, time
+import os, sys, time
+os.environ["ADVNTR_ROWS_MIN"] = "0"      # the default call takes the row-blocked kernel for every read it can hold
+os.environ["ADVNTR_ROWS_MIN_READ"] = "1"
 import numpy as np
 sys.path.insert(0, '.')
 import __graft_entry__ as e
@@ -38,6 +40,12 @@ for k in range(n_loci):
     a = _lib.viterbi_batch([dm], bases, off, which, want_paths=want_paths)
     b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=want_paths)
     c = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_STREAM)
+    d = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL, want_paths=want_paths)
+    assert np.array_equal(a[0], d[0]), ("rows vs anti-diagonal logp", k, flank, plen, copies, err,
+                                        np.flatnonzero(~((a[0] == d[0]) | (np.isnan(a[0]) & np.isnan(d[0]))))[:5])
+    assert np.array_equal(a[1], d[1]), ("rows vs anti-diagonal summary", k, np.flatnonzero((a[1] != d[1]).any(1))[:5])
+    if want_paths:
+        assert a[2] == d[2], ("rows vs anti-diagonal paths", k)
     assert np.array_equal(a[0], b[0]), ("logp", k, flank, plen, copies, err)
     assert np.array_equal(a[1], b[1]), ("summary", k, flank, plen, copies, err, np.flatnonzero((a[1] != b[1]).any(1))[:5])
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), ("stream", k)

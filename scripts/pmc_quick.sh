@@ -12,7 +12,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/p/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "viterbi_columns" not in row.get("Kernel_Name", ""): continue
+        if "viterbi_columns" not in row.get("Kernel_Name", "") and "viterbi_rows" not in row.get("Kernel_Name", ""): continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 for k in sorted(tot): print("%-24s %16.0f per launch" % (k, tot[k] / n[k]))
 PY

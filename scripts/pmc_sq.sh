@@ -2,7 +2,7 @@
 # SQ counter passes over one bench launch set (run on the GPU box): scripts/pmc_sq.sh <out_dir> [lib.so]
 # Each pass is its own rocprofv3 run with --pmc only (no tracing), as the pool requires.
 out=$1; lib=$2
-root=$(pwd)
+root=$(pwd); mkdir -p $root/$out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
@@ -19,7 +19,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "viterbi_columns" not in row.get("Kernel_Name", ""): continue
+        if "viterbi_columns" not in row.get("Kernel_Name", "") and "viterbi_rows" not in row.get("Kernel_Name", ""): continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 with open(out + "/sq_summary.txt", "w") as w:
     for k in sorted(tot):

@@ -114,10 +114,14 @@ def test_mirror_model_viterbi_api():
 
 
 @pytest.mark.parametrize("shape", ["s300", "ref150"])
-@pytest.mark.parametrize("force_generic", [True, False, "stream"])
-def test_synthetic_batch_vs_oracle(shape, force_generic):
-    """Seeded C1-style batch at a size the oracle finishes in seconds."""
+@pytest.mark.parametrize("force_generic", [True, False, "stream", "rows"])
+def test_synthetic_batch_vs_oracle(shape, force_generic, monkeypatch):
+    """Seeded C1-style batch at a size the oracle finishes in seconds.  "rows": the row-blocked kernel that
+    large batches of 129-155-base reads go to, forced here for every read it can take (1..155 bases)."""
     from advntr_amd import _lib, workloads
+    if force_generic == "rows":
+        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
+        monkeypatch.setenv("ADVNTR_ROWS_MIN_READ", "1")
     from oracle.oracle import OracleModel
     locus = getattr(workloads, shape)()
     n_reads = 1500 if shape == "s300" else 400
@@ -128,7 +132,7 @@ def test_synthetic_batch_vs_oracle(shape, force_generic):
     dm = m.device_model()
     if force_generic is not True and not dm.has_column_program():
         pytest.skip("no column program")
-    flags = {True: _lib.FLAG_FORCE_GENERIC, False: 0, "stream": _lib.FLAG_STREAM}[force_generic]
+    flags = {True: _lib.FLAG_FORCE_GENERIC, False: 0, "stream": _lib.FLAG_STREAM, "rows": 0}[force_generic]
     bases, off = _lib.encode_reads(reads)
     logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
                                            want_paths=True)
@@ -348,16 +352,22 @@ def test_full_size_c1_properties():
     sb, so = _lib.encode_reads([reads[i] for i in idx])
     lp_g, sm_g, _ = _lib.viterbi_batch([dm], sb, so, np.zeros(len(idx), np.int32), flags=_lib.FLAG_FORCE_GENERIC)
     assert np.array_equal(lp_g, logp[idx]) and np.array_equal(sm_g, summ[idx])
+    # the batch above went through the row-blocked kernel (two reads per wavefront); one read per wavefront gives the same
+    lp_a, sm_a, _ = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL)
+    assert np.array_equal(lp_a, logp) and np.array_equal(sm_a, summ)
 
 
-@pytest.mark.parametrize("mode", ["columns", "stream"])
-def test_random_locus_shapes_vs_oracle(mode):
+@pytest.mark.parametrize("mode", ["columns", "stream", "rows"])
+def test_random_locus_shapes_vs_oracle(mode, monkeypatch):
     """Shape sweep: random flank / pattern / copies (incl. a single copy: no fan-in state) / error rates / multi-row
     profiles, ragged read lengths 1..320 (1-4 chunks, row tiles, tiny models that use the range-checked sweep)."""
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     rng = np.random.default_rng(4242)
     flags = _lib.FLAG_STREAM if mode == "stream" else 0
+    if mode == "rows":                     # every read of up to 155 bases through the row-blocked kernel
+        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
+        monkeypatch.setenv("ADVNTR_ROWS_MIN_READ", "1")
     for trial in range(10):
         flank = int(rng.integers(3, 60))
         plen = int(rng.integers(2, 30))
