@@ -210,12 +210,14 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
     const double logp = col_tail(cp, final_row, tailwin, NC, lane);
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
+#ifndef EXP_NO_TB
     if (logp != -INFINITY) {
         auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
         len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
                                  1 << 30);
         len = __builtin_amdgcn_readfirstlane(len);
     }
+#endif
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);

@@ -143,6 +143,11 @@ def main():
         dm = locus.model.device_model()
         batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
     kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
+    # large batches of 129-155-base reads go to the row-blocked kernel (engine.hip: use_rows); the name is what
+    # rocprofv3 --kernel-trace shows for the dominant kernel of this command
+    if (kernel == "viterbi_columns" and not args.stream and 129 <= n <= 155 and args.reads >= 4096
+            and "ADVNTR_ROWS_MIN" not in os.environ and "ADVNTR_ROWS_MIN_READ" not in os.environ):
+        kernel = "viterbi_rows"
 
     gathered = None
     if use_dist:
@@ -206,7 +211,10 @@ def main():
     traffic, valu_insts = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        if args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_columns":
+        if args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_rows":
+            traffic = pmc["viterbi_rows"]["hbm_bytes_per_launch_fetch_x2"] / 1e9
+            valu_insts = pmc["viterbi_rows"].get("valu_insts_per_launch")
+        elif args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_columns":
             traffic = pmc["hbm_bytes_per_launch_fetch_x2"] / 1e9
             valu_insts = pmc.get("valu_insts_per_launch")
     except Exception:
