@@ -67,7 +67,9 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     const int w = k / 5, j = k - 5 * w;
     const int cnt = (R - 5 * w) < 5 ? (R - 5 * w) : 5;
     const unsigned word = bpw[((int64_t)(cc + lp) * 64 + lane0 + lp) * WORDS + w];
-    return (int)((word >> (6 * (cnt - 1 - j))) & 63u);
+    // the sweep relaxes M, then I, then b: aM bM aI bI aB bB -> the layout bp_ptr_* decode (aI bI aM bM aB bB)
+    const unsigned b = (word >> (6 * (cnt - 1 - j))) & 63u;
+    return (int)(((b << 2) & 0x30u) | ((b >> 2) & 0x0cu) | (b & 3u));
 }
 
 template <int R, int G>
@@ -95,11 +97,11 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
     const bool first_lane = lp == 0;
     const bool fix = G == 2 && lane == 32;
-    // shifted I / M values of the even and the odd steps: a DPP shift writes over its `old` operand, and the previous
-    // step's shifted values are still needed (diagonal inputs of the lane's first row), so the two parities own a
-    // register pair each -- whose group-first lanes hold the row-0 value -inf for the whole sweep, since the shift
-    // never writes them -- and no copy is made
-    double nIa = -INFINITY, nMa = -INFINITY, nIb = -INFINITY, nMb = -INFINITY, pB = -INFINITY;
+    // Row above the lane's first row (the neighbouring lane's last row at the previous step), shifted in with DPP.  A
+    // step evaluates M of the lane's first row FIRST, from the values shifted in one step earlier (its diagonal
+    // inputs), and only then shifts -- in place: the group-first lanes of nI / nM, which the shift never writes, hold the
+    // row-0 value -inf for the whole sweep.
+    double nI = -INFINITY, nM = -INFINITY, nB = -INFINITY;
     unsigned pa = L.pinfo + (unsigned)(64 - lp) * 16u;          // padded info record of column c = -lp (64 dummies in front)
     uint2 meta = lds_uint2(pa + 8u);
     double v0b = *(LdsDouble *)(size_t)pa;
@@ -109,18 +111,13 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     unsigned bp_off = (unsigned)lane * WORDS;
     int c = -lp;                                                // this lane's column
     const unsigned win0 = 4u * (sink_base + (unsigned)(R * lp + 1));
-    auto step = [&](double &nIcur, double &nMcur, const double pI, const double pM) {
+    auto step = [&]() {
         pa += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
         const double v0b_next = *(LdsDouble *)(size_t)pa;
         LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
         const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
         const unsigned eM0 = meta.y & 0xffffu, eI0 = meta.y >> 16;
-        // last row of the neighbouring lane at the previous step = row above this lane's first row, same column
-        const double nI = nIcur = rows_shift<G>(I[R - 1], nIcur);
-        const double nM = nMcur = rows_shift<G>(M[R - 1], nMcur);
-        double nB = rows_shift<G>(B[R - 1], v0b);                // row 0 is read independent (host precomputed)
-        if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;        // (I and M arrive as -inf from the padding lane)
         const unsigned fl = meta.x >> 16;
         const bool anysink = __ballot((fl & COL_FLAG_SINK) != 0) != 0;      // wave-uniform, rare
         // Fan-in (hmm.pyx order: the first maximum over the feeders, in column order): every row keeps the running
@@ -130,10 +127,11 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         const double erw = (fl & COL_FLAG_FEED) ? T->erw : -INFINITY;
         const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
         int bits[WORDS];
-        double upI = nI, upM = nM, upB = nB, dgI = pI, dgM = pM, dgB = pB;
         // emission log-probs are fetched one cell ahead
         double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
         double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
+        double dgI = nI, dgM = nM, dgB = nB;        // (t-1, c-1) of the lane's first row: shifted in at the previous step
+        double upI = 0.0, upM = 0.0, upB = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int w = k / 5;
@@ -142,18 +140,27 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 eI_next = *(LdsDouble *)(size_t)(eI0 + xof(k + 1));
                 eM_next = *(LdsDouble *)(size_t)(eM0 + xof(k + 1));
             }
-            const double oI = I[k], oM = M[k], oB = B[k];
-            // I_c(t) <- [I_c, M_c, b_c](t-1)
-            double vI = (upI + iI) + eI;
-            if (k % 5 == 0) relax_bit_first(vI, bits[w], (upM + iM) + eI);
-            else relax_bit(vI, bits[w], (upM + iM) + eI);
-            relax_bit(vI, bits[w], (upB + iD) + eI);
-            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there
+            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there.
+            // Evaluated first in the cell: its inputs -- the previous values of the row above -- die here.
             double vM = (dgI + mI) + eM;
             double cM = dgM + mM;
             if (k == 0) cM = first_lane ? T->mX : cM;
-            relax_bit(vM, bits[w], cM + eM);
+            if (k % 5 == 0) relax_bit_first(vM, bits[w], cM + eM);
+            else relax_bit(vM, bits[w], cM + eM);
             relax_bit(vM, bits[w], (dgB + mD) + eM);
+            if (k == 0) {
+                // row above the lane's first row, same column: the neighbouring lane's last row of the previous step
+                nI = rows_shift<G>(I[R - 1], nI);
+                nM = rows_shift<G>(M[R - 1], nM);
+                nB = rows_shift<G>(B[R - 1], v0b);               // row 0 is read independent (host precomputed)
+                if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
+                upI = nI; upM = nM; upB = nB;
+            }
+            const double oI = I[k], oM = M[k], oB = B[k];
+            // I_c(t) <- [I_c, M_c, b_c](t-1)
+            double vI = (upI + iI) + eI;
+            relax_bit(vI, bits[w], (upM + iM) + eI);
+            relax_bit(vI, bits[w], (upB + iD) + eI);
             // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)
             double vB = oI + dI;
             relax_bit(vB, bits[w], oM + dM);
@@ -175,15 +182,12 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
             upI = vI; upM = vM; upB = vB;
             dgI = oI; dgM = oM; dgB = oB;
         }
-        pB = nB;
-#ifndef EXP_NO_BP
         if (WORDS == 1) bpw[bp_off] = (unsigned)bits[0];
         else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
         else {
 #pragma unroll
             for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = (unsigned)bits[w];
         }
-#endif
         bp_off += 64 * WORDS;
         cap_off += 3u;
         ++c;
@@ -193,8 +197,8 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     // two steps per loop iteration: the rotation of the loop-carried row values (a cell's old values stay live for the
     // row below while its new ones are produced) becomes register renaming instead of ~3 moves per cell
     int s = 0;
-    for (; s < s_end; s += 2) { step(nIa, nMa, nIb, nMb); step(nIb, nMb, nIa, nMa); }
-    if (s == s_end) step(nIa, nMa, nIb, nMb);
+    for (; s < s_end; s += 2) { step(); step(); }
+    if (s == s_end) step();
 }
 
 // tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group
@@ -280,6 +284,7 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride);
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
+#ifndef EXP_NO_FINISH
 #pragma unroll 1
             for (int q = 0; q < G; ++q) {
                 if (j + q >= tile.count) break;
@@ -289,6 +294,7 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
                 rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * row_doubles + 3 * W, bpw, q * W, tailwin,
                                     aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
             }
+#endif
         }
     }
 }
