@@ -569,6 +569,8 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     int64_t rows_min = 4096;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
+    int rows_tile_mult = 1;
+    if (const char *e = getenv("ADVNTR_ROWS_TILE")) rows_tile_mult = atoi(e);
     auto kof = [&](int r) {
         const int64_t n = read_off[r + 1] - read_off[r];
         if (use_rows && rows_len(n)) return 0;
@@ -671,7 +673,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
-                if (K == 0) cap = std::max<int>(COL_WAVES * ROWS_G, cap * ROWS_G / 2);        // ROWS_G reads per wavefront
+                if (K == 0) cap = std::max<int>(COL_WAVES * ROWS_G, cap * ROWS_G * rows_tile_mult / 2);        // ROWS_G reads per wavefront
                 int j = i;
                 while (j < B->n_col && j - i < cap && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
                 C.tiles[K == 0 ? 5 : K - 1].push_back(ColTile{mod, i, j - i, 0});

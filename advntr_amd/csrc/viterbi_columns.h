@@ -107,7 +107,9 @@ __device__ __forceinline__ void relax_bit(double &best, int &bits, const double 
 #else
     asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
         "v_max_f64 %0, %0, %2\n\t"
+#ifdef COL_RELAX_NOP
         "s_nop 0\n\t"
+#endif
         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
         : "+v"(best), "+v"(bits)
         : "v"(cand)
@@ -124,7 +126,9 @@ __device__ __forceinline__ void relax_bit_first(double &best, int &bits, const d
 #else
     asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
         "v_max_f64 %0, %0, %2\n\t"
+#ifdef COL_RELAX_NOP
         "s_nop 0\n\t"
+#endif
         "v_addc_co_u32_e32 %1, vcc, 0, %3, vcc"
         : "+v"(best), "=v"(bits)
         : "v"(cand), "v"(0)

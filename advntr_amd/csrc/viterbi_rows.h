@@ -67,9 +67,10 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     const int w = k / 5, j = k - 5 * w;
     const int cnt = (R - 5 * w) < 5 ? (R - 5 * w) : 5;
     const unsigned word = bpw[((int64_t)(cc + lp) * 64 + lane0 + lp) * WORDS + w];
-    // the sweep relaxes M, then I, then b: aM bM aI bI aB bB -> the layout bp_ptr_* decode (aI bI aM bM aB bB)
-    const unsigned b = (word >> (6 * (cnt - 1 - j))) & 63u;
-    return (int)(((b << 2) & 0x30u) | ((b >> 2) & 0x0cu) | (b & 3u));
+    // word = I outcomes << 20 | M outcomes << 10 | b outcomes, two bits per cell (first cell of the word highest);
+    // returned in the layout bp_ptr_* decode (aI bI aM bM aB bB)
+    const int sh = 2 * (cnt - 1 - j);
+    return (int)((((word >> (20 + sh)) & 3u) << 4) | (((word >> (10 + sh)) & 3u) << 2) | ((word >> sh) & 3u));
 }
 
 template <int R, int G>
@@ -124,10 +125,11 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         // maximum `er`; a feeder that beats it writes its column straight into the sink's back-pointer slot of that row
         // (later winners overwrite earlier ones), so no winner register is carried.  Lanes that are not on a feeder
         // column carry weight -inf and never win.
-        const double erw = (fl & COL_FLAG_FEED) ? T->erw : -INFINITY;
+        const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
+        const double erw = (fl & COL_FLAG_FEED) ? erw_c : -INFINITY;
         const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
-        int bits[WORDS];
-        // emission log-probs are fetched one cell ahead
+        int bM[WORDS], bI[WORDS], bB[WORDS];      // comparison outcomes of the M / I / b relaxations: three add-with-carry chains
+        // emission log-probs are fetched one cell ahead (all 2R up front costs registers: 11.6 ms instead of 11.4)
         double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
         double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
         double dgI = nI, dgM = nM, dgB = nB;        // (t-1, c-1) of the lane's first row: shifted in at the previous step
@@ -141,13 +143,15 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 eM_next = *(LdsDouble *)(size_t)(eM0 + xof(k + 1));
             }
             // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there.
-            // Evaluated first in the cell: its inputs -- the previous values of the row above -- die here.
+            // Its inputs -- the previous values of the row above -- die here.
             double vM = (dgI + mI) + eM;
             double cM = dgM + mM;
-            if (k == 0) cM = first_lane ? T->mX : cM;
-            if (k % 5 == 0) relax_bit_first(vM, bits[w], cM + eM);
-            else relax_bit(vM, bits[w], cM + eM);
-            relax_bit(vM, bits[w], (dgB + mD) + eM);
+            if (k == 0) cM = first_lane ? mX : cM;
+            const double cM2 = cM + eM, cM3 = (dgB + mD) + eM;
+            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t): the lane's own previous values
+            const double oI = I[k], oM = M[k], oB = B[k];
+            double vB = oI + dI;
+            const double cB2 = oM + dM, cB3 = oB + dD;
             if (k == 0) {
                 // row above the lane's first row, same column: the neighbouring lane's last row of the previous step
                 nI = rows_shift<G>(I[R - 1], nI);
@@ -156,15 +160,24 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
                 upI = nI; upM = nM; upB = nB;
             }
-            const double oI = I[k], oM = M[k], oB = B[k];
-            // I_c(t) <- [I_c, M_c, b_c](t-1)
+            // I_c(t) <- [I_c, M_c, b_c](t-1): the values the row above just got
             double vI = (upI + iI) + eI;
-            relax_bit(vI, bits[w], (upM + iM) + eI);
-            relax_bit(vI, bits[w], (upB + iD) + eI);
-            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t)
-            double vB = oI + dI;
-            relax_bit(vB, bits[w], oM + dM);
-            relax_bit(vB, bits[w], oB + dD);
+            const double cI2 = (upM + iM) + eI, cI3 = (upB + iD) + eI;
+            // The three states' relaxations are independent of each other: issued interleaved (M, b, I, M, b, I), so a
+            // compare never waits for the maximum issued just before it (wave64 fp64 results are not available to the
+            // very next instruction of the same wave; with 3 waves per SIMD that latency is not always covered)
+            if (k % 5 == 0) {
+                relax_bit_first(vM, bM[w], cM2);
+                relax_bit_first(vB, bB[w], cB2);
+                relax_bit_first(vI, bI[w], cI2);
+            } else {
+                relax_bit(vM, bM[w], cM2);
+                relax_bit(vB, bB[w], cB2);
+                relax_bit(vI, bI[w], cI2);
+            }
+            relax_bit(vM, bM[w], cM3);
+            relax_bit(vB, bB[w], cB3);
+            relax_bit(vI, bI[w], cI3);
             if (anysink) {
                 asm volatile("; fan-in column" ::);              // keeps this a (wave-uniform) branch, not four selects per cell
                 const bool sk = (fl & COL_FLAG_SINK) != 0;
@@ -182,11 +195,14 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
             upI = vI; upM = vM; upB = vB;
             dgI = oI; dgM = oM; dgB = oB;
         }
-        if (WORDS == 1) bpw[bp_off] = (unsigned)bits[0];
-        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
+        unsigned bits[WORDS];
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) bits[w] = ((unsigned)bI[w] << 20) | ((unsigned)bM[w] << 10) | (unsigned)bB[w];
+        if (WORDS == 1) bpw[bp_off] = bits[0];
+        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2(bits[0], bits[1]);
         else {
 #pragma unroll
-            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = (unsigned)bits[w];
+            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = bits[w];
         }
         bp_off += 64 * WORDS;
         cap_off += 3u;

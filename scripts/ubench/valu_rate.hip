@@ -2,6 +2,7 @@
 // every CU busy.  Prints cycles per wave-instruction per SIMD (kernel time x clock / instructions per SIMD).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define ITERS 4096
@@ -30,6 +31,11 @@ __global__ void __launch_bounds__(256) bench(double *out, int n)
             if (OP == 13) { asm volatile("v_cmp_gt_f64 vcc, %0, %4\n s_nop 1\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %5, vcc\n v_cndmask_b32 %3, %3, %5, vcc" : "+v"(a), "+v"(ia), "+v"(ib), "+v"(ic) : "v"(b), "v"(ie) : "vcc"); }
             if (OP == 14) { asm volatile("v_cmp_gt_f64_e64 s[20:21], %0, %4\n s_nop 1\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cndmask_b32_e64 %3, %3, %5, s[20:21]" : "+v"(a), "+v"(ia), "+v"(ib), "+v"(ic) : "v"(b), "v"(ie) : "s20", "s21"); }
             if (OP == 15) { asm volatile("v_cmp_gt_f64_e64 s[20:21], %0, %4\n v_cmp_gt_f64_e64 s[22:23], %6, %4\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cndmask_b32_e64 %3, %3, %5, s[22:23]\n v_cndmask_b32_e64 %7, %7, %5, s[22:23]" : "+v"(a), "+v"(ia), "+v"(ib), "+v"(ic) : "v"(b), "v"(ie), "v"(c), "v"(id) : "s20", "s21", "s22", "s23"); }
+            if (OP == 20) { asm volatile("v_cmp_gt_f64_e32 vcc, %2, %0\n v_max_f64 %0, %0, %2\n v_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(a), "+v"(ia) : "v"(b) : "vcc"); }
+            if (OP == 21) { asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2" : "=v"(ia) : "v"(id), "v"(ie)); asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2" : "=v"(ib) : "v"(id), "v"(ie)); asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_2" : "=v"(ic) : "v"(id), "v"(ie)); }
+            if (OP == 22) { asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(ia) :: "vcc"); asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(ib) :: "vcc"); asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(ic) :: "vcc"); }
+            if (OP == 23) { asm volatile("v_cmp_gt_f64_e32 vcc, %2, %0\n v_max_f64 %0, %0, %2\n v_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(a), "+v"(ia) : "v"(b) : "vcc"); asm volatile("v_cmp_gt_f64_e32 vcc, %2, %0\n v_max_f64 %0, %0, %2\n v_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(c), "+v"(ib) : "v"(b) : "vcc"); asm volatile("v_cmp_gt_f64_e32 vcc, %2, %0\n v_max_f64 %0, %0, %2\n v_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "+v"(d), "+v"(ic) : "v"(b) : "vcc"); }
+            if (OP == 24) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(a) : "v"(b)); }
             if (OP == 8) { asm volatile("v_mov_b32 %0, %1" : "=v"(ia) : "v"(ie)); asm volatile("v_mov_b32 %0, %1" : "=v"(ib) : "v"(ie)); asm volatile("v_mov_b32 %0, %1" : "=v"(ic) : "v"(ie)); }
             if (OP == 9) { asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ia) : "v"(ie)); asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ib) : "v"(ie)); asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(ic) : "v"(ie)); }
         }
@@ -37,9 +43,10 @@ __global__ void __launch_bounds__(256) bench(double *out, int n)
     out[blockIdx.x * blockDim.x + threadIdx.x] = a + c + d + ia + ib + ic + id + ie;
 }
 
+static int g_waves = 4;
 template <int OP> static void run(const char *name, double *d_out, double clock_ghz)
 {
-    const int grid = 256 * 4;            // 4 blocks of 4 waves per CU = 4 waves per SIMD
+    const int grid = 256 * g_waves;      // g_waves blocks of 4 waves per CU = g_waves waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(bench<OP>, dim3(grid), dim3(256), 0, 0, d_out, 16);
@@ -50,13 +57,15 @@ template <int OP> static void run(const char *name, double *d_out, double clock_
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double insts_per_simd = 4.0 * ITERS * UNROLL * 3;      // 4 waves per SIMD, 3 instructions per unroll step
+    const double insts_per_simd = (double)g_waves * ITERS * UNROLL * 3;      // g_waves waves per SIMD, 3 instructions per unroll step
     printf("%-28s %8.3f ms  -> %.2f cycles per wave-instruction per SIMD (at %.2f GHz)\n", name, ms,
            ms * 1e-3 * clock_ghz * 1e9 / insts_per_simd, clock_ghz);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) g_waves = atoi(argv[1]);
+    printf("%d waves per SIMD\n", g_waves);
     double *d_out;
     hipMalloc(&d_out, sizeof(double) * 256 * 4 * 256);
     const double ghz = 2.4;
@@ -74,6 +83,11 @@ int main()
     run<13>("cmp vcc + 3 cndmask vcc (/3 => x4/3)", d_out, ghz);
     run<14>("cmp s[20:21] + 3 cndmask e64 (x4/3)", d_out, ghz);
     run<15>("2 cmp sgpr + 4 cndmask e64 (x2)", d_out, ghz);
+    run<20>("relax: cmp,max,addc one chain", d_out, ghz);
+    run<23>("relax x3 independent chains", d_out, ghz);
+    run<21>("v_add_u32_sdwa", d_out, ghz);
+    run<22>("v_addc_co_u32 vcc in/out", d_out, ghz);
+    run<24>("v_add_f64 dependent chain", d_out, ghz);
     run<8>("v_mov_b32", d_out, ghz);
     run<9>("v_lshl_or_b32", d_out, ghz);
     return 0;
