@@ -12,9 +12,9 @@
 //     W = 64/G lanes (G = 4: a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
 //     operand = the row-0 boundary, so groups need no fix-up at all), and a 150-base read costs (NC + 15) steps of 10
 //     cells on 16 lanes: 91 % of the lane-steps do useful work instead of 70 %;
-//   * the six comparison outcomes of a cell are shifted into a running word across the lane's rows (relax_bit's
-//     add-with-carry chain simply continues into the next cell): 5 cells = 30 bits per dword, one 8-byte store per lane
-//     and step instead of one byte store per cell.
+//   * the six comparison outcomes of a cell are shifted into running words across the lane's rows (relax_bit's
+//     add-with-carry chains simply continue into the next cell, one chain per state): 5 cells = 30 bits per dword, one
+//     4-byte store per lane and step instead of one byte store per cell.
 //
 // Reads of a tile go G at a time to a wavefront; after the sweep the wave finishes them one by one (tail states,
 // cooperative traceback, path summary) with the code of viterbi_columns.h.
