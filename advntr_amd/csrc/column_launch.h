@@ -18,9 +18,9 @@ struct ColumnLaunch {
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
-    std::vector<ColTile> tiles[6];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5] = row-blocked kernel
-    ColTile *d_tiles[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int32_t *d_tile_counters = nullptr;     // 6 counters
+    std::vector<ColTile> tiles[8];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels
+    ColTile *d_tiles[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_tile_counters = nullptr;     // 8 counters
     double *d_rown = nullptr;
     int32_t *d_aux = nullptr;
     uint8_t *d_bp = nullptr;
@@ -49,15 +49,17 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     hipLaunchKernelGGL((viterbi_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
 }
 
-// short reads, ROWS_G per wavefront (viterbi_rows.h)
-static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+// short reads, G per wavefront (viterbi_rows.h); cfg = index into rows_configs, tile list 5 + cfg
+template <int R, int G>
+static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream, const int cfg)
 {
-    if (cl.tiles[5].empty()) return;
+    const int slot = 5 + cfg;
+    if (cl.tiles[slot].empty()) return;
     ColArgs g{};
     g.a = a;
-    g.tiles = cl.d_tiles[5];
-    g.n_tiles = (int32_t)cl.tiles[5].size();
-    g.tile_counter = cl.d_tile_counters + 5;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
     g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
@@ -66,9 +68,9 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.sink_stride = cl.sink_stride;
     const int grid = std::min(cl.grid, g.n_tiles);
     if (cl.lds_bytes + 16 > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<ROWS_R, ROWS_G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
-    hipLaunchKernelGGL((viterbi_rows_kernel<ROWS_R, ROWS_G>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+    hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
 }
 
 template <int K>

@@ -560,21 +560,24 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     }
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
     // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read
-    // bucket 0 = short reads of a large batch: row-blocked kernel (viterbi_rows.h), ROWS_G reads per wavefront.  Small
-    // batches (a locus-sized call) stay on the one-read-per-wavefront kernel, which spreads them over more CUs.
-    int64_t n_short = 0, rows_lo = ROWS_MIN_READ;
-    if (const char *e = getenv("ADVNTR_ROWS_MIN_READ")) rows_lo = atoll(e);          // (tests: route every short read)
+    // buckets 0..2 = short reads of a large batch: row-blocked kernels (viterbi_rows.h: rows_configs[bucket], 2 or 4 reads
+    // per wavefront); 3 + K = the anti-diagonal kernel with K chunks (K = 5: row-tiled).  Small batches (a locus-sized
+    // call) stay on the one-read-per-wavefront kernel, which spreads them over more CUs.
+    int64_t n_short = 0, rows_lo = 1;
+    if (const char *e = getenv("ADVNTR_ROWS_MIN_READ")) rows_lo = atoll(e);          // (experiments: shortest read routed there)
     auto rows_len = [&](int64_t n) { return n >= rows_lo && n <= ROWS_MAX_READ; };
     for (int r : col_reads) n_short += rows_len(read_off[r + 1] - read_off[r]);
     int64_t rows_min = 4096;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
-    int rows_tile_mult = 1;
-    if (const char *e = getenv("ADVNTR_ROWS_TILE")) rows_tile_mult = atoi(e);
     auto kof = [&](int r) {
         const int64_t n = read_off[r + 1] - read_off[r];
-        if (use_rows && rows_len(n)) return 0;
-        return (int)std::min<int64_t>(5, (n + 63) / 64);
+        if (use_rows && rows_len(n)) {
+            int cfg = 0;
+            while (cfg + 1 < ROWS_CONFIGS && n <= rows_configs[cfg + 1].max_read) ++cfg;       // the tightest fit
+            return cfg;
+        }
+        return 3 + (int)std::min<int64_t>(5, (n + 63) / 64);
     };
     {   // one 64-bit key per read (bucket | model | inverted length), index in the low bits keeps the sort stable
         std::vector<std::pair<uint64_t, int32_t>> keyed(col_reads.size());
@@ -665,7 +668,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             // tiles of up to 16 reads of one model and one chunk count; the last ~15 % of the reads go out in
             // smaller tiles (8, then 4 = one read per wave) so the dynamic dequeue ends evenly across the CUs
             for (int i = 0; i < B->n_col;) {
-                const int r0 = col_reads[i], K = kof(r0), mod = read_model[r0];
+                const int r0 = col_reads[i], bucket = kof(r0), mod = read_model[r0];
                 const int left = B->n_col - i;
                 // small batches (a locus-sized call): one read per wavefront so the reads spread over the CUs
                 const int full = std::max<int>(COL_WAVES, std::min<int>(COL_TILE_READS, B->n_col / std::max(1, cus * per_cu)));
@@ -673,10 +676,14 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
-                if (K == 0) cap = std::max<int>(COL_WAVES * ROWS_G, cap * ROWS_G * rows_tile_mult / 2);        // ROWS_G reads per wavefront
+                if (bucket < 3) {                                  // G reads per wavefront
+                    const int G = rows_configs[bucket].G;
+                    cap = std::max<int>(COL_WAVES * G, cap * G / 2);
+                    rows_groups = std::max(rows_groups, G);
+                }
                 int j = i;
-                while (j < B->n_col && j - i < cap && kof(col_reads[j]) == K && read_model[col_reads[j]] == mod) ++j;
-                C.tiles[K == 0 ? 5 : K - 1].push_back(ColTile{mod, i, j - i, 0});
+                while (j < B->n_col && j - i < cap && kof(col_reads[j]) == bucket && read_model[col_reads[j]] == mod) ++j;
+                C.tiles[bucket < 3 ? 5 + bucket : bucket - 4].push_back(ColTile{mod, i, j - i, 0});
                 i = j;
             }
             const int kmax = std::min(4, (n_max_col + 63) / 64);
@@ -686,15 +693,14 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             C.bp_stride = (std::max(short_bp, long_bp) + 255) & ~int64_t(255);
             C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
             C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
-            if (!C.tiles[5].empty()) {        // row-blocked kernel: ROWS_G reads per wave, ceil(R/5) dwords per lane and step
-                const int64_t rows_bp = (int64_t)(C.nc_max + 64 / ROWS_G + 1) * 64 * ((ROWS_R + 4) / 5) * 4;
+            if (rows_groups > 1) {            // row-blocked kernels: G reads per wave, one dword per lane and step
+                const int64_t rows_bp = (int64_t)(C.nc_max + 33) * 64 * 4;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
-                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_G * (3 * ((int64_t)C.nc_max + 2 * (64 / ROWS_G)) + COL_MAX_TAIL));
-                rows_groups = ROWS_G;
+                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * (3 * ((int64_t)C.nc_max + 64) + COL_MAX_TAIL));
             }
         }
         size_t n_tiles = 0;
-        for (int k = 0; k < 6; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
+        for (int k = 0; k < 8; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
         // back-pointer scratch of all resident waves: at most 60 % of the free HBM (288 GB per MI355X: 4 096 resident
         // waves x 25 MB for 15-kb reads on a 1 440-column model still fit); beyond that, fewer resident waves
@@ -708,7 +714,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
         if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < 8; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
             HIP_TRY(hipMemcpy(C.d_tiles[k], C.tiles[k].data(), C.tiles[k].size() * sizeof(ColTile), hipMemcpyHostToDevice));
@@ -817,7 +823,9 @@ extern "C" int advntr_batch_run(advntr_batch *B)
             column_launch_k<3, false>(B->col, a, B->flags, B->stream);
             column_launch_k<4, false>(B->col, a, B->flags, B->stream);
             column_launch_k<COL_LONG_K, true>(B->col, a, B->flags, B->stream);
-            column_launch_rows(B->col, a, B->flags, B->stream);
+            column_launch_rows<5, 2>(B->col, a, B->flags, B->stream, 0);
+            column_launch_rows<4, 2>(B->col, a, B->flags, B->stream, 1);
+            column_launch_rows<4, 4>(B->col, a, B->flags, B->stream, 2);
         }
     }
     if (B->n_gen) {
@@ -925,7 +933,9 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 column_launch_fwd<3, false>(B->col, a, B->stream, 2);
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3);      // 193-256 rows: two row tiles
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4);
-                column_launch_fwd<3, false>(B->col, a, B->stream, 5);               // the row-blocked kernel's list (<= 160 rows)
+                column_launch_fwd<3, false>(B->col, a, B->stream, 5);               // the row-blocked kernels' lists
+                column_launch_fwd<2, false>(B->col, a, B->stream, 6);
+                column_launch_fwd<1, false>(B->col, a, B->stream, 7);
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

@@ -9,9 +9,11 @@
 //     column's info word and 88-B transition class are read from LDS once per R cells (the anti-diagonal kernel is
 //     co-limited by VALU issue and LDS reads);
 //   * the skew of the systolic sweep is one column per LANE, not per row: G reads share a wavefront, each in a group of
-//     W = 64/G lanes (G = 4: a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
-//     operand = the row-0 boundary, so groups need no fix-up at all), and a 150-base read costs (NC + 15) steps of 10
-//     cells on 16 lanes: 91 % of the lane-steps do useful work instead of 70 %;
+//     W = 64/G lanes, and a 150-base read costs (NC + 29) steps of 5 cells on 32 lanes: 88 % of the lane-steps do useful
+//     work instead of 70 %.  G = 2: `wave_shr:1` crosses from the first group into the second; the first group's last
+//     lane is kept a padding lane whose rows stay at -inf, which is the row-0 value of I and M, and b takes one select.
+//     G = 4: a group is a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
+//     operand = the row-0 boundary, so there is no fix-up at all;
 //   * the six comparison outcomes of a cell are shifted into running words across the lane's rows (relax_bit's
 //     add-with-carry chains simply continue into the next cell, one chain per state): 5 cells = 30 bits per dword, one
 //     4-byte store per lane and step instead of one byte store per cell.
@@ -21,27 +23,24 @@
 #pragma once
 #include "viterbi_columns.h"
 
+// Three instantiations cover the short reads of a large batch (engine.hip routes by length):
+//   <5, 2>: 125-155 bases, 5 rows per lane, 2 reads per wavefront (32 lanes each, the 32nd a padding lane)
+//   <4, 2>:  65-124 bases, 4 rows per lane, 2 reads per wavefront
+//   <4, 4>:   1-64  bases, 4 rows per lane, 4 reads per wavefront (a DPP row of 16 lanes each: `row_shr:1` never crosses
+//             groups and lanes 0/16/32/48 keep the `old` operand = the row-0 boundary, so no fix-up at all)
 // Measured on the bench workload (100 k reads of 150 bases, 453-column model; kernel ms per launch; the anti-diagonal
-// kernel: 16.5):  R = 5, G = 2 at 3 waves/SIMD 11.3 (no spill inside the sweep loop); at 4 waves/SIMD (128 VGPRs) 12.6:
+// kernel: 16.5):  <5, 2> at 3 waves/SIMD 11.3 (no spill inside the sweep loop); at 4 waves/SIMD (128 VGPRs) 12.6:
 // the loop then reloads spilled values, and on gfx9 a vector-memory load waits behind the back-pointer stores in the
-// same counter;  R = 10, G = 4 needs 256 VGPRs (2 waves/SIMD) 13.2, with 3 waves it spills 22.3.
-#ifndef ROWS_R
-#define ROWS_R 5                    // rows per lane
-#endif
-#ifndef ROWS_G
-#define ROWS_G 2                    // reads per wavefront
-#endif
+// same counter;  <10, 4> needs 256 VGPRs (2 waves/SIMD) 13.2, with 3 waves it spills 22.3.
+#define ROWS_CONFIGS 3
+struct RowsConfig { int R, G, max_read; };
+// longest read of a configuration: G = 2 keeps the group's last lane a padding lane (see rows_sweep)
+static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 * 31}, {4, 4, 4 * 16}};
 #ifndef ROWS_WAVES_PER_SIMD
 #define ROWS_WAVES_PER_SIMD 3
 #endif
-// longest read the kernel takes (G = 2: the group's last lane stays a padding lane, see rows_sweep)
-#define ROWS_MAX_READ (ROWS_R * (64 / ROWS_G - (ROWS_G == 2 ? 1 : 0)))
-// shorter reads stay on the anti-diagonal kernel: a read of up to 128 bases takes two 64-row chunks there, which costs
-// about what R * 32 lanes cost here; one of up to 64 bases half of that
-#ifndef ROWS_MIN_READ
-#define ROWS_MIN_READ 129
-#endif
-#define ROWS_TILE_READS (8 * ROWS_G)
+#define ROWS_MAX_READ 155           // longest read any configuration takes
+#define ROWS_MAX_GROUPS 4
 
 template <int G>
 __device__ __forceinline__ int rows_shr1(const int old, const int src)
@@ -292,7 +291,7 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             nmax = __builtin_amdgcn_readfirstlane(nmax);
             const unsigned cap_base = (unsigned)(grp * row_doubles);
             const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * COL_MAX_SINKS * g.sink_stride);
-            if (!padded || nmax > ROWS_MAX_READ) {                       // the host never routes such a tile here
+            if (!padded || nmax > R * (W - (G == 2 ? 1 : 0))) {                       // the host never routes such a tile here
                 if (have && lp == 0) g.a.out_logp[r] = __longlong_as_double(0x7ff8000000000000ll);
                 continue;
             }
