@@ -572,7 +572,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
     auto kof = [&](int r) {
         const int64_t n = read_off[r + 1] - read_off[r];
-        if (use_rows && rows_len(n)) {
+        // (the row-blocked sweep reaches class and emission records through 16-bit LDS addresses: a model whose two tables
+        // pass 64 KiB keeps its reads on the anti-diagonal kernel, which has a range-checked sweep for that case)
+        if (use_rows && rows_len(n) && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) {
             int cfg = 0;
             while (cfg + 1 < ROWS_CONFIGS && n <= rows_configs[cfg + 1].max_read) ++cfg;       // the tightest fit
             return cfg;
