@@ -18,9 +18,10 @@ struct ColumnLaunch {
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
-    std::vector<ColTile> tiles[8];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels
-    ColTile *d_tiles[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int32_t *d_tile_counters = nullptr;     // 8 counters
+    std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,
+                                            // [8] = row-blocked kernel for reads of more than 155 bases (row tiles)
+    ColTile *d_tiles[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t *d_tile_counters = nullptr;     // 9 counters
     double *d_rown = nullptr;
     int32_t *d_aux = nullptr;
     uint8_t *d_bp = nullptr;
@@ -71,6 +72,29 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
         (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
     hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+}
+
+// reads of more than 155 bases, one per wavefront, row tiles of 64 * ROWS_LONG_R rows (viterbi_rows.h); tile list 8
+static inline void column_launch_rows_long(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
+{
+    const int slot = 8;
+    if (cl.tiles[slot].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
+    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
+    g.sink_stride = cl.sink_stride;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    if (cl.lds_bytes + 16 > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)viterbi_rows_long_kernel<ROWS_LONG_R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(cl.lds_bytes + 16));
+    hipLaunchKernelGGL((viterbi_rows_long_kernel<ROWS_LONG_R>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
 }
 
 template <int K>

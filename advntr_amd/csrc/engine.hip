@@ -570,6 +570,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     int64_t rows_min = 4096;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
+    // bucket 3 = longer reads (156 bases and up) of a batch with enough of them: the row-tiled row-blocked kernel
+    int64_t n_longer = 0, rows_long_min = 1024;
+    for (int r : col_reads) n_longer += (read_off[r + 1] - read_off[r]) > ROWS_MAX_READ;
+    if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_long_min = atoll(e);
+    const bool use_rows_long = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_longer >= rows_long_min;
     auto kof = [&](int r) {
         const int64_t n = read_off[r + 1] - read_off[r];
         // (the row-blocked sweep reaches class and emission records through 16-bit LDS addresses: a model whose two tables
@@ -579,6 +584,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             while (cfg + 1 < ROWS_CONFIGS && n <= rows_configs[cfg + 1].max_read) ++cfg;       // the tightest fit
             return cfg;
         }
+        if (use_rows_long && n > ROWS_MAX_READ && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) return 3;
         return 3 + (int)std::min<int64_t>(5, (n + 63) / 64);
     };
     {   // one 64-bit key per read (bucket | model | inverted length), index in the low bits keeps the sort stable
@@ -685,7 +691,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 }
                 int j = i;
                 while (j < B->n_col && j - i < cap && kof(col_reads[j]) == bucket && read_model[col_reads[j]] == mod) ++j;
-                C.tiles[bucket < 3 ? 5 + bucket : bucket - 4].push_back(ColTile{mod, i, j - i, 0});
+                C.tiles[bucket <= 3 ? 5 + bucket : bucket - 4].push_back(ColTile{mod, i, j - i, 0});
                 i = j;
             }
             const int kmax = std::min(4, (n_max_col + 63) / 64);
@@ -695,6 +701,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             C.bp_stride = (std::max(short_bp, long_bp) + 255) & ~int64_t(255);
             C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
             C.sink_stride = std::max(COL_MAX_READ, n_max_col) + 1;
+            if (!C.tiles[8].empty()) {        // tiled row-blocked kernel: one slab of (NC + 64) x 64 dwords per 64 R rows
+                const int RT = 64 * ROWS_LONG_R;
+                const int64_t tiled_bp = (int64_t)((n_max_col + RT - 1) / RT) * (C.nc_max + 64) * 64 * 4;
+                C.bp_stride = (std::max(C.bp_stride, tiled_bp) + 255) & ~int64_t(255);
+                C.rown_stride = std::max<int64_t>(C.rown_stride, 2 * (3 * ((int64_t)C.nc_max + 128) + COL_MAX_TAIL));
+            }
             if (rows_groups > 1) {            // row-blocked kernels: G reads per wave, one dword per lane and step
                 const int64_t rows_bp = (int64_t)(C.nc_max + 33) * 64 * 4;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
@@ -702,7 +714,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             }
         }
         size_t n_tiles = 0;
-        for (int k = 0; k < 8; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
+        for (int k = 0; k < 9; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
         // back-pointer scratch of all resident waves: at most 60 % of the free HBM (288 GB per MI355X: 4 096 resident
         // waves x 25 MB for 15-kb reads on a 1 440-column model still fit); beyond that, fewer resident waves
@@ -716,7 +728,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
         if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 9; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
             HIP_TRY(hipMemcpy(C.d_tiles[k], C.tiles[k].data(), C.tiles[k].size() * sizeof(ColTile), hipMemcpyHostToDevice));
@@ -828,6 +840,7 @@ extern "C" int advntr_batch_run(advntr_batch *B)
             column_launch_rows<5, 2>(B->col, a, B->flags, B->stream, 0);
             column_launch_rows<4, 2>(B->col, a, B->flags, B->stream, 1);
             column_launch_rows<4, 4>(B->col, a, B->flags, B->stream, 2);
+            column_launch_rows_long(B->col, a, B->flags, B->stream);
         }
     }
     if (B->n_gen) {
@@ -938,6 +951,7 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 column_launch_fwd<3, false>(B->col, a, B->stream, 5);               // the row-blocked kernels' lists
                 column_launch_fwd<2, false>(B->col, a, B->stream, 6);
                 column_launch_fwd<1, false>(B->col, a, B->stream, 7);
+                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 8);
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

@@ -41,6 +41,9 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 #endif
 #define ROWS_MAX_READ 155           // longest read any configuration takes
 #define ROWS_MAX_GROUPS 4
+#ifndef ROWS_LONG_R
+#define ROWS_LONG_R 4                // rows per lane of the tiled kernel for longer reads: row tiles of 256 rows
+#endif
 
 template <int G>
 __device__ __forceinline__ int rows_shr1(const int old, const int src)
@@ -54,6 +57,13 @@ __device__ __forceinline__ double rows_shift(const double v, const double inject
 {
     const int lo = rows_shr1<G>(__double2loint(inject), __double2loint(v));
     const int hi = rows_shr1<G>(__double2hiint(inject), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rows_rol1(const double v)          // lane i <- v[i+1], lane 63 <- v[0]
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -72,11 +82,14 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     return (int)((((word >> (20 + sh)) & 3u) << 4) | (((word >> (10 + sh)) & 3u) << 2) | ((word >> sh) & 3u));
 }
 
-template <int R, int G>
+// TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
+// the first) is the previous tile's last row, captured at seam[3 * (c + 64) + {0, 1, 2}], and takes the place of row 0.
+template <int R, int G, bool TILED = false>
 __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, const int s_end,
                                            const uint8_t *__restrict__ seq, const int n, const int lp, const int lane,
                                            unsigned *__restrict__ bpw, double *__restrict__ rown, const unsigned cap_base,
-                                           int32_t *__restrict__ aux, const unsigned sink_base, const int sink_stride)
+                                           int32_t *__restrict__ aux, const unsigned sink_base, const int sink_stride,
+                                           const int row0 = 0, const double *__restrict__ seam = nullptr)
 {
     constexpr int W = 64 / G, WORDS = (R + 4) / 5;
     double I[R], M[R], B[R], er[R];
@@ -95,7 +108,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     auto xof = [&](const int k) { return (xp[k / 4] >> (8 * (k % 4))) & 0xffu; };
     // the lane that holds the read's last row, and the slot it sits in
     const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
-    const bool first_lane = lp == 0;
+    const bool first_lane = lp == 0 && (!TILED || row0 == 0);       // owner of the read's first row: entry edges
     const bool fix = G == 2 && lane == 32;
     // Row above the lane's first row (the neighbouring lane's last row at the previous step), shifted in with DPP.  A
     // step evaluates M of the lane's first row FIRST, from the values shifted in one step earlier (its diagonal
@@ -110,7 +123,13 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     unsigned cap_off = cap_base + (unsigned)(W - lp) * 3u;
     unsigned bp_off = (unsigned)lane * WORDS;
     int c = -lp;                                                // this lane's column
-    const unsigned win0 = 4u * (sink_base + (unsigned)(R * lp + 1));
+    // TILED, tiles after the first: lane l holds the seam values of column 64 * (s / 64) + ((l + s) % 64): a window of 64
+    // columns, reloaded every 64 steps and rotated one lane per step (DPP wave_rol:1), so that lane 0 -- the only lane
+    // whose shifted-in values come from the seam -- always holds the values of the column it works on
+    const bool seamed = TILED && seam != nullptr;
+    double wI = -INFINITY, wM = -INFINITY, wB = -INFINITY;
+    int sstep = 0;
+    const unsigned win0 = 4u * (sink_base + (unsigned)(row0 + R * lp + 1));
     auto step = [&]() {
         pa += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
@@ -153,9 +172,20 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
             const double cB2 = oM + dM, cB3 = oB + dD;
             if (k == 0) {
                 // row above the lane's first row, same column: the neighbouring lane's last row of the previous step
+                if (TILED && seamed) {
+                    if ((sstep & 63) == 0) {
+                        const int cw = min(sstep + lane, NC - 1) + 64;
+                        wI = seam[3 * cw]; wM = seam[3 * cw + 1]; wB = seam[3 * cw + 2];
+                    }
+                    nI = rows_shift<G>(I[R - 1], wI);
+                    nM = rows_shift<G>(M[R - 1], wM);
+                    nB = rows_shift<G>(B[R - 1], wB);
+                    wI = rows_rol1(wI); wM = rows_rol1(wM); wB = rows_rol1(wB);
+                } else {
                 nI = rows_shift<G>(I[R - 1], nI);
                 nM = rows_shift<G>(M[R - 1], nM);
                 nB = rows_shift<G>(B[R - 1], v0b);               // row 0 is read independent (host precomputed)
+                }
                 if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
                 upI = nI; upM = nM; upB = nB;
             }
@@ -206,6 +236,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         bp_off += 64 * WORDS;
         cap_off += 3u;
         ++c;
+        if (TILED) ++sstep;
         meta = meta_next;
         v0b = v0b_next;
     };
@@ -310,6 +341,83 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
                                     aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
             }
 #endif
+        }
+    }
+}
+
+// Reads longer than the single-sweep kernels take (156 bases up to COL_MAX_LONG_READ), one per wavefront, in row tiles of
+// 64 R rows: the last row of a tile ("seam", in the per-wave row buffers, ping-pong) is what the next tile's first lane
+// shifts in instead of row 0.  One back-pointer slab per tile.
+template <int R>
+__global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
+viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int W = 64, RT = 64 * R;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
+    int32_t *tile_slot = (int32_t *)lds;
+    uint8_t *tables = lds + 16;
+    unsigned *bpw = (unsigned *)(g.bp + gw * g.bp_stride);
+    double *rown = g.rown + gw * g.rown_stride;
+    int32_t *aux = g.aux + gw * g.aux_stride;
+    int32_t *tailwin = aux;
+    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
+    int cur_model = -1;
+    bool padded = false;
+    LdsTables L{};
+    const ColProgram *cp = nullptr;
+    DevModel M{};
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
+        __syncthreads();
+        const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);
+        if (ti >= g.n_tiles) break;
+        const ColTile tile = g.tiles[ti];
+        if (tile.model != cur_model) {
+            cur_model = tile.model;
+            M = g.a.models[cur_model];
+            cp = M.cols;
+            padded = stage_model<1>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+        }
+        const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
+        const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;
+        const int64_t slab = (int64_t)(NC + W) * 64;                  // back-pointer dwords per row tile
+        for (int j = wave; j < tile.count; j += COL_WAVES) {
+            const int r = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j]);
+            const uint8_t *seq = g.a.bases + g.a.read_off[r];
+            const int n = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[r + 1] - g.a.read_off[r]));
+            if (!padded) {                                            // the host never routes such a read here
+                if (lane == 0) g.a.out_logp[r] = __longlong_as_double(0x7ff8000000000000ll);
+                continue;
+            }
+            const int n_tiles = (n + RT - 1) / RT;
+            for (int i = 0; i < n_tiles; ++i) {
+                const int row0 = i * RT, nt = min(RT, n - row0);
+                rows_sweep<R, 1, true>(L, NC, NC - 1 + (nt - 1) / R, seq + row0, nt, lane, lane, bpw + i * slab, rown,
+                                       (unsigned)(((i + 1) & 1) * row_doubles), aux, (unsigned)COL_MAX_TAIL, g.sink_stride, row0,
+                                       i > 0 ? rown + (i & 1) * row_doubles : nullptr);
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+            }
+            double *final_row = rown + (n_tiles & 1) * row_doubles + 3 * W;
+            const double logp = col_tail(cp, final_row, tailwin, NC, lane);
+            if (lane == 0) g.a.out_logp[r] = logp;
+            int len = 0;
+            if (logp != -INFINITY) {
+                auto bp_at = [&](int tt, int cc) -> int {
+                    const int tl = (tt - 1) / RT;
+                    return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc);
+                };
+                len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, aux + COL_MAX_TAIL, rev,
+                                         g.a.path_cap, lane, 0, 1 << 30);
+                len = __builtin_amdgcn_readfirstlane(len);
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
         }
     }
 }

@@ -225,9 +225,12 @@ def test_score_reads_strand_choice_and_recruit():
     assert n_rev > 0
 
 
-def test_long_reads_row_tiled_vs_oracle():
+@pytest.mark.parametrize("kernel", ["antidiagonal", "rows"])
+def test_long_reads_row_tiled_vs_oracle(kernel, monkeypatch):
     """Reads longer than one 256-row tile go through the row-tiled column kernel (seam rows in HBM): PacBio-like
     locus (error 0.3, flank 100), reads of 257..900 bases incl. exact tile multiples."""
+    if kernel == "rows":                   # the row-blocked kernels (large batches go there by themselves)
+        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
@@ -253,10 +256,13 @@ def test_long_reads_row_tiled_vs_oracle():
         assert summ[i][_lib.SUM_RU] == Or.number_of_repeats([names[j] for j in opath][1:-1])
 
 
-def test_pacbio_c4_style_loci_vs_oracle():
+@pytest.mark.parametrize("kernel", ["antidiagonal", "rows"])
+def test_pacbio_c4_style_loci_vs_oracle(kernel, monkeypatch):
     """Config C4 of BASELINE.json at test scale: flank 100, error 0.3, copies = round((max_len-100)/len(pattern))
     (vntr_finder.py:538-549), trimmed spanning reads of VNTR +-20 % + 200 bases with 12 % indel/substitution
     noise; RU counts exact, log-probs bit-equal."""
+    if kernel == "rows":                   # the row-blocked kernels (large batches go there by themselves)
+        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
