@@ -570,8 +570,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     int64_t rows_min = 4096;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
-    // bucket 3 = longer reads (156 bases and up) of a batch with enough of them: the row-tiled row-blocked kernel
-    int64_t n_longer = 0, rows_long_min = 1024;
+    // bucket 3 = longer reads (156 bases and up): the row-tiled row-blocked kernel (one read per wavefront like the
+    // anti-diagonal one, so batches of any size go there)
+    int64_t n_longer = 0, rows_long_min = 1;
     for (int r : col_reads) n_longer += (read_off[r + 1] - read_off[r]) > ROWS_MAX_READ;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_long_min = atoll(e);
     const bool use_rows_long = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_longer >= rows_long_min;

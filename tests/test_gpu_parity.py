@@ -229,8 +229,12 @@ def test_score_reads_strand_choice_and_recruit():
 def test_long_reads_row_tiled_vs_oracle(kernel, monkeypatch):
     """Reads longer than one 256-row tile go through the row-tiled column kernel (seam rows in HBM): PacBio-like
     locus (error 0.3, flank 100), reads of 257..900 bases incl. exact tile multiples."""
-    if kernel == "rows":                   # the row-blocked kernels (large batches go there by themselves)
+    kflags = 0
+    if kernel == "rows":                   # the row-blocked kernels, also for reads short enough for a single sweep
         monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
+    else:
+        from advntr_amd import _lib as _l
+        kflags = _l.FLAG_ANTIDIAGONAL
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
@@ -243,7 +247,7 @@ def test_long_reads_row_tiled_vs_oracle(kernel, monkeypatch):
     dm = m.device_model()
     assert dm.has_column_program()
     bases, off = _lib.encode_reads(reads)
-    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), want_paths=True)
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), want_paths=True, flags=kflags)
     a = m.baked_arrays()
     edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
              for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
@@ -261,8 +265,12 @@ def test_pacbio_c4_style_loci_vs_oracle(kernel, monkeypatch):
     """Config C4 of BASELINE.json at test scale: flank 100, error 0.3, copies = round((max_len-100)/len(pattern))
     (vntr_finder.py:538-549), trimmed spanning reads of VNTR +-20 % + 200 bases with 12 % indel/substitution
     noise; RU counts exact, log-probs bit-equal."""
-    if kernel == "rows":                   # the row-blocked kernels (large batches go there by themselves)
+    kflags = 0
+    if kernel == "rows":                   # the row-blocked kernels, also for reads short enough for a single sweep
         monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
+    else:
+        from advntr_amd import _lib as _l
+        kflags = _l.FLAG_ANTIDIAGONAL
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
@@ -290,7 +298,7 @@ def test_pacbio_c4_style_loci_vs_oracle(kernel, monkeypatch):
             which.append(k)
     dms = [l.model.device_model() for l in loci]
     bases, off = _lib.encode_reads(reads)
-    logp, summ, paths = _lib.viterbi_batch(dms, bases, off, np.asarray(which, np.int32), want_paths=True)
+    logp, summ, paths = _lib.viterbi_batch(dms, bases, off, np.asarray(which, np.int32), want_paths=True, flags=kflags)
     for k, loc in enumerate(loci):
         a = loc.model.baked_arrays()
         edges = [(int(a["in_src"][q]), l, float(a["in_logp"][q]))
