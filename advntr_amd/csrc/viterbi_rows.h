@@ -14,9 +14,9 @@
 //     lane is kept a padding lane whose rows stay at -inf, which is the row-0 value of I and M, and b takes one select.
 //     G = 4: a group is a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
 //     operand = the row-0 boundary, so there is no fix-up at all;
-//   * the six comparison outcomes of a cell are shifted into running words across the lane's rows (relax_bit's
-//     add-with-carry chains simply continue into the next cell, one chain per state): 5 cells = 30 bits per dword, one
-//     4-byte store per lane and step instead of one byte store per cell.
+//   * the six comparison outcomes of a cell are shifted into a running word across the lane's rows (relax_bit's
+//     add-with-carry chain simply continues into the next cell): 5 cells = 30 bits per dword, one 4-byte store per lane
+//     and step instead of one byte store per cell.
 //
 // Reads of a tile go G at a time to a wavefront; after the sweep the wave finishes them one by one (tail states,
 // cooperative traceback, path summary) with the code of viterbi_columns.h.
@@ -76,10 +76,9 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     const int w = k / 5, j = k - 5 * w;
     const int cnt = (R - 5 * w) < 5 ? (R - 5 * w) : 5;
     const unsigned word = bpw[((int64_t)(cc + lp) * 64 + lane0 + lp) * WORDS + w];
-    // word = I outcomes << 20 | M outcomes << 10 | b outcomes, two bits per cell (first cell of the word highest);
-    // returned in the layout bp_ptr_* decode (aI bI aM bM aB bB)
-    const int sh = 2 * (cnt - 1 - j);
-    return (int)((((word >> (20 + sh)) & 3u) << 4) | (((word >> (10 + sh)) & 3u) << 2) | ((word >> sh) & 3u));
+    // the sweep relaxes M, then I, then b: aM bM aI bI aB bB -> the layout bp_ptr_* decode (aI bI aM bM aB bB)
+    const unsigned b = (word >> (6 * (cnt - 1 - j))) & 63u;
+    return (int)(((b << 2) & 0x30u) | ((b >> 2) & 0x0cu) | (b & 3u));
 }
 
 // TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
@@ -146,7 +145,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
         const double erw = (fl & COL_FLAG_FEED) ? erw_c : -INFINITY;
         const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
-        int bM[WORDS], bI[WORDS], bB[WORDS];      // comparison outcomes of the M / I / b relaxations: three add-with-carry chains
+        int bits[WORDS];                          // comparison outcomes of the step's cells: one add-with-carry chain per word
         // emission log-probs are fetched one cell ahead (all 2R up front costs registers: 11.6 ms instead of 11.4)
         double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
         double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
@@ -192,21 +191,15 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
             // I_c(t) <- [I_c, M_c, b_c](t-1): the values the row above just got
             double vI = (upI + iI) + eI;
             const double cI2 = (upM + iM) + eI, cI3 = (upB + iD) + eI;
-            // The three states' relaxations are independent of each other: issued interleaved (M, b, I, M, b, I), so a
-            // compare never waits for the maximum issued just before it (wave64 fp64 results are not available to the
-            // very next instruction of the same wave; with 3 waves per SIMD that latency is not always covered)
-            if (k % 5 == 0) {
-                relax_bit_first(vM, bM[w], cM2);
-                relax_bit_first(vB, bB[w], cB2);
-                relax_bit_first(vI, bI[w], cI2);
-            } else {
-                relax_bit(vM, bM[w], cM2);
-                relax_bit(vB, bB[w], cB2);
-                relax_bit(vI, bI[w], cI2);
-            }
-            relax_bit(vM, bM[w], cM3);
-            relax_bit(vB, bB[w], cB3);
-            relax_bit(vI, bI[w], cI3);
+            // relaxations in the order M, I, b (one carry chain; interleaving the three states or giving each its own chain
+            // measures the same)
+            if (k % 5 == 0) relax_bit_first(vM, bits[w], cM2);
+            else relax_bit(vM, bits[w], cM2);
+            relax_bit(vM, bits[w], cM3);
+            relax_bit(vI, bits[w], cI2);
+            relax_bit(vI, bits[w], cI3);
+            relax_bit(vB, bits[w], cB2);
+            relax_bit(vB, bits[w], cB3);
             if (anysink) {
                 asm volatile("; fan-in column" ::);              // keeps this a (wave-uniform) branch, not four selects per cell
                 const bool sk = (fl & COL_FLAG_SINK) != 0;
@@ -224,14 +217,11 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
             upI = vI; upM = vM; upB = vB;
             dgI = oI; dgM = oM; dgB = oB;
         }
-        unsigned bits[WORDS];
-#pragma unroll
-        for (int w = 0; w < WORDS; ++w) bits[w] = ((unsigned)bI[w] << 20) | ((unsigned)bM[w] << 10) | (unsigned)bB[w];
-        if (WORDS == 1) bpw[bp_off] = bits[0];
-        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2(bits[0], bits[1]);
+        if (WORDS == 1) bpw[bp_off] = (unsigned)bits[0];
+        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
         else {
 #pragma unroll
-            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = bits[w];
+            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = (unsigned)bits[w];
         }
         bp_off += 64 * WORDS;
         cap_off += 3u;
