@@ -119,15 +119,15 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     double v0b = *(LdsDouble *)(size_t)pa;
     // row-n capture of column c at rown[cap_off + 3 * c]; back-pointer words at bpw[bp_off + 64 * WORDS * s]: 32-bit
     // offsets from wave-uniform bases (scalar base + vector offset addressing, no 64-bit pointer arithmetic per step)
-    unsigned cap_off = cap_base + (unsigned)(W - lp) * 3u;
-    unsigned bp_off = (unsigned)lane * WORDS;
-    int c = -lp;                                                // this lane's column
+    // (the step index is wave-uniform: the per-step parts of these offsets are scalar arithmetic, the per-lane parts constants)
+    const unsigned cap_lane = cap_base + (unsigned)(W - lp) * 3u;
+    const unsigned bp_lane = (unsigned)lane * WORDS;
+    int sstep = 0;                                              // step index (scalar)
     // TILED, tiles after the first: lane l holds the seam values of column 64 * (s / 64) + ((l + s) % 64): a window of 64
     // columns, reloaded every 64 steps and rotated one lane per step (DPP wave_rol:1), so that lane 0 -- the only lane
     // whose shifted-in values come from the seam -- always holds the values of the column it works on
     const bool seamed = TILED && seam != nullptr;
     double wI = -INFINITY, wM = -INFINITY, wB = -INFINITY;
-    int sstep = 0;
     const unsigned win0 = 4u * (sink_base + (unsigned)(row0 + R * lp + 1));
     auto step = [&]() {
         pa += 16u;
@@ -143,9 +143,9 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         // (later winners overwrite earlier ones), so no winner register is carried.  Lanes that are not on a feeder
         // column carry weight -inf and never win.
         const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
-        const double erw = (fl & COL_FLAG_FEED) ? erw_c : -INFINITY;
-        const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
+        const bool anyfeed = __ballot((fl & COL_FLAG_FEED) != 0) != 0;      // wave-uniform: false while the wave is in a flank
         int bits[WORDS];                          // comparison outcomes of the step's cells: one add-with-carry chain per word
+        double *capq = rown + 3 * sstep + cap_lane;          // where this column's row-n values go (lane holding the last row)
         // emission log-probs are fetched one cell ahead (all 2R up front costs registers: 11.6 ms instead of 11.4)
         double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
         double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
@@ -206,27 +206,31 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 vB = sk ? er[k] : vB;
                 er[k] = sk ? -INFINITY : er[k];
             }
-            {
-                const double cand = vB + erw;
-                const bool won = cand > er[k];
-                asm("v_max_f64 %0, %0, %1" : "+v"(er[k]) : "v"(cand));        // (fmax() adds two canonicalising self-maxima)
-                if (won) *(int32_t *)((char *)aux + (win + 4u * k)) = c;
-            }
             I[k] = vI; M[k] = vM; B[k] = vB;
-            if (kcap == k) { rown[cap_off] = vI; rown[cap_off + 1] = vM; rown[cap_off + 2] = vB; }
+            if (kcap == k) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
             upI = vI; upM = vM; upB = vB;
             dgI = oI; dgM = oM; dgB = oB;
         }
-        if (WORDS == 1) bpw[bp_off] = (unsigned)bits[0];
-        else if (WORDS == 2) *(uint2 *)(bpw + bp_off) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
+        if (anyfeed) {                 // after the cells: the accumulators take the rows' final b values of this column
+            asm volatile("; feeder column" ::);
+            const double erw = (fl & COL_FLAG_FEED) ? erw_c : -INFINITY;
+            const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double cand = B[k] + erw;
+                const bool won = cand > er[k];
+                asm("v_max_f64 %0, %0, %1" : "+v"(er[k]) : "v"(cand));        // (fmax() adds two canonicalising self-maxima)
+                if (won) *(int32_t *)((char *)aux + (win + 4u * k)) = sstep - lp;      // this lane's column
+            }
+        }
+        unsigned *bps = bpw + (int64_t)sstep * (64 * WORDS);    // scalar part of the address
+        if (WORDS == 1) bps[bp_lane] = (unsigned)bits[0];
+        else if (WORDS == 2) *(uint2 *)(bps + bp_lane) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
         else {
 #pragma unroll
-            for (int w = 0; w < WORDS; ++w) bpw[bp_off + w] = (unsigned)bits[w];
+            for (int w = 0; w < WORDS; ++w) bps[bp_lane + w] = (unsigned)bits[w];
         }
-        bp_off += 64 * WORDS;
-        cap_off += 3u;
-        ++c;
-        if (TILED) ++sstep;
+        ++sstep;
         meta = meta_next;
         v0b = v0b_next;
     };
