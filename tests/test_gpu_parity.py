@@ -795,3 +795,34 @@ def test_models_loaded_from_json_score_like_the_reference():
         m = HiddenMarkovModel.from_json(case["json"])
         for r, want in zip(case["reads"], case["logp"]):
             assert m.viterbi(r)[0] == want, (case["name"], r)
+
+
+@pytest.mark.gpu
+def test_row_blocked_kernels_at_their_length_boundaries():
+    """A batch large enough for the default routing (>= 4096 short reads): every row-blocked configuration at the edges
+    of its length range (<4,4> 1-64, <4,2> 65-124, <5,2> 125-155, tiled 156+ incl. exact tile multiples) against the
+    generic-CSR kernel and, on a sample, the oracle; log-probs, summaries and paths identical."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(77)
+    loc = workloads.make_locus(rng, 60, 9, 9, 0.05, n_units=3)
+    dm = loc.model.device_model()
+    assert dm.has_column_program()
+    lens = [1, 2, 4, 5, 63, 64, 65, 80, 123, 124, 125, 128, 129, 150, 154, 155, 156, 160, 255, 256, 257, 300, 511, 512, 513]
+    reads = []
+    for i in range(7000):          # 16 of 25 lengths are short: 4 480 reads >= the 4 096 of the default routing
+        n = lens[i % len(lens)]
+        reads.append(workloads.make_reads(rng, loc, 1, n, locus_fraction=0.7, sub_rate=0.03)[0])
+    bases, off = _lib.encode_reads(reads)
+    which = np.zeros(len(reads), np.int32)
+    a = _lib.viterbi_batch([dm], bases, off, which, want_paths=True)
+    b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=True)
+    c = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL, want_paths=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and a[2] == c[2]
+    m = loc.model.baked_arrays()
+    edges = [(int(m["in_src"][k]), l, float(m["in_logp"][k])) for l in range(m["m"]) for k in range(m["in_ptr"][l], m["in_ptr"][l + 1])]
+    O = OracleModel(m["m"], m["silent_start"], m["start_index"], m["end_index"], edges, m["emis_logp"])
+    for i in range(0, 2 * len(lens)):
+        olp, opath = O.viterbi(reads[i])
+        assert a[0][i] == olp and a[2][i] == opath, (i, len(reads[i]))
