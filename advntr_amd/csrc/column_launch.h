@@ -4,6 +4,7 @@
 #include "forward_columns.h"
 #include "viterbi_columns_stream.h"
 #include "viterbi_rows.h"
+#include "forward_rows.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side of the launch
@@ -142,3 +143,23 @@ static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a,
     hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g);
 }
 
+// sum-product on the row-blocked layout: the short reads of a large batch (tile list 5 + cfg)
+template <int R, int G>
+static inline void column_launch_fwd_rows(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int cfg)
+{
+    const int slot = 5 + cfg;
+    if (cl.tiles[slot].empty()) return;
+    ColArgs g{};
+    g.a = a;
+    g.tiles = cl.d_tiles[slot];
+    g.n_tiles = (int32_t)cl.tiles[slot].size();
+    g.tile_counter = cl.d_tile_counters + slot;
+    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
+    g.lds_tables = (int32_t)cl.lds_bytes;
+    g.lds_level = cl.lds_level;
+    const int grid = std::min(cl.grid, g.n_tiles);
+    const size_t lds = ((cl.lds_bytes + 15) & ~size_t(15)) + 16 + 16 * (size_t)cl.nc_max + 16;      // + linear row-0 table
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((forward_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g);
+}

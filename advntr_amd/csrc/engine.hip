@@ -949,9 +949,9 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 column_launch_fwd<3, false>(B->col, a, B->stream, 2);
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3);      // 193-256 rows: two row tiles
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4);
-                column_launch_fwd<3, false>(B->col, a, B->stream, 5);               // the row-blocked kernels' lists
-                column_launch_fwd<2, false>(B->col, a, B->stream, 6);
-                column_launch_fwd<1, false>(B->col, a, B->stream, 7);
+                column_launch_fwd_rows<5, 2>(B->col, a, B->stream, 0);              // the row-blocked kernels' lists
+                column_launch_fwd_rows<4, 2>(B->col, a, B->stream, 1);
+                column_launch_fwd_rows<4, 4>(B->col, a, B->stream, 2);
                 column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 8);
             }
             if (B->n_gen) {

@@ -402,10 +402,14 @@ def test_random_locus_shapes_vs_oracle(mode, monkeypatch):
             assert paths[i] == opath, (trial, flank, plen, copies, len(r))
 
 
-def test_forward_column_kernel_vs_generic_and_oracle():
+@pytest.mark.parametrize("kernel", ["antidiagonal", "rows"])
+def test_forward_column_kernel_vs_generic_and_oracle(kernel, monkeypatch):
     """log_probability on the column program (sum-product sweep, row tiles for long reads) against the generic
-    forward kernel and the CPU oracle: rounding-level agreement (1e-9 relative; north-star bar 1e-4)."""
+    forward kernel and the CPU oracle: rounding-level agreement (1e-9 relative; north-star bar 1e-4).  "rows": short
+    reads through the row-blocked sum-product kernels (forward_rows.h), as in a large batch."""
     from advntr_amd import _lib, workloads
+    if kernel == "rows":
+        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
     from oracle.oracle import OracleModel
     rng = np.random.default_rng(8)
     loc = workloads.make_locus(rng, 60, 17, 5, n_units=3)
