@@ -560,14 +560,16 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     }
     // column reads: grouped by chunk count K=ceil(n/64), then model, then longest first
     // bucket 1..4 = chunk count of a single-tile read, 5 = row-tiled long read
-    // buckets 0..2 = short reads of a large batch: row-blocked kernels (viterbi_rows.h: rows_configs[bucket], 2 or 4 reads
-    // per wavefront); 3 + K = the anti-diagonal kernel with K chunks (K = 5: row-tiled).  Small batches (a locus-sized
-    // call) stay on the one-read-per-wavefront kernel, which spreads them over more CUs.
+    // buckets 0..2 = short reads: row-blocked kernels (viterbi_rows.h: rows_configs[bucket], 2 or 4 reads per wavefront);
+    // 3 = longer reads: the tiled row-blocked kernel; 3 + K = the anti-diagonal kernel with K chunks (K = 5: row-tiled),
+    // which runs when ADVNTR_FLAG_ANTIDIAGONAL asks for it or a model's tables do not fit 16-bit LDS addresses.  (The
+    // row-blocked kernels are the faster ones at every batch size: 16 reads 0.41 against 0.50 ms, 4 000 reads 0.62
+    // against 0.81 ms, scripts/small_batch_bench.py.)
     int64_t n_short = 0, rows_lo = 1;
     if (const char *e = getenv("ADVNTR_ROWS_MIN_READ")) rows_lo = atoll(e);          // (experiments: shortest read routed there)
     auto rows_len = [&](int64_t n) { return n >= rows_lo && n <= ROWS_MAX_READ; };
     for (int r : col_reads) n_short += rows_len(read_off[r + 1] - read_off[r]);
-    int64_t rows_min = 4096;
+    int64_t rows_min = 1;
     if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
     const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
     // bucket 3 = longer reads (156 bases and up): the row-tiled row-blocked kernel (one read per wavefront like the

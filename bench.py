@@ -143,9 +143,9 @@ def main():
         dm = locus.model.device_model()
         batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
     kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
-    # large batches of reads of up to 155 bases go to the row-blocked kernels (engine.hip: use_rows); the name is what
+    # reads of up to 155 bases go to the row-blocked kernels (engine.hip: use_rows); the name is what
     # rocprofv3 --kernel-trace shows for the dominant kernel of this command
-    if (kernel == "viterbi_columns" and not args.stream and n <= 155 and args.reads >= 4096
+    if (kernel == "viterbi_columns" and not args.stream and n <= 155
             and "ADVNTR_ROWS_MIN" not in os.environ and "ADVNTR_ROWS_MIN_READ" not in os.environ):
         kernel = "viterbi_rows"
 

@@ -34,18 +34,19 @@ def device_model_from_golden(g):
     return dm, O
 
 
-@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("force_generic", [True, False, "antidiagonal"])
 @pytest.mark.parametrize("name", ALL_MODEL_GOLDENS)
 def test_golden_logp_paths_summaries(name, force_generic):
     from advntr_amd import _lib
     from advntr_amd.hmm_utils import flanking_rate_from_counts
     g = load_golden(name)
     dm, _ = device_model_from_golden(g)
-    if not force_generic and not dm.has_column_program():
+    if force_generic is not True and not dm.has_column_program():
         pytest.skip("model has no column program; generic kernel covered by the other parametrisation")
     reads = [r["seq"] for r in g["reads"]]
     bases, off = _lib.encode_reads(reads)
-    flags = _lib.FLAG_FORCE_GENERIC if force_generic else 0
+    # False = the default routing (row-blocked kernels), "antidiagonal" = one read per wavefront
+    flags = {True: _lib.FLAG_FORCE_GENERIC, False: 0, "antidiagonal": _lib.FLAG_ANTIDIAGONAL}[force_generic]
     logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
                                            want_paths=True)
     for i, r in enumerate(g["reads"]):
@@ -115,13 +116,10 @@ def test_mirror_model_viterbi_api():
 
 @pytest.mark.parametrize("shape", ["s300", "ref150"])
 @pytest.mark.parametrize("force_generic", [True, False, "stream", "rows"])
-def test_synthetic_batch_vs_oracle(shape, force_generic, monkeypatch):
-    """Seeded C1-style batch at a size the oracle finishes in seconds.  "rows": the row-blocked kernel that
-    large batches of 129-155-base reads go to, forced here for every read it can take (1..155 bases)."""
+def test_synthetic_batch_vs_oracle(shape, force_generic):
+    """Seeded C1-style batch at a size the oracle finishes in seconds.  "rows": the default routing
+    (row-blocked kernels); False: the anti-diagonal kernel, one read per wavefront."""
     from advntr_amd import _lib, workloads
-    if force_generic == "rows":
-        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
-        monkeypatch.setenv("ADVNTR_ROWS_MIN_READ", "1")
     from oracle.oracle import OracleModel
     locus = getattr(workloads, shape)()
     n_reads = 1500 if shape == "s300" else 400
@@ -132,7 +130,7 @@ def test_synthetic_batch_vs_oracle(shape, force_generic, monkeypatch):
     dm = m.device_model()
     if force_generic is not True and not dm.has_column_program():
         pytest.skip("no column program")
-    flags = {True: _lib.FLAG_FORCE_GENERIC, False: 0, "stream": _lib.FLAG_STREAM, "rows": 0}[force_generic]
+    flags = {True: _lib.FLAG_FORCE_GENERIC, False: _lib.FLAG_ANTIDIAGONAL, "stream": _lib.FLAG_STREAM, "rows": 0}[force_generic]
     bases, off = _lib.encode_reads(reads)
     logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
                                            want_paths=True)
@@ -229,12 +227,8 @@ def test_score_reads_strand_choice_and_recruit():
 def test_long_reads_row_tiled_vs_oracle(kernel, monkeypatch):
     """Reads longer than one 256-row tile go through the row-tiled column kernel (seam rows in HBM): PacBio-like
     locus (error 0.3, flank 100), reads of 257..900 bases incl. exact tile multiples."""
-    kflags = 0
-    if kernel == "rows":                   # the row-blocked kernels, also for reads short enough for a single sweep
-        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
-    else:
-        from advntr_amd import _lib as _l
-        kflags = _l.FLAG_ANTIDIAGONAL
+    from advntr_amd import _lib as _l
+    kflags = 0 if kernel == "rows" else _l.FLAG_ANTIDIAGONAL          # rows = the default routing
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
@@ -265,12 +259,8 @@ def test_pacbio_c4_style_loci_vs_oracle(kernel, monkeypatch):
     """Config C4 of BASELINE.json at test scale: flank 100, error 0.3, copies = round((max_len-100)/len(pattern))
     (vntr_finder.py:538-549), trimmed spanning reads of VNTR +-20 % + 200 bases with 12 % indel/substitution
     noise; RU counts exact, log-probs bit-equal."""
-    kflags = 0
-    if kernel == "rows":                   # the row-blocked kernels, also for reads short enough for a single sweep
-        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
-    else:
-        from advntr_amd import _lib as _l
-        kflags = _l.FLAG_ANTIDIAGONAL
+    from advntr_amd import _lib as _l
+    kflags = 0 if kernel == "rows" else _l.FLAG_ANTIDIAGONAL          # rows = the default routing
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     from oracle import oracle as Or
@@ -378,10 +368,7 @@ def test_random_locus_shapes_vs_oracle(mode, monkeypatch):
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     rng = np.random.default_rng(4242)
-    flags = _lib.FLAG_STREAM if mode == "stream" else 0
-    if mode == "rows":                     # every read of up to 155 bases through the row-blocked kernel
-        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
-        monkeypatch.setenv("ADVNTR_ROWS_MIN_READ", "1")
+    flags = {"stream": _lib.FLAG_STREAM, "columns": _lib.FLAG_ANTIDIAGONAL, "rows": 0}[mode]     # rows = default routing
     for trial in range(10):
         flank = int(rng.integers(3, 60))
         plen = int(rng.integers(2, 30))
@@ -408,8 +395,6 @@ def test_forward_column_kernel_vs_generic_and_oracle(kernel, monkeypatch):
     forward kernel and the CPU oracle: rounding-level agreement (1e-9 relative; north-star bar 1e-4).  "rows": short
     reads through the row-blocked sum-product kernels (forward_rows.h), as in a large batch."""
     from advntr_amd import _lib, workloads
-    if kernel == "rows":
-        monkeypatch.setenv("ADVNTR_ROWS_MIN", "0")
     from oracle.oracle import OracleModel
     rng = np.random.default_rng(8)
     loc = workloads.make_locus(rng, 60, 17, 5, n_units=3)
@@ -417,7 +402,7 @@ def test_forward_column_kernel_vs_generic_and_oracle(kernel, monkeypatch):
     dm = loc.model.device_model()
     bases, off = _lib.encode_reads(reads)
     which = np.zeros(len(reads), np.int32)
-    col = _lib.forward_batch([dm], bases, off, which)
+    col = _lib.forward_batch([dm], bases, off, which, flags=0 if kernel == "rows" else _lib.FLAG_ANTIDIAGONAL)
     gen = _lib.forward_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC)
     assert np.all(np.abs(col - gen) <= 1e-9 * np.maximum(1.0, np.abs(gen)))
     a = loc.model.baked_arrays()
@@ -803,7 +788,7 @@ def test_models_loaded_from_json_score_like_the_reference():
 
 @pytest.mark.gpu
 def test_row_blocked_kernels_at_their_length_boundaries():
-    """A batch large enough for the default routing (>= 4096 short reads): every row-blocked configuration at the edges
+    """A large mixed batch under the default routing: every row-blocked configuration at the edges
     of its length range (<4,4> 1-64, <4,2> 65-124, <5,2> 125-155, tiled 156+ incl. exact tile multiples) against the
     generic-CSR kernel and, on a sample, the oracle; log-probs, summaries and paths identical."""
     from advntr_amd import _lib, workloads
@@ -814,7 +799,7 @@ def test_row_blocked_kernels_at_their_length_boundaries():
     assert dm.has_column_program()
     lens = [1, 2, 4, 5, 63, 64, 65, 80, 123, 124, 125, 128, 129, 150, 154, 155, 156, 160, 255, 256, 257, 300, 511, 512, 513]
     reads = []
-    for i in range(7000):          # 16 of 25 lengths are short: 4 480 reads >= the 4 096 of the default routing
+    for i in range(7000):
         n = lens[i % len(lens)]
         reads.append(workloads.make_reads(rng, loc, 1, n, locus_fraction=0.7, sub_rate=0.03)[0])
     bases, off = _lib.encode_reads(reads)
