@@ -26,13 +26,17 @@ def _read_fasta(path):
     with open(path) as fh:
         first = fh.readline()
         if first.startswith("@"):                                   # FASTQ: name, sequence, '+', qualities
-            line = first
-            while line:
-                names.append(line[1:].rstrip("\n"))
-                seqs.append(fh.readline().rstrip("\n"))
-                fh.readline()
-                fh.readline()
-                line = fh.readline()
+            lines = [first] + fh.readlines()
+            lines = [l.rstrip("\r\n") for l in lines]
+            while lines and not lines[-1].strip():                  # trailing blank lines are not records
+                lines.pop()
+            if len(lines) % 4:
+                raise ValueError("%s: FASTQ needs four lines per record (multi-line records are not supported)" % path)
+            for i in range(0, len(lines), 4):
+                if not lines[i].startswith("@") or not lines[i + 2].startswith("+"):
+                    raise ValueError("%s: malformed FASTQ record at line %d" % (path, i + 1))
+                names.append(lines[i][1:])
+                seqs.append(lines[i + 1])
             return names, seqs
         chunks = None
         for line in [first] + fh.readlines():
@@ -104,14 +108,19 @@ def genotype(args):
                 out.append(row(loc, vntr_finder.GenotypeResult(geno, len(spanning), len(spanning), 0, prob)))
             return out
         return finish(sharding.run_sharded([len(loc["pattern"]) for loc in loci], pacbio_job))
-    # Illumina: prefilter every read (both strands) against all loci at once
+    # Illumina: prefilter every read against all loci at once.  The reference runs adVNTR-Filtering on the reads as
+    # they are (genome_analyzer.py:173-199), so a read sequenced from the opposite strand only passes through keywords
+    # that happen to be reverse-palindromic; --prefilter-both-strands (off by default = the reference's candidate sets)
+    # also scans the reverse complements and unions the hits.
     fasta = "".join(">%d\n%s\n" % (i, s.upper()) for i, s in enumerate(seqs))
     keywords = {int(loc["id"]): filtering.get_keywords_for_filtering(loc["left"], loc["repeat_segments"], loc["right"],
                                                                        loc["pattern"], True, 15) for loc in loci}
     _, ids_fwd = filtering.get_filtered_read_ids(fasta, keywords, min_matches=args.min_matches)
-    rc = "".join(">%d\n%s\n" % (i, vntr_finder.reverse_complement(s.upper()) if "N" not in s.upper() else s.upper())
-                 for i, s in enumerate(seqs))
-    _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
+    ids_rev = {}
+    if args.prefilter_both_strands:
+        rc = "".join(">%d\n%s\n" % (i, vntr_finder.reverse_complement(s.upper()) if "N" not in s.upper() else s.upper())
+                     for i, s in enumerate(seqs))
+        _, ids_rev = filtering.get_filtered_read_ids(rc, keywords, min_matches=args.min_matches)
     head = [len(r.seq) for r in samfile.head(5)] if samfile is not None else [len(s) for s in seqs[:5]]
     read_length = sorted(head)[len(head) // 2] if head else 150                   # vntr_finder.py:714-718
     def candidates(loc):
@@ -219,6 +228,9 @@ def main(argv=None):
     g.add_argument("--haploid", action="store_true")
     g.add_argument("--accuracy-filter", action="store_true")
     g.add_argument("--min-matches", type=int, default=5)
+    g.add_argument("--prefilter-both-strands", action="store_true",
+                   help="also run the keyword prefilter on the reverse complement of every read (a superset of the "
+                        "reference's candidate reads; the reference scans the reads as given, genome_analyzer.py:173-199)")
     g.add_argument("-fs", "--frameshift", action="store_true",
                    help="search for a frameshift in the VNTR instead of a copy number (vntr_finder.py:256-309)")
     g.add_argument("--outfmt", choices=["text", "bed", "vcf"], default="text",

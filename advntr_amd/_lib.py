@@ -43,6 +43,7 @@ SYMBOLS = {
     "advntr_batch_fetch_paths": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "advntr_batch_result_ptrs": (ctypes.c_int, [_vp, _vp, _vp]),
     "advntr_batch_device_bytes": (_i64, [_vp]),
+    "advntr_batch_info": (ctypes.c_int, [_vp, _vp, _i32]),
     "advntr_kwfilter_create": (_vp, [_vp, _vp, _vp, _i32]),
     "advntr_kwfilter_destroy": (None, [_vp]),
     "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -385,6 +386,16 @@ class DeviceBatch(object):
 
     def device_bytes(self):
         return int(load().advntr_batch_device_bytes(self._h))
+
+    def kernels(self):
+        """[(kernel name as rocprofv3 shows it, reads, tiles)] in launch order (advntr_batch_info)."""
+        buf = ctypes.create_string_buffer(4096)
+        check(load().advntr_batch_info(self._h, ctypes.addressof(buf), 4096))
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, reads, tiles = line.rsplit(" ", 2)
+            out.append((name, int(reads), int(tiles)))
+        return out
 
     def result_ptrs(self):
         a, b = ctypes.c_void_p(0), ctypes.c_void_p(0)

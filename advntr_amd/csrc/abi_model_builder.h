@@ -162,6 +162,7 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     slab->refs = n;
     for (int i = 0; i < n; ++i) {
         out[i]->slab = slab;
+        out[i]->device = current_device();
         hmm_bind(out[i], (const uint8_t *)slab->d + at[i]);
     }
     return ADVNTR_OK;

@@ -15,6 +15,7 @@ struct ColumnLaunch {
     int nc_max = 0;
     int sink_stride = COL_MAX_READ + 1;
     size_t lds_bytes = 0;
+    size_t lds_core_bytes = 0, lds_min_bytes = 0;     // footprints of staging levels 1 and 0 (batch_build)
     int lds_level = 2;
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
@@ -121,13 +122,19 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     hipLaunchKernelGGL((viterbi_columns_stream_kernel<K>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
 }
 
+// LDS bytes of a sum-product launch whose tables take `tables` bytes: + tile slot + the linear row-0 table
+static inline size_t forward_lds_bytes(const size_t tables, const int nc_max)
+{
+    return ((tables + 15) & ~size_t(15)) + 16 + 16 * (size_t)nc_max + 16;
+}
+
 // slot: which tile list (0..3 = reads of 1..4 chunks, 4 = long reads).  The sum-product sweep works in the linear domain
 // with a per-row scale of 16, which bounds a row tile to 192 rows: reads of 193-256 rows (slot 3) go through the
 // row-tiled kernel like the long ones.
 template <int K, bool LONG>
-static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int slot)
+static inline hipError_t column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int slot)
 {
-    if (cl.tiles[slot].empty()) return;
+    if (cl.tiles[slot].empty()) return hipSuccess;
     ColArgs g{};
     g.a = a;
     g.tiles = cl.d_tiles[slot];
@@ -137,18 +144,20 @@ static inline void column_launch_fwd(const ColumnLaunch &cl, const BatchArgs &a,
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     const int grid = std::min(cl.grid, g.n_tiles);
-    const size_t lds = ((cl.lds_bytes + 15) & ~size_t(15)) + 16 + 16 * (size_t)cl.nc_max + 16;      // + linear row-0 table
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)forward_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)forward_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL((forward_columns_kernel<K, LONG>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g);
+    return hipSuccess;
 }
 
 // sum-product on the row-blocked layout: the short reads of a large batch (tile list 5 + cfg)
 template <int R, int G>
-static inline void column_launch_fwd_rows(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int cfg)
+static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int cfg)
 {
     const int slot = 5 + cfg;
-    if (cl.tiles[slot].empty()) return;
+    if (cl.tiles[slot].empty()) return hipSuccess;
     ColArgs g{};
     g.a = a;
     g.tiles = cl.d_tiles[slot];
@@ -158,8 +167,10 @@ static inline void column_launch_fwd_rows(const ColumnLaunch &cl, const BatchArg
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     const int grid = std::min(cl.grid, g.n_tiles);
-    const size_t lds = ((cl.lds_bytes + 15) & ~size_t(15)) + 16 + 16 * (size_t)cl.nc_max + 16;      // + linear row-0 table
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL((forward_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g);
+    return hipSuccess;
 }

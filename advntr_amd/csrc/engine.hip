@@ -7,10 +7,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/advntr_hip.h"
@@ -183,7 +185,8 @@ struct advntr_hmm {
     size_t off[14] = {0};             // table offsets: [0..11] generic-kernel tables, [12] classes, [13] column program
     bool gen_in_blob = false;         // the generic-kernel tables are part of host_blob / the core allocation
     void *d_gen = nullptr;            // generic-kernel tables uploaded on demand (hmm_ensure_generic)
-    std::mutex gen_mu;
+    std::mutex gen_mu;            // guards d_gen and the generic-kernel pointers of `dev`
+    int device = 0;               // the device that holds the blob
     DevModel dev{};
 };
 
@@ -369,12 +372,20 @@ static int hmm_ensure_generic(advntr_hmm *H)
 {
     std::lock_guard<std::mutex> lk(H->gen_mu);
     if (H->gen_in_blob || H->d_gen) return ADVNTR_OK;
+    if (current_device() != H->device)
+        return fail(ADVNTR_ERR_DEVICE, "model lives on device %d, the current device is %d", H->device, current_device());
     BlobBuilder B;
     size_t o[12];
     generic_tables(*H, B, o);
-    HIP_TRY(hipMalloc(&H->d_gen, B.bytes.size()));
-    HIP_TRY(hipMemcpy(H->d_gen, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice));
-    bind_generic(H->dev, (const uint8_t *)H->d_gen, o);
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, B.bytes.size()));
+    const hipError_t e = hipMemcpy(d, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(ADVNTR_ERR_DEVICE, "upload of the generic-kernel tables failed: %s", hipGetErrorString(e));
+    }
+    bind_generic(H->dev, (const uint8_t *)d, o);
+    H->d_gen = d;              // published last: a later call returns early only when the tables are bound
     return ADVNTR_OK;
 }
 
@@ -411,6 +422,7 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
         delete H;
         return nullptr;
     }
+    H->device = current_device();
     hmm_bind(H, H->d_blob);
     return H;
 }
@@ -565,19 +577,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     // which runs when ADVNTR_FLAG_ANTIDIAGONAL asks for it or a model's tables do not fit 16-bit LDS addresses.  (The
     // row-blocked kernels are the faster ones at every batch size: 16 reads 0.41 against 0.50 ms, 4 000 reads 0.62
     // against 0.81 ms, scripts/small_batch_bench.py.)
-    int64_t n_short = 0, rows_lo = 1;
-    if (const char *e = getenv("ADVNTR_ROWS_MIN_READ")) rows_lo = atoll(e);          // (experiments: shortest read routed there)
-    auto rows_len = [&](int64_t n) { return n >= rows_lo && n <= ROWS_MAX_READ; };
-    for (int r : col_reads) n_short += rows_len(read_off[r + 1] - read_off[r]);
-    int64_t rows_min = 1;
-    if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_min = atoll(e);
-    const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_short >= rows_min;
+    auto rows_len = [&](int64_t n) { return n >= 1 && n <= ROWS_MAX_READ; };
+    const bool use_rows = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL));
     // bucket 3 = longer reads (156 bases and up): the row-tiled row-blocked kernel (one read per wavefront like the
     // anti-diagonal one, so batches of any size go there)
-    int64_t n_longer = 0, rows_long_min = 1;
-    for (int r : col_reads) n_longer += (read_off[r + 1] - read_off[r]) > ROWS_MAX_READ;
-    if (const char *e = getenv("ADVNTR_ROWS_MIN")) rows_long_min = atoll(e);
-    const bool use_rows_long = !(flags & (ADVNTR_FLAG_STREAM | ADVNTR_FLAG_ANTIDIAGONAL)) && n_longer >= rows_long_min;
+    const bool use_rows_long = use_rows;
     auto kof = [&](int r) {
         const int64_t n = read_off[r + 1] - read_off[r];
         // (the row-blocked sweep reaches class and emission records through 16-bit LDS addresses: a model whose two tables
@@ -612,7 +616,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if ((rc = hmm_ensure_generic(B->models[read_model[r]]))) return rc;
     {
         std::vector<DevModel> dm;
-        for (auto *H : B->models) dm.push_back(H->dev);
+        for (auto *H : B->models) {
+            if (H->device != B->device)
+                return fail(ADVNTR_ERR_DEVICE, "batch on device %d holds a model that lives on device %d", B->device, H->device);
+            std::lock_guard<std::mutex> lk(H->gen_mu);          // another thread may be binding the generic tables
+            dm.push_back(H->dev);
+        }
         if ((rc = B->dmalloc(&B->d_models, dm.size()))) return rc;
         HIP_TRY(hipMemcpy(B->d_models, dm.data(), dm.size() * sizeof(DevModel), hipMemcpyHostToDevice));
     }
@@ -654,8 +663,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         // > 1000 columns) leave the traceback's state table, then the unpadded column-info table, in HBM/L2 when
         // that buys another resident workgroup
         auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + 1024))); };
+        C.lds_core_bytes = lds_core; C.lds_min_bytes = lds_min;
         if (wgs(lds_core) > wgs(C.lds_bytes)) { C.lds_bytes = lds_core; C.lds_level = 1; }
         if (wgs(lds_min) > wgs(C.lds_bytes)) { C.lds_bytes = lds_min; C.lds_level = 0; }
+        if (C.lds_bytes + 16 > 160 * 1024)
+            return fail(ADVNTR_ERR_TOO_LARGE, "batch: the class / emission tables of a %d-column model take %zu B of LDS "
+                        "(> 160 KiB per CU)", C.nc_max, C.lds_bytes + 16);
         int per_cu = wgs(C.lds_bytes);
         if (C.stream) {
             // stream kernel: reads of one model, any length, packed back to back by each wavefront
@@ -798,6 +811,39 @@ extern "C" int advntr_batch_result_ptrs(advntr_batch *B, void **d_logp, void **d
 }
 
 extern "C" int64_t advntr_batch_device_bytes(const advntr_batch *B) { return B ? B->device_bytes : 0; }
+
+// Which kernels advntr_batch_run launches for this batch: one line "kernel reads tiles" per non-empty launch, in launch
+// order (the routing is decided in batch_build from read lengths, model tables and flags only).
+extern "C" int advntr_batch_info(const advntr_batch *B, char *buf, int32_t capacity)
+{
+    if (!B || !buf || capacity <= 0) return fail(ADVNTR_ERR_ARG, "advntr_batch_info: bad argument");
+    static const char *const names[9] = {
+        "viterbi_columns_kernel<1, false>", "viterbi_columns_kernel<2, false>", "viterbi_columns_kernel<3, false>",
+        "viterbi_columns_kernel<4, false>", "viterbi_columns_kernel<3, true>", "viterbi_rows_kernel<5, 2>",
+        "viterbi_rows_kernel<4, 2>", "viterbi_rows_kernel<4, 4>", "viterbi_rows_long_kernel<4>"};
+    static_assert(COL_LONG_K == 3 && ROWS_LONG_R == 4, "kernel names above");
+    std::string out;
+    char line[160];
+    if (B->n_col) {
+        static const int launch_order[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+        for (int k : launch_order) {
+            const auto &tiles = B->col.tiles[k];
+            if (tiles.empty()) continue;
+            int64_t reads = 0;
+            for (const ColTile &t : tiles) reads += t.count;
+            snprintf(line, sizeof line, "%s %lld %zu\n", B->col.stream ? "viterbi_columns_stream_kernel<3>" : names[k],
+                     (long long)reads, tiles.size());
+            out += line;
+        }
+    }
+    if (B->n_gen) {
+        snprintf(line, sizeof line, "viterbi_generic_kernel %d %d\n", B->n_gen, B->grid_gen);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > capacity) return fail(ADVNTR_ERR_TOO_LARGE, "advntr_batch_info: need %zu bytes", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return ADVNTR_OK;
+}
 
 static BatchArgs make_args(advntr_batch *B)
 {
@@ -946,15 +992,24 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
                 BatchArgs a = make_args(B);
                 a.n_reads = B->n_col;
                 a.order = B->d_order;
-                column_launch_fwd<1, false>(B->col, a, B->stream, 0);
-                column_launch_fwd<2, false>(B->col, a, B->stream, 1);
-                column_launch_fwd<3, false>(B->col, a, B->stream, 2);
-                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3);      // 193-256 rows: two row tiles
-                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4);
-                column_launch_fwd_rows<5, 2>(B->col, a, B->stream, 0);              // the row-blocked kernels' lists
-                column_launch_fwd_rows<4, 2>(B->col, a, B->stream, 1);
-                column_launch_fwd_rows<4, 4>(B->col, a, B->stream, 2);
-                column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 8);
+                // batch_build sized the LDS staging level for the Viterbi kernels; the sum-product kernels add a linear
+                // row-0 table (16 B per column): step the level down until the launch fits the 160 KiB of a CU
+                ColumnLaunch &C = B->col;
+                const size_t kLds = 160 * 1024;
+                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 1) { C.lds_bytes = C.lds_core_bytes; C.lds_level = 1; }
+                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 0) { C.lds_bytes = C.lds_min_bytes; C.lds_level = 0; }
+                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds)
+                    return fail(ADVNTR_ERR_TOO_LARGE, "advntr_forward_batch: a model of %d columns needs %zu B of LDS for the "
+                                "sum-product sweep (> 160 KiB)", C.nc_max, forward_lds_bytes(C.lds_bytes, C.nc_max));
+                HIP_TRY((column_launch_fwd<1, false>(B->col, a, B->stream, 0)));
+                HIP_TRY((column_launch_fwd<2, false>(B->col, a, B->stream, 1)));
+                HIP_TRY((column_launch_fwd<3, false>(B->col, a, B->stream, 2)));
+                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3)));      // 193-256 rows: two row tiles
+                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4)));
+                HIP_TRY((column_launch_fwd_rows<5, 2>(B->col, a, B->stream, 0)));              // the row-blocked kernels' lists
+                HIP_TRY((column_launch_fwd_rows<4, 2>(B->col, a, B->stream, 1)));
+                HIP_TRY((column_launch_fwd_rows<4, 4>(B->col, a, B->stream, 2)));
+                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 8)));
             }
             if (B->n_gen) {
                 BatchArgs a = generic_args(B);

@@ -96,44 +96,26 @@ __device__ __forceinline__ double bcast63(double v)
 // no packing are needed.  Three instructions: v_cmp_gt_f64 into VCC, v_max_f64 for the value (equal to the select:
 // no NaNs occur and max(a,b) of equal values is that value), v_addc_co_u32 bits+bits+VCC.  Written as assembly
 // because the compiler lowers the C form to a compare, two or three VOP3 selects per relaxation and an or/shift
-// chain per cell (SQ_INSTS_VALU per launch 13.3 G -> see profiles); -DCOL_RELAX_PLAIN builds the C form.
+// chain per cell (SQ_INSTS_VALU per launch 13.3 G -> see profiles).
 //   byte = aI<<5 | bI<<4 | aM<<3 | bM<<2 | aB<<1 | bB      (a: the 2nd candidate won, b: the last one did)
 __device__ __forceinline__ void relax_bit(double &best, int &bits, const double cand)
 {
-#ifdef COL_RELAX_PLAIN
-    const bool won = cand > best;
-    best = won ? cand : best;
-    bits = bits + bits + (won ? 1 : 0);
-#else
     asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
         "v_max_f64 %0, %0, %2\n\t"
-#ifdef COL_RELAX_NOP
-        "s_nop 0\n\t"
-#endif
         "v_addc_co_u32_e32 %1, vcc, %1, %1, vcc"
         : "+v"(best), "+v"(bits)
         : "v"(cand)
         : "vcc");
-#endif
 }
 // the first relaxation of a cell starts the byte (bits = won): saves the move that would clear it
 __device__ __forceinline__ void relax_bit_first(double &best, int &bits, const double cand)
 {
-#ifdef COL_RELAX_PLAIN
-    const bool won = cand > best;
-    best = won ? cand : best;
-    bits = won ? 1 : 0;
-#else
     asm("v_cmp_gt_f64_e32 vcc, %2, %0\n\t"
         "v_max_f64 %0, %0, %2\n\t"
-#ifdef COL_RELAX_NOP
-        "s_nop 0\n\t"
-#endif
         "v_addc_co_u32_e32 %1, vcc, 0, %3, vcc"
         : "+v"(best), "=v"(bits)
         : "v"(cand), "v"(0)
         : "vcc");
-#endif
 }
 // pointers out of a back-pointer byte: 0/1/2(/3) = index of the winning candidate in evaluation order
 // (M: 0 = I, 1 = M -- or, in a read's first row, the entry edge --, 3 = b of the previous column)
@@ -350,9 +332,7 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
     }
     R.pI[k] = nI; R.pM[k] = nM; R.pB[k] = nB;
     R.I[k] = vI; R.M[k] = vM; R.B[k] = vB;
-#ifndef EXP_NO_BP
     if (!FWD) C.bp[(int64_t)(s - 1) * TPAD + (t - 1)] = (uint8_t)bits;
-#endif
     if (MODE == 2) {
         if (k == K - 1) {                                            // last row of a full tile -> next tile's seam
             if (lane == 63 && c >= 0 && c < NC) {
@@ -712,13 +692,11 @@ __device__ __forceinline__ void col_finish_read(const ColArgs &g, const uint32_t
     const double logp = col_tail(cp, final_row, tailwin, NC, lane);
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
-#ifndef EXP_NO_TB
     if (logp != -INFINITY) {
         len = col_traceback<K>(cp, L, n, M.start, M.P, bp, slab, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane,
                                U0, ring, W);
         len = __builtin_amdgcn_readfirstlane(len);
     }
-#endif
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);

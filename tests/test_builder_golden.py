@@ -10,12 +10,14 @@ import pytest
 
 from conftest import READ_MATCHER_GOLDENS, load_golden
 from advntr_amd import hmm_utils, settings
+from oracle import stepwise_builder
 
 
 def build_from_golden(g, native=True):
     settings.MAX_ERROR_RATE = g["error_rate"]
     try:
-        return hmm_utils.get_read_matcher_model(g["left"], g["right"], g["aligned_repeats"], g["copies"], native=native)
+        build = hmm_utils.get_read_matcher_model if native else stepwise_builder.get_read_matcher_model
+        return build(g["left"], g["right"], g["aligned_repeats"], g["copies"])
     finally:
         settings.MAX_ERROR_RATE = 0.05
 
@@ -33,7 +35,7 @@ def _close(got, want):
 @pytest.mark.parametrize("name", READ_MATCHER_GOLDENS)
 def test_read_matcher_matches_reference_bake(name, native):
     """native: the library's C++ builder (csrc/model_builder.h); stepwise: the call-by-call assembly through the
-    pomegranate mirror.  Both must reproduce the reference's baked model."""
+    pomegranate mirror (oracle/stepwise_builder.py, the checker of the native builder).  Both must reproduce the reference's baked model."""
     g = load_golden(name)
     gm = g["model"]
     m = build_from_golden(g, native)
@@ -68,7 +70,8 @@ def test_profile_parameters_multi_row():
 @pytest.mark.parametrize("native", [True, False])
 def test_unaligned_repeats_are_refused(native):
     with pytest.raises(NotImplementedError):
-        hmm_utils.get_read_matcher_model("ACGTACGT", "TTGACCAA", ["ACGTT", "ACGT"], 2, native=native)
+        build = hmm_utils.get_read_matcher_model if native else stepwise_builder.get_read_matcher_model
+        build("ACGTACGT", "TTGACCAA", ["ACGTT", "ACGT"], 2)
 
 
 def _baked_equals(m, gm):
@@ -126,7 +129,8 @@ def test_model_json_round_trip_equals_the_reference():
         assert [s.name for s in again.states] == case["loaded"]["state_names"]
     spec = g["cases"][0]["spec"]
     for native in (True, False):
-        fresh = hmm_utils.get_read_matcher_model(spec["left"], spec["right"], [spec["pattern"]], spec["copies"], native=native)
+        build = hmm_utils.get_read_matcher_model if native else stepwise_builder.get_read_matcher_model
+        fresh = build(spec["left"], spec["right"], [spec["pattern"]], spec["copies"])
         _baked_equals(HiddenMarkovModel.from_json(fresh.to_json()), g["cases"][0]["loaded"])
 
 
@@ -170,7 +174,8 @@ def test_model_reestimated_from_viterbi_paths(native):
     g = load_golden("model_update")
     vpaths = [(seq, [(0, State(None, n)) for n in names]) for seq, names in g["vpaths"]]
     assert hmm_utils.get_multiple_alignment_of_repeats_from_reads(vpaths) == g["alignment"]
-    m = hmm_utils.get_read_matcher_model(g["left"], g["right"], None, g["copies"], vpaths, native=native)
+    build = hmm_utils.get_read_matcher_model if native else stepwise_builder.get_read_matcher_model
+    m = build(g["left"], g["right"], None, g["copies"], vpaths)
     gm = g["model"]
     assert [s.name for s in m.states] == gm["state_names"]
     assert (m.silent_start, m.start_index, m.end_index) == (gm["silent_start"], gm["start_index"], gm["end_index"])

@@ -527,7 +527,8 @@ def test_cli_genotype_text_output(tmp_path):
     (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
     from conftest import ROOT
     out = subprocess.run([sys.executable, "-m", "advntr_amd", "genotype", "--loci", str(tmp_path / "loci.json"),
-                          "--reads", str(tmp_path / "reads.fa")], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
+                          "--reads", str(tmp_path / "reads.fa"), "--prefilter-both-strands"], cwd=ROOT,
+                         stdout=subprocess.PIPE, check=True).stdout.decode()
     assert out == "11\n3/5\n12\n4/4\n"
 
 
@@ -558,7 +559,8 @@ def test_cli_genotype_from_model_database(tmp_path):
                 reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
     reads += [workloads.rand_seq(rng, 150) for _ in range(100)]
     (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
-    cmd = [sys.executable, "-m", "advntr_amd", "genotype", "--models", db, "--reads", str(tmp_path / "reads.fa")]
+    cmd = [sys.executable, "-m", "advntr_amd", "genotype", "--models", db, "--reads", str(tmp_path / "reads.fa"),
+           "--prefilter-both-strands"]
     out = subprocess.run(cmd + ["--align-repeats"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
     assert out == "21\n2/4\n22\n3/6\n"
     out = subprocess.run(cmd + ["--vntr-id", "21"], cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout.decode()
@@ -679,7 +681,8 @@ def test_cli_sharded_over_two_ranks_equals_single_process(tmp_path):
                 reads.append(s if rng.random() < 0.5 else vntr_finder.reverse_complement(s))
     (tmp_path / "loci.json").write_text(json.dumps(loci))
     (tmp_path / "reads.fa").write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
-    args = ["genotype", "--loci", str(tmp_path / "loci.json"), "--reads", str(tmp_path / "reads.fa"), "--outfmt", "bed"]
+    args = ["genotype", "--loci", str(tmp_path / "loci.json"), "--reads", str(tmp_path / "reads.fa"), "--outfmt", "bed",
+            "--prefilter-both-strands"]
     single = subprocess.run([sys.executable, "-m", "advntr_amd"] + args, cwd=ROOT, stdout=subprocess.PIPE, check=True).stdout
     env = dict(os.environ, ADVNTR_DIST_BACKEND="gloo")
     multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

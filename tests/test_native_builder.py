@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from advntr_amd import _lib, hmm_utils
+from oracle import stepwise_builder
 
 
 def _random_locus(rng, rows_max=6):
@@ -57,7 +58,7 @@ def test_native_equals_stepwise_on_random_loci():
     native = hmm_utils.build_read_matcher_models(loci, threads=4)               # numpy.exp through the callback
     libm = hmm_utils.build_read_matcher_models(loci, threads=4, exp="libm")
     for locus, n, lm in zip(loci, native, libm):
-        ref = hmm_utils.get_read_matcher_model(*locus, native=False)
+        ref = stepwise_builder.get_read_matcher_model(*locus)
         _same(n, ref, exact=True)
         _same(lm, ref, exact=False)
 
@@ -70,7 +71,7 @@ def test_illumina_shapes_and_thread_counts_agree():
     many = hmm_utils.build_read_matcher_models(loci, threads=0)
     for locus, a, b in zip(loci, one, many):
         _same(a, b, exact=True)
-        _same(a, hmm_utils.get_read_matcher_model(*locus, native=False), exact=True)
+        _same(a, stepwise_builder.get_read_matcher_model(*locus), exact=True)
     assert (one[1].n_states, one[1].silent_start, one[1].n_edges) == (1413, 921, 4626)      # REF150
 
 
@@ -93,7 +94,7 @@ def test_built_model_host_surface():
     assert m.states[m.start_index].name == "Read Matcher-start" and m.states[m.end_index].name == "Read Matcher-end"
     assert m.start is m.states[m.start_index]
     assert all(s.is_silent() == (i >= m.silent_start) for i, s in enumerate(m.states))
-    ref = hmm_utils.get_read_matcher_model("ACGTACGTAC", "TTGACCAATG", ["ACGTT"], 2, native=False)
+    ref = stepwise_builder.get_read_matcher_model("ACGTACGTAC", "TTGACCAATG", ["ACGTT"], 2)
     assert np.array_equal(m.dense_transition_matrix(), ref.dense_transition_matrix())
     i = m.silent_start - 1
     assert m.states[i].distribution.log_probability("A") == ref.states[i].distribution.log_probability("A")
@@ -160,6 +161,6 @@ def test_builder_aligns_ragged_units_only_on_request():
     settings.ALIGN_REPEATS = True
     try:
         _same(hmm_utils.get_read_matcher_model(left, right, units, 3), want, exact=True)
-        _same(hmm_utils.get_read_matcher_model(left, right, units, 3, native=False), want, exact=True)
+        _same(stepwise_builder.get_read_matcher_model(left, right, units, 3), want, exact=True)
     finally:
         settings.ALIGN_REPEATS = False
