@@ -71,8 +71,9 @@ def genotype(args):
                                      loc.get("gene_name"), loc.get("annotation"), len(loc["repeat_segments"]))
             v.init_from_xml(loc["repeat_segments"], loc["left"], loc["right"])
             loc["vntr"] = v
-    from . import genome_analyzer, sharding
-    rank = _init_distributed()
+    from . import comm as comm_mod, genome_analyzer, sharding
+    comm = args.comm = comm_mod.init_from_env()       # one process per GPU under a launcher; None for a plain run
+    rank = comm.rank if comm is not None else 0
     if rank == 0 and not args.frameshift:
         if args.outfmt == "bed":
             sys.stdout.write(genome_analyzer.bed_header(args.haploid))
@@ -107,7 +108,7 @@ def genotype(args):
                     accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
                 out.append(row(loc, vntr_finder.GenotypeResult(geno, len(spanning), len(spanning), 0, prob)))
             return out
-        return finish(sharding.run_sharded([len(loc["pattern"]) for loc in loci], pacbio_job))
+        return finish(sharding.run_sharded([len(loc["pattern"]) for loc in loci], pacbio_job, comm))
     # Illumina: prefilter every read against all loci at once.  The reference runs adVNTR-Filtering on the reads as
     # they are (genome_analyzer.py:173-199), so a read sequenced from the opposite strand only passes through keywords
     # that happen to be reverse-palindromic; --prefilter-both-strands (off by default = the reference's candidate sets)
@@ -128,8 +129,9 @@ def genotype(args):
         return [seqs[i] for i in sorted(set(int(n) for n in ids_fwd.get(vid, ())) | set(int(n) for n in ids_rev.get(vid, ())))]
 
     cands = [candidates(loc) for loc in loci]
-    # whole loci go to ranks by estimated work (calls x states); one process per GPU under
-    # torch.distributed.run, a plain loop over everything otherwise
+    # whole loci go to ranks by estimated work (calls x states); one process per GPU under a launcher
+    # (`python -m torch.distributed.run --nproc-per-node N -m advntr_amd genotype ...` or any other that sets RANK /
+    # LOCAL_RANK / WORLD_SIZE / MASTER_PORT), rows gathered to rank 0 over RCCL; a plain loop over everything otherwise
     work = [max(1, len(c)) * (6 * read_length + 3 * vntr_finder.get_copies_for_hmm(read_length, len(loc["pattern"])) *
                               (len(loc["repeat_segments"][0]) + 1) + 18) for loc, c in zip(loci, cands)]
     if args.frameshift:        # genome_analyzer.py:260-271: the id, then the frameshift state label or None
@@ -138,7 +140,7 @@ def genotype(args):
             for i in indices:
                 out.append(_frameshift_row(loci[i], cands[i], read_length, hmm_utils, vntr_finder))
             return out
-        return finish(sharding.run_sharded(work, frameshift_job))
+        return finish(sharding.run_sharded(work, frameshift_job, comm))
     def genotype_job(indices):
         # all models of this rank's share in one native build, all (read, strand, locus) calls in one engine batch
         specs = [(loci[i]["left"][-read_length:], loci[i]["right"][:read_length], loci[i]["repeat_segments"],
@@ -162,7 +164,7 @@ def genotype(args):
                                                                     is_haploid=args.haploid)
             out.append(row(loci[i], res))
         return out
-    return finish(sharding.run_sharded(work, genotype_job))
+    return finish(sharding.run_sharded(work, genotype_job, comm))
 
 
 def _frameshift_row(loc, cand, read_length, hmm_utils, vntr_finder):
@@ -172,40 +174,6 @@ def _frameshift_row(loc, cand, read_length, hmm_utils, vntr_finder):
     result = vntr_finder.find_frameshift(model, len(loc["pattern"]), sum(len(x) for x in loc["repeat_segments"]), cand,
                                          loc.get("scaled_score"))
     return "%s\n%s\n" % (loc["id"], result)
-
-
-def _init_distributed():
-    """Under torch.distributed.run (one process per GPU): join the process group over RCCL and bind this rank's GPU.
-    Returns the rank (0 when run as a single process)."""
-    import os
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
-        return 0
-    import torch
-    import torch.distributed as dist
-    from . import _lib
-    # one rank per GPU; ADVNTR_DIST_BACKEND=gloo lets several ranks share a GPU (single-GPU test boxes), where RCCL
-    # would refuse two ranks on one device
-    backend = os.environ.get("ADVNTR_DIST_BACKEND", "nccl")
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not dist.is_initialized():
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=backend)
-    _lib.check(_lib.load().advntr_set_device(local))
-    return dist.get_rank()
-
-
-def _shutdown_distributed():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            dist.barrier()
-            dist.destroy_process_group()
-    except ImportError:
-        pass
 
 
 def main(argv=None):
@@ -241,10 +209,12 @@ def main(argv=None):
             ap.error("genotype needs --reads and/or --alignment")
         if args.alignment and (args.pacbio or args.frameshift):
             ap.error("--alignment is the Illumina copy-number path")
+        args.comm = None
         try:
             return genotype(args)
         finally:
-            _shutdown_distributed()
+            if args.comm is not None:
+                args.comm.close()
     ap.print_help()
     return 2
 

@@ -55,6 +55,16 @@ SYMBOLS = {
     "advntr_built_upload": (_vp, [_vp]),
     "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
     "advntr_built_destroy": (None, [_vp]),
+    "advntr_comm_unique_id": (ctypes.c_int, [_vp]),
+    "advntr_comm_create": (_vp, [_i32, _i32, _vp]),
+    "advntr_comm_destroy": (None, [_vp]),
+    "advntr_comm_info": (ctypes.c_int, [_vp, _vp, _vp]),
+    "advntr_comm_allgather_i64": (ctypes.c_int, [_vp, _i64, _vp]),
+    "advntr_comm_allreduce_max_f64": (ctypes.c_int, [_vp, _vp]),
+    "advntr_comm_barrier": (ctypes.c_int, [_vp]),
+    "advntr_comm_gather_results_start": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
+    "advntr_comm_gather_results_finish": (ctypes.c_int, [_vp, _vp, _vp]),
+    "advntr_comm_gather_bytes": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

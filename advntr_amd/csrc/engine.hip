@@ -1029,3 +1029,4 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
 #include "abi_keyword_filter.h"
 #include "abi_model_builder.h"
 #include "abi_flank_align.h"
+#include "abi_comm.h"

@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- reads/s Viterbi-scored on the BASELINE.json workload, one process per GPU.
+"""bench.py -- reads/s Viterbi-scored on the BASELINE.json workloads, one process per GPU, no PyTorch.
 
-A "step" is one pass of the hot path (Viterbi DP + traceback + path summaries) over one resident batch
-of synthetic reads.  Workload at every N: config C1 of BASELINE.json / SURVEY 8d -- one REF150 locus
-(flank 150, 14-bp pattern, 11 copies: 1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp
-reads PER GPU (weak scaling: the read x locus batch shards with no data-path collective; the only RCCL
-call is the gather of the 40-B/read result records to rank 0, inside the timed region; the gather of pass i
-runs from staging buffers while the kernel of pass i+1 computes, and all of them complete before the clock stops).
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path (Viterbi DP + traceback + path summaries) over one resident batch of synthetic
+reads; inputs are in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+  --gpus 1 (default): config C1 of BASELINE.json / SURVEY 8d -- one REF150 locus (flank 150, 14-bp pattern, 11 copies:
+      1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp reads.  The line also carries the S300 shape
+      (the "~300-state" label of the metric), the roofline object, the VALU bound that actually binds, and the CPU
+      baseline (the C oracle on the host cores, with its calibration against the vendored pomegranate).
+  --gpus N > 1: config C3 -- ONE set of 6 719 synthetic Illumina loci (~1.07 M calls) partitioned over the N GPUs by
+      estimated work (strong scaling; whole loci per rank, LPT), every rank scores its share with no exchange, and the
+      per-call result records are gathered to rank 0 over RCCL inside the timed region (the gather of pass i overlaps
+      the kernels of pass i+1; all gathers complete before the clock stops).  `value` = calls of the WHOLE set per second.
+
+Launching: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the driver's way; only the
+launcher is torch, this file imports none of it) the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; started
+plainly with --gpus N > 1 this process starts the N ranks itself as CHILD processes, before anything touches a GPU,
+forwards rank 0's line and exits with their status (it never replaces itself by another program).
+--dry-run does the planning and the rendezvous without any GPU work (CPU-side check of the multi-rank plumbing).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,6 +32,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS, CLOCK_GHZ = 1024, 2.4      # 256 CUs x 4 SIMDs, 2.4 GHz
 
 
 def algorithmic_bytes(n, m):
@@ -28,19 +40,90 @@ def algorithmic_bytes(n, m):
     return n + (n + 1) * m + (n + m) + 32
 
 
-class _CudaArray(object):
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": typestr, "version": 2}
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000, help="c1: reads per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=2000)
+    ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
+    ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
+    ap.add_argument("--antidiagonal", action="store_true", help="one-read-per-wavefront anti-diagonal kernel")
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "c4"],
+                    help="default: c1 at --gpus 1, c3 at --gpus > 1.  c1: 1 REF150 locus x --reads per GPU (weak); c2: --loci "
+                         "synthetic loci x ~160 calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by "
+                         "estimated work (strong scaling, BASELINE config 3), records gathered to rank 0 over RCCL; "
+                         "c4: --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads per GPU")
+    ap.add_argument("--loci", type=int, default=None, help="c2/c3: default 6719; c4: default 8960")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-s300", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="plan + rendezvous only, no GPU work (host communicator)")
+    ap.add_argument("--dump-records", default=None,
+                    help="rank 0 writes every call's (global id, logp, summary), gathered from all ranks after the timed "
+                         "region, to this .npz (parity of an N-rank run with a 1-rank run: tests/test_gpu_parity.py)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: N ranks as child processes (only when no launcher set RANK for us)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    import socket
+    import tempfile
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rdzv = tempfile.mkdtemp(prefix="advntr_rdzv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ADVNTR_RDZV_DIR=rdzv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                                       # the exact child we started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    import shutil
+    shutil.rmtree(rdzv, ignore_errors=True)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle is the checker, timed here as the reported baseline
+# ------------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def oracle_model(locus):
+    from oracle.oracle import OracleModel
+    a = locus.model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    return OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
 
 
 def cpu_baseline(locus, bases, off, n_sample):
     """The oracle (C restatement of the reference loop, full tables calloc'd per call) on a bounded sample
     of the same reads, 1 thread -- the reference path is single-threaded (GIL held, hmm.pyx:1958)."""
-    from oracle.oracle import OracleModel
-    a = locus.model.baked_arrays()
-    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
-             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
-    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    O = oracle_model(locus)
     sub_off = off[:n_sample + 1]
     t0 = time.perf_counter()
     logp, _ = O.viterbi_many(bases[:sub_off[-1]], sub_off)
@@ -61,248 +144,330 @@ def ru_concordance(O, locus, reads, summ, n_check):
     return same
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=2000)
-    ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
-    ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
-    ap.add_argument("--workload", default="c1", choices=["c1", "c2", "c3", "c4"],
-                    help="c1 (default, the bench line): 1 REF150 locus x --reads per GPU; c2: --loci synthetic loci x ~160 "
-                         "calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by estimated work "
-                         "(strong scaling, BASELINE config 3), per-call records gathered to rank 0 over RCCL; "
-                         "c4: --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads per GPU")
-    ap.add_argument("--loci", type=int, default=64)
-    ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+def load_json(*parts):
+    try:
+        return json.load(open(os.path.join(ROOT, *parts)))
+    except (OSError, ValueError):
+        return None
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    import torch
-    torch.cuda.set_device(local_rank)
-    # under torch.distributed.run (RANK set) the RCCL path is exercised even with one rank, so the
-    # gather code is tested on a single-GPU box too
-    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("ADVNTR_BENCH_DIST", "1") == "1")
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+def pmc_section(workload, n_calls, kernel):
+    """Counters per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench);
+    None when no committed profile describes this workload / kernel / size."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        pmc = load_json("profiles", name)
+        if not pmc:
+            continue
+        for sec in pmc.get("sections", []):
+            if sec.get("workload") == workload and sec.get("calls") == n_calls and sec.get("kernel") == kernel:
+                return dict(sec, file="profiles/" + name)
+        if name == "r01_pmc_summary.json" and workload == "c1" and n_calls == 100000 and kernel == "viterbi_rows_kernel<5, 2>":
+            s = pmc.get("viterbi_rows", {})
+            if s:
+                return {"hbm_bytes_per_launch_fetch_x2": s.get("hbm_bytes_per_launch_fetch_x2"),
+                        "valu_insts_per_launch": s.get("valu_insts_per_launch"), "file": "profiles/" + name,
+                        "stale": "counters of the round-1 build of this kernel"}
+    return None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "RANK" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, argv)
+
+    from advntr_amd import comm as comm_mod
+    rank, local_rank, world = comm_mod.env_world()
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; using %d\n" % (args.gpus, world, world))
+    workload = args.workload or ("c1" if world == 1 else "c3")
+    n_loci = args.loci if args.loci is not None else (8960 if workload == "c4" else 6719)
 
     import __graft_entry__ as entry
     entry.build()
-    from advntr_amd import _lib, workloads
-    _lib.check(_lib.load().advntr_set_device(local_rank))
+    from advntr_amd import _lib, sharding, workloads
 
+    comm = None
+    if world > 1 or "RANK" in os.environ:
+        # (under a launcher the RCCL path is exercised even with one rank, so the gather code runs on a 1-GPU box too)
+        comm = comm_mod.init_from_env(backend="host" if args.dry_run else None, set_device=not args.dry_run)
+    elif not args.dry_run:
+        _lib.check(_lib.load().advntr_set_device(local_rank))
+
+    # ---------------------------------------------------------------- workload
     n = 150
-    flags = _lib.FLAG_FORCE_GENERIC if args.generic else (_lib.FLAG_STREAM if args.stream else 0)
-    total_calls = None
-    if args.workload in ("c2", "c3", "c4"):
-        if args.workload == "c4":
-            loci, reads, which = workloads.make_c4(args.loci, seed=20240603 + rank)
-        elif args.workload == "c3":
-            # every rank derives the same plan and the same LPT partition without communicating
-            from advntr_amd import sharding
-            plan = workloads.c2_plan(args.loci, seed=20240602)
-            work = [calls * 151 * states for calls, states in plan]
-            mine = sharding.partition_loci(work, world)[rank]
-            total_calls = int(sum(c for c, _ in plan))
-            loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602, build=False, only=mine)
+    flags = (_lib.FLAG_FORCE_GENERIC if args.generic else _lib.FLAG_STREAM if args.stream else
+             _lib.FLAG_ANTIDIAGONAL if args.antidiagonal else 0)
+    total_calls, t_build, plan_info = None, 0.0, {}
+    host_workers = max(1, min(32, (os.cpu_count() or 2) // world - 1))
+    if workload == "c3":
+        # every rank derives the same plan and the same LPT partition without communicating (SURVEY 8e)
+        plan = workloads.c2_plan(n_loci, seed=20240602)
+        work = [calls * 151 * states for calls, states in plan]
+        parts = sharding.partition_loci(work, world)
+        mine = parts[rank]
+        total_calls = int(sum(c for c, _ in plan))
+        loads = [float(sum(work[int(k)] for k in p)) for p in parts]
+        plan_info = {"loci_per_rank": [int(len(p)) for p in parts],
+                     "calls_per_rank": [int(sum(plan[int(k)][0] for k in p)) for p in parts],
+                     "load_imbalance_max_over_mean": max(loads) / (sum(loads) / world)}
+    if args.dry_run:
+        counts = comm.allgather_i64(plan_info["calls_per_rank"][rank] if plan_info else args.reads) if comm else [args.reads]
+        if comm:
+            comm.barrier()
+            got = comm.allreduce_max(float(rank))
+            assert got == float(world - 1), got
+        if rank == 0:
+            print(json.dumps({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
+                              "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload == "c3" else "weak",
+                              "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
+                                              "comm": comm.backend if comm else None}, **plan_info)}), flush=True)
+        if comm:
+            comm.close()
+        return 0
+    _lib.require_gpu()
+
+    if workload in ("c2", "c3", "c4"):
+        if workload == "c4":
+            loci, reads, which = workloads.make_c4(n_loci, seed=20240603 + rank, workers=host_workers)
+        elif workload == "c3":
+            loci, reads, which = workloads.make_c2_parallel(n_loci, seed=20240602, build=False, only=mine, workers=host_workers)
         else:
-            loci, reads, which = workloads.make_c2_parallel(args.loci, seed=20240602 + rank, build=False)
+            loci, reads, which = workloads.make_c2_parallel(n_loci, seed=20240602 + rank, build=False, workers=host_workers)
         t_build = time.perf_counter()
-        workloads.build_models(loci)           # native builder, all host cores
+        workloads.build_models(loci)           # native builder, host threads
         t_build = time.perf_counter() - t_build
         locus = loci[0]
         bases, off = _lib.encode_reads(reads)
         from advntr_amd.pomegranate import device_models
         dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
-        args.reads = len(reads)
+        n_reads = len(reads)
         batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
-        dm = dms[0]
         ms = np.array([d.m for d in dms])
         m = int(round(float(np.mean(ms[which]))))
-        P, E = locus.model.silent_start, int(np.mean([l.model.n_edges for l in loci]))
+        edges_per_locus = np.array([l.model.n_edges for l in loci], np.int64)
+        P, E = locus.model.silent_start, int(np.mean(edges_per_locus))
         lens = np.diff(off)
         n = int(round(float(lens.mean())))
         # exact sums over the calls (models and read lengths differ per call)
         alg_bytes_total = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
-        relax_total = float(np.sum((lens + 1) * np.array([l.model.n_edges for l in loci], np.int64)[which]))
-        args.no_cpu = True
+        relax_total = float(np.sum((lens + 1) * edges_per_locus[which]))
     else:
         locus = workloads.ref150()
         a = locus.model.baked_arrays()
         m, P, E = a["m"], a["silent_start"], len(a["in_src"])
-        reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, args.reads, n)
+        n_reads = args.reads
+        reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, n_reads, n)
         bases, off = _lib.encode_reads(reads)
-        dm = locus.model.device_model()
-        batch = _lib.DeviceBatch([dm], bases, off, np.zeros(args.reads, np.int32), flags=flags)
-    kernel = "viterbi_columns" if (dm.has_column_program() and not args.generic) else "viterbi_generic"
-    # reads of up to 155 bases go to the row-blocked kernels (engine.hip: use_rows); the name is what
-    # rocprofv3 --kernel-trace shows for the dominant kernel of this command
-    if (kernel == "viterbi_columns" and not args.stream and n <= 155
-            and "ADVNTR_ROWS_MIN" not in os.environ and "ADVNTR_ROWS_MIN_READ" not in os.environ):
-        kernel = "viterbi_rows"
+        batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(n_reads, np.int32), flags=flags)
+        alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
+        relax_total = float(n_reads) * (n + 1) * E
+    kernels = batch.kernels()                   # what the engine launches for this batch (advntr_batch_info)
+    kernel = max(kernels, key=lambda k: k[1])[0] if kernels else "none"
 
-    gathered = None
-    if use_dist:
-        p_logp, p_sum = batch.result_ptrs()
-        e_logp = torch.as_tensor(_CudaArray(p_logp, (args.reads,), "<f8"), device="cuda")
-        e_sum = torch.as_tensor(_CudaArray(p_sum, (args.reads, 8), "<i4"), device="cuda")
-        # ranks may hold different numbers of calls (c3): gather fixed-size buffers padded to the largest share
-        cap = torch.tensor([args.reads], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        cap = int(cap.item())
-        # staging buffers: the gather of step i runs from them while the kernel of step i+1 refills the engine's
-        # result arrays (the only collective of the path overlaps the next pass instead of serialising with it)
-        t_logp = torch.zeros(cap, dtype=torch.float64, device="cuda")
-        t_sum = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
-        if rank == 0:
-            gathered = ([torch.empty_like(t_logp) for _ in range(world)],
-                        [torch.empty_like(t_sum) for _ in range(world)])
-    pending = []
+    # ---------------------------------------------------------------- timed region
+    counts = comm.allgather_i64(n_reads) if comm else [n_reads]
+    use_gather = comm is not None and comm.backend == "rccl"
+    state = {"pending": False}
 
     def step():
         batch.run()
-        if use_dist:
-            batch.sync()                                   # this pass's records are final
-            for w in pending:                              # the previous gather has had a whole pass to finish
-                w.wait()
-            del pending[:]
-            t_logp[:args.reads].copy_(e_logp)
-            t_sum[:args.reads].copy_(e_sum)
-            torch.cuda.current_stream().synchronize()      # engine buffers may be overwritten by the next pass
-            pending.append(dist.gather(t_logp, gathered[0] if rank == 0 else None, dst=0, async_op=True))
-            pending.append(dist.gather(t_sum, gathered[1] if rank == 0 else None, dst=0, async_op=True))
+        if use_gather:
+            if state["pending"]:                            # the previous gather has had a whole pass to finish
+                comm.gather_results_finish(fetch=False)
+            comm.gather_results_start(batch, counts, root=0)      # queued behind this pass; the next pass overlaps it
+            state["pending"] = True
 
-    def drain():
-        for w in pending:
-            w.wait()
-        del pending[:]
+    def drain(fetch=False):
+        out = (None, None)
+        if state["pending"]:
+            out = comm.gather_results_finish(fetch=fetch)
+            state["pending"] = False
+        return out
 
     for _ in range(args.warmup):
         step()
     drain()
     batch.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    if comm:
+        comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()                                                # every gather of the timed steps completes inside the region
     batch.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm:
+        comm.barrier()
+    elapsed_mine = time.perf_counter() - t0
+    elapsed = comm.allreduce_max(elapsed_mine) if comm else elapsed_mine
 
-    # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside
-    # the bench); None when the profile does not describe this workload/kernel
-    traffic, valu_insts = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        if args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_rows":
-            traffic = pmc["viterbi_rows"]["hbm_bytes_per_launch_fetch_x2"] / 1e9
-            valu_insts = pmc["viterbi_rows"].get("valu_insts_per_launch")
-        elif args.workload == "c1" and args.reads == 100000 and kernel == "viterbi_columns":
-            traffic = pmc["hbm_bytes_per_launch_fetch_x2"] / 1e9
-            valu_insts = pmc.get("valu_insts_per_launch")
-    except Exception:
-        traffic = None
-
+    # one more pass outside the timed region whose gathered records rank 0 checks against what its engine holds
+    gathered = (None, None)
+    if use_gather:
+        step()
+        gathered = drain(fetch=True)
     # kernel-only duration, HIP events on the engine's launch stream
     kernel_ms = batch.run_timed(max(1, min(args.steps, 3)))
     logp, summ = batch.fetch()
-    if use_dist and rank == 0:
-        # the gathered copy of rank 0's own records must equal what the engine holds
-        assert np.array_equal(gathered[0][0][:args.reads].cpu().numpy(), logp), "RCCL gather returned different log-probs"
-        assert np.array_equal(gathered[1][0][:args.reads].cpu().numpy(), summ), "RCCL gather returned different summaries"
+    per_rank = None
+    if comm:
+        rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
+                          "kernel_ms": kernel_ms, "model_build_s": t_build}).encode()
+        parts_json = comm.gather_bytes(rec, 0)
+        if rank == 0:
+            per_rank = [json.loads(p) for p in parts_json]
+    if use_gather and rank == 0:
+        at = 0                                              # rank 0's own records sit first
+        assert np.array_equal(gathered[0][at:at + n_reads], logp), "RCCL gather returned different log-probabilities"
+        assert np.array_equal(gathered[1][at:at + n_reads], summ), "RCCL gather returned different summaries"
+        assert len(gathered[0]) == sum(counts)
+        if workload == "c3":
+            assert sum(counts) == total_calls, (sum(counts), total_calls)
 
+    if args.dump_records:
+        if workload == "c3":                                # global call id = position in the whole set's locus order
+            first = np.concatenate([[0], np.cumsum([c for c, _ in plan])])
+            ids = np.concatenate([np.arange(first[int(k)], first[int(k) + 1]) for k in mine]) if len(mine) else np.zeros(0, np.int64)
+        else:
+            ids = np.arange(n_reads, dtype=np.int64) + rank * n_reads
+        res = sharding.gather_records(comm, ids, logp, summ) if comm else (ids, logp, summ)
+        if rank == 0:
+            np.savez(args.dump_records, ids=res[0], logp=res[1], summary=res[2])
+
+    rc = 0
     if rank == 0:
-        total_reads = total_calls if total_calls is not None else args.reads * world
+        total_reads = total_calls if total_calls is not None else n_reads * world
         value = total_reads * args.steps / elapsed
         B = algorithmic_bytes(n, m)
-        if args.workload == "c1":
-            alg_bytes_total, relax_total = float(B) * args.reads, float(args.reads) * (n + 1) * E
         achieved = alg_bytes_total / (kernel_ms * 1e-3) / 1e9
+        pmc = pmc_section(workload, n_reads, kernel) or {}
+        traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
+        traffic = traffic / 1e9 if traffic else None
+        valu_insts = pmc.get("valu_insts_per_launch")
+        if workload == "c1":
+            metric = "reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
+            wl = ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic 150-bp reads per GPU, "
+                  "seed 20240601")
+        elif workload == "c4":
+            metric = ("calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs, "
+                      "mean %d states)" % (n, n_loci, m))
+            wl = ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x 20 trimmed "
+                  "spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution noise, seed 20240603; "
+                  "host model build %.2f s" % (n_loci, t_build))
+        else:
+            metric = ("calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (n_loci, world)
+                      if workload == "c3" else
+                      "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs, mean %d states)" % (n_loci, m))
+            wl = ("%s: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x ~Poisson(80) mapped + "
+                  "2*Poisson(40) unmapped-strand calls, seed 20240602%s; host model build %.2f s (native builder)"
+                  % (workload.upper(), n_loci,
+                     " (whole loci assigned to ranks by LPT on calls x states; %d calls in total)" % total_calls
+                     if workload == "c3" else "", t_build))
         out = {
-            "metric": ("reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
-                       if args.workload == "c1" else
-                       "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (args.loci, world)
-                       if args.workload == "c3" else
-                       "calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs, "
-                       "mean %d states)" % (n, args.loci, m) if args.workload == "c4" else
-                       "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs, mean %d states)" % (args.loci, m)),
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if args.workload == "c3" else "weak",
+            "scaling": "strong" if workload == "c3" else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic "
-                                    "150-bp reads per GPU, seed 20240601") if args.workload == "c1" else
-                                   ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x "
-                                    "20 trimmed spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution "
-                                    "noise, seed 20240603; host model build %.2f s" % (args.loci, t_build))
-                                   if args.workload == "c4" else
-                                   ("%s: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x "
-                                    "~Poisson(80) mapped + 2*Poisson(40) unmapped-strand calls, seed 20240602%s; "
-                                    "host model build %.2f s (native builder, %d threads)"
-                                    % (args.workload.upper(), args.loci,
-                                       " (whole loci assigned to ranks by LPT on calls x states)" if args.workload == "c3" else "",
-                                       t_build, os.cpu_count() or 1)),
-                       "states": int(m), "emitting": int(P), "edges": int(E), "reads_per_gpu": args.reads,
-                       "read_len": n, "kernel": kernel, "outputs": "logp + RU count + 6 path summaries per read",
-                       "relaxations_per_s": value * relax_total / max(args.reads, 1)},
+            "config": dict({"workload": wl, "states": int(m), "emitting": int(P), "edges": int(E),
+                            "calls_this_rank": int(n_reads), "read_len": n, "kernel": kernel,
+                            "kernels": [{"name": k, "reads": r, "tiles": t} for k, r, t in kernels],
+                            "outputs": "logp + RU count + 6 path summaries per read",
+                            "relaxations_per_s": value * relax_total / max(n_reads, 1)}, **plan_info),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "GB per launch (profiles/r01_pmc_summary.json: WRITE_SIZE + 2 x FETCH_SIZE)",
+                         "traffic_unit": "GB per launch (WRITE_SIZE + 2 x FETCH_SIZE of the committed PMC passes)",
+                         "traffic_source": pmc.get("file"),
                          "algorithmic_gb_per_launch": alg_bytes_total / 1e9,
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_read": B,
-                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the max-plus recurrence is "
-                                 "fp64-VALU/LDS-issue bound long before HBM (see DESIGN.md)"},
+                         "note": "tier rule: algorithmic bytes (SURVEY 8d) / HIP-event kernel time against HBM; the "
+                                 "roof that actually binds this max-plus recurrence is fp64 VALU issue -> bound_actual"},
         }
+        if comm:
+            out["config"]["comm"] = comm.backend
+            out["config"]["world_size_seen_by_comm"] = comm.world
+            out["config"]["per_rank"] = per_rank
         if valu_insts:
-            # what actually bounds the kernel: every wave64 VALU instruction holds its SIMD for 4 cycles (MI355X: 256 CUs x
-            # 4 SIMDs at 2.4 GHz); SQ_INSTS_VALU per launch from the committed PMC pass of this same command
-            bound_ms = valu_insts * 4 / (1024 * 2.4e9) * 1e3
-            out["roofline"]["valu_issue"] = {"valu_insts_per_launch": valu_insts, "cycles_per_inst": 4, "simds": 1024,
-                                             "clock_ghz": 2.4, "issue_bound_ms": bound_ms, "kernel_ms": kernel_ms,
-                                             "frac": bound_ms / kernel_ms}
-        if not args.no_cpu:
-            cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, args.reads))
+            # what actually bounds the kernel: every wave64 VALU instruction holds its SIMD for >= 4 cycles (fp64: 16
+            # lanes per cycle); SQ_INSTS_VALU per launch from the committed PMC pass of this same command
+            bound_ms = valu_insts * 4 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+            out["roofline"]["bound_actual"] = {"bound": "valu_f64", "valu_insts_per_launch": valu_insts, "cycles_per_inst": 4,
+                                               "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "issue_bound_ms": bound_ms,
+                                               "kernel_ms": kernel_ms, "frac": bound_ms / kernel_ms,
+                                               "source": pmc.get("file"), "stale": pmc.get("stale")}
+        if workload == "c1" and not args.no_s300:
+            out["s300"] = s300_record(_lib, workloads, flags, args)
+        if workload == "c1" and world == 1 and not args.no_cpu:
+            cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
             n_ru = min(500, len(cpu_logp))
             same = ru_concordance(O, locus, reads, summ, n_ru)
             out["ru_concordance"] = {"reads": n_ru, "identical_ru_counts": same, "fraction": same / n_ru,
                                      "note": "GPU path summaries vs hmm_utils.get_number_of_repeats_in_vpath on the oracle path"}
-            out["cpu_baseline"] = {"value": cps, "unit": "reads/s", "cores": 1, "kind": "port",
+            cal = load_json("profiles", "cpu_calibration.json") or {}
+            ratio = cal.get("oracle_over_pomegranate")
+            out["cpu_baseline"] = {"value": cps, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu_model_name(),
+                                   "host_threads_available": os.cpu_count(),
                                    "sample": "first %d reads of rank 0's batch, oracle/viterbi_oracle.c, 1 thread; "
-                                             "GPU logp bit-equal on the sample" % len(cpu_logp)}
+                                             "GPU logp bit-equal on the sample" % len(cpu_logp),
+                                   "pomegranate_equivalent": (cps / ratio) if ratio else None,
+                                   "calibration": ("oracle / vendored pomegranate = %.2f on %s, same 2000-read REF150 batch, 1 "
+                                                   "thread (profiles/cpu_calibration.json, oracle/tools/calibrate_cpu.py)"
+                                                   % (ratio, cal.get("cpu_model", "?"))) if ratio else None}
             out["config"]["speedup_vs_cpu_1thread"] = value / cps
             # the same restatement on every host core (the reference has no such mode; stated for scale only)
             cores = os.cpu_count() or 1
-            n_mt = min(args.reads, max(2000, 150 * cores))
+            n_mt = min(n_reads, max(2000, 150 * cores))
             t0 = time.perf_counter()
             mt_logp = O.viterbi_many_threads(bases[:off[n_mt]], off[:n_mt + 1], cores)
             dt = time.perf_counter() - t0
             assert np.array_equal(mt_logp, logp[:n_mt]), "GPU/oracle log-prob mismatch on the all-cores sample"
             out["cpu_baseline_all_cores"] = {"value": n_mt / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                                             "cpu_model": cpu_model_name(),
                                              "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
                                                        "bit-equal on the sample" % (n_mt, cores)}
         print(json.dumps(out), flush=True)
     batch.close()
-    if use_dist:
-        dist.destroy_process_group()
+    if comm:
+        comm.close()
+    return rc
+
+
+def s300_record(_lib, workloads, flags, args):
+    """The label-matching shape of BASELINE's metric: flank 30, 12-bp pattern, 3 copies -> 315 states / 197 emitting /
+    1004 edges, the same 100 000 synthetic 150-bp reads recipe (report both shapes with m/P/E stated)."""
+    locus = workloads.s300()
+    a = locus.model.baked_arrays()
+    m, P, E = a["m"], a["silent_start"], len(a["in_src"])
+    n, n_reads = 150, args.reads
+    reads = workloads.make_reads(np.random.default_rng(20240601), locus, n_reads, n)
+    bases, off = _lib.encode_reads(reads)
+    batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(n_reads, np.int32), flags=flags)
+    batch.run()
+    batch.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+    batch.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    kernel_ms = batch.run_timed(3)
+    kernels = batch.kernels()
+    B = algorithmic_bytes(n, m)
+    rec = {"states": int(m), "emitting": int(P), "edges": int(E), "reads": n_reads, "read_len": n,
+           "value": n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "kernel_ms": kernel_ms,
+           "kernel": max(kernels, key=lambda k: k[1])[0], "bytes_per_read": B,
+           "achieved_gbps": B * n_reads / (kernel_ms * 1e-3) / 1e9, "frac": B * n_reads / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "relaxations_per_s": n_reads / dt * (n + 1) * E}
+    if not args.no_cpu:
+        O = oracle_model(locus)
+        k = min(args.cpu_sample, n_reads)
+        t0 = time.perf_counter()
+        cpu_logp, _ = O.viterbi_many(bases[:off[k]], off[:k + 1])
+        rec["cpu_1thread_reads_per_s"] = k / (time.perf_counter() - t0)
+        logp, _ = batch.fetch()
+        assert np.array_equal(cpu_logp, logp[:k]), "GPU/oracle log-prob mismatch on the S300 sample"
+    batch.close()
+    return rec
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

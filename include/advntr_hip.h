@@ -197,6 +197,33 @@ int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_
                        const int32_t *flank_off, int32_t n_flanks, const int32_t *pair_read, const int32_t *pair_flank,
                        int32_t n_pairs, int32_t *out_score, int32_t *out_begin, int32_t *out_end, float *kernel_ms);
 
+/* ---- multi-GPU: the gather of the result records over RCCL / xGMI --------------------------------------------
+ * One process per GPU; whole loci (with all their reads) are assigned to ranks (advntr_amd/sharding.py), so scoring
+ * needs no exchange at all and the ONLY collective of the path is the final gather of the per-read records (fp64
+ * log-probability + ADVNTR_SUMMARY_INTS x int32) to a root rank.  The reference has no counterpart: it scores loci
+ * serially (/root/reference/advntr/genome_analyzer.py:280-297) and its optional worker processes append to a
+ * multiprocessing.Manager().list() (/root/reference/advntr/vntr_finder.py:425-427).
+ * Rank 0 makes the 128-byte id (ncclGetUniqueId) and the host hands it to the other ranks by any means (a file, a
+ * socket: advntr_amd/comm.py); every rank then calls advntr_comm_create on its own device.  librccl.so is loaded on
+ * first use.  counts[] arrays have one entry per rank and must be the same on every rank.                        */
+typedef struct advntr_comm advntr_comm;
+int advntr_comm_unique_id(uint8_t *id128);
+advntr_comm *advntr_comm_create(int32_t rank, int32_t world, const uint8_t *id128);   /* NULL on error */
+void advntr_comm_destroy(advntr_comm *comm);
+int advntr_comm_info(const advntr_comm *comm, int32_t *rank, int32_t *world);
+int advntr_comm_allgather_i64(advntr_comm *comm, int64_t mine, int64_t *out_world);
+int advntr_comm_allreduce_max_f64(advntr_comm *comm, double *inout);
+int advntr_comm_barrier(advntr_comm *comm);
+/* gather-v of the batch's records as they are after the launches queued so far: returns at once (the records are
+ * copied to staging buffers on the batch's own stream, so the next advntr_batch_run may follow immediately and
+ * overlaps the transfer); counts[r] = reads of rank r's batch.  _finish waits; on the root out_logp / out_summary
+ * (host, sum(counts) records in rank order, either may be NULL) receive everything.                              */
+int advntr_comm_gather_results_start(advntr_comm *comm, advntr_batch *batch, int32_t root, const int64_t *counts);
+int advntr_comm_gather_results_finish(advntr_comm *comm, double *out_logp, int32_t *out_summary);
+/* ragged gather of host byte strings through the devices (the genotype driver's per-locus result rows):
+ * counts[r] = bytes of rank r; dst (root only) receives them rank after rank.                                   */
+int advntr_comm_gather_bytes(advntr_comm *comm, int32_t root, const void *src, const int64_t *counts, void *dst);
+
 #ifdef __cplusplus
 }
 #endif

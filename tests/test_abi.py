@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     from advntr_amd import _lib
     L = _lib.load()
     header = open(os.path.join(ROOT, "include", "advntr_hip.h")).read()
-    declared = set(re.findall(r"\b(advntr_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(advntr_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:

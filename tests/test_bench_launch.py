@@ -1,0 +1,43 @@
+"""bench.py's multi-rank entry point on CPU: `--gpus N` really starts N ranks (as child processes, or under
+torch.distributed.run as the driver does), they rendezvous, derive the same C3 plan and rank 0 prints one line with
+n_gpus = N.  --dry-run stops before any GPU work, so this runs without a GPU; the full path runs in the GPU suite."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _line(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--loci", "48"],
+                         cwd=ROOT, stdout=subprocess.PIPE, check=True, timeout=300).stdout
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["scaling"] == "strong"
+    cfg = d["config"]
+    assert cfg["workload"] == "c3" and cfg["comm"] == "host"
+    assert cfg["calls_seen_by_ranks"] == cfg["calls_per_rank"] and len(cfg["calls_per_rank"]) == 2      # both ranks reported in
+    assert sum(cfg["loci_per_rank"]) == 48 and cfg["load_imbalance_max_over_mean"] < 1.05
+
+
+def test_gpus_3_under_torch_distributed_run():
+    """The driver's launch line: torch is only the launcher; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "3", "--dry-run", "--loci", "30"], cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, check=True, timeout=300).stdout
+    d = _line(out)
+    assert d["n_gpus"] == 3 and len(d["config"]["calls_per_rank"]) == 3 and sum(d["config"]["loci_per_rank"]) == 30
+
+
+def test_single_process_default_is_c1():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], cwd=ROOT, stdout=subprocess.PIPE,
+                         check=True, timeout=300).stdout
+    d = _line(out)
+    assert d["n_gpus"] == 1 and d["config"]["workload"] == "c1" and d["scaling"] == "weak"

