@@ -154,16 +154,11 @@ def genotype(args):
             return [row(loci[i], vntr_finder.find_repeat_count_from_selected_reads(
                 [s.summary for s in sel], accuracy_filter=args.accuracy_filter, is_haploid=args.haploid))
                 for i, sel in zip(indices, picked)]
-        scored_all = vntr_finder.score_reads_multi(built, [cands[i] for i in indices],
-                                                   [loci[i].get("scaled_score") for i in indices], True)
-        out = []
-        for i, scored in zip(indices, scored_all):
-            scored = [s for s in scored if s is not None]
-            selected = [s.summary for s in scored if s.recruited and s.repeat_bp > 2]          # vntr_finder.py:251
-            res = vntr_finder.find_repeat_count_from_selected_reads(selected, accuracy_filter=args.accuracy_filter,
-                                                                    is_haploid=args.haploid)
-            out.append(row(loci[i], res))
-        return out
+        # scoring (both strands), recruit rule, selection and the per-locus aggregation + genotype without a Python object
+        # per read: one engine batch, then advntr_genotype_illumina on the summary records
+        results = vntr_finder.genotype_loci(built, [cands[i] for i in indices], [loci[i].get("scaled_score") for i in indices],
+                                            accuracy_filter=args.accuracy_filter, is_haploid=args.haploid)
+        return [row(loci[i], res) for i, res in zip(indices, results)]
     return finish(sharding.run_sharded(work, genotype_job, comm))
 
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADVNTR_HIP_LIB") or os.path.join(_HERE, "libadvntr_hip.so")   # override: kernel experiments
 
 OK, ERR_ARG, ERR_SYMBOL, ERR_DEVICE, ERR_TOO_LARGE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY, FLAG_STREAM, FLAG_ANTIDIAGONAL = 1, 2, 4, 8, 16
+FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY, FLAG_STREAM, FLAG_ANTIDIAGONAL, FLAG_BOTH_STRANDS = 1, 2, 4, 8, 16, 32
 SUMMARY_INTS = 8
 SUM_RU, SUM_MATCHES, SUM_REPEAT_BP, SUM_LEFT_BP, SUM_RIGHT_BP, SUM_LEFT_MATCH, SUM_RIGHT_MATCH, SUM_PATH_LEN = range(8)
 
@@ -55,6 +55,8 @@ SYMBOLS = {
     "advntr_built_upload": (_vp, [_vp]),
     "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
     "advntr_built_destroy": (None, [_vp]),
+    "advntr_encode_ascii": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "advntr_comm_unique_id": (ctypes.c_int, [_vp]),
     "advntr_comm_create": (_vp, [_i32, _i32, _vp]),
     "advntr_comm_destroy": (None, [_vp]),
@@ -146,6 +148,22 @@ def encode_reads(seqs):
     return np.ascontiguousarray(bases), off
 
 
+def encode_ascii(seqs, threads=0):
+    """advntr_encode_ascii: list of str -> (codes uint8 over the concatenation, read_off int64, bad uint8[n]) on host
+    threads: upper/lower-case ACGT -> 0..3, N -> 254, anything else -> 255; bad[read] = 1 for a read holding N (the
+    reference skips those before scoring, vntr_finder.py:237), 2 for one holding another symbol (its viterbi raises
+    ValueError there, hmm.pyx:72,79), 0 otherwise."""
+    n = len(seqs)
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n), out=off[1:])
+    raw = "".join(seqs).encode("latin-1", "replace")
+    codes = np.empty(len(raw), np.uint8)
+    bad = np.zeros(n, np.uint8)
+    check(load().advntr_encode_ascii(raw, ptr(off), n, int(threads), ptr(codes), ptr(bad)))
+    return codes, off, bad
+
+
 class DeviceModel(object):
     """Owns one advntr_hmm handle (a baked model resident in HBM)."""
 
@@ -200,6 +218,50 @@ def _numpy_exp(src, dst, n, _user):
 
 
 _NUMPY_EXP = EXP_FN(_numpy_exp)
+_NUMPY_EXP_LOOP = False          # (address, data) of numpy's own fp64 exp inner loop once found, None if not usable
+
+
+def _numpy_exp_loop():
+    """numpy.exp's fp64 inner loop as a C function pointer, so that the builder's worker threads call it directly instead
+    of queueing for a Python callback behind the interpreter lock.  Read from the ufunc object (PyUFuncObject, numpy's
+    public C struct: ufuncobject.h) after checking that the object looks the way that header says; verified against
+    numpy.exp itself on a test vector before it is trusted.  None -> the callback is used."""
+    global _NUMPY_EXP_LOOP
+    if _NUMPY_EXP_LOOP is not False:
+        return _NUMPY_EXP_LOOP
+    _NUMPY_EXP_LOOP = None
+    try:
+        u = np.exp
+        base, ptr_size = id(u), ctypes.sizeof(ctypes.c_void_p)
+        if ptr_size != 8 or not isinstance(u, np.ufunc):
+            return None
+        nin, nout, nargs, _identity = (ctypes.c_int * 4).from_address(base + 16)
+        ntypes = ctypes.c_int.from_address(base + 48).value
+        name = ctypes.c_char_p.from_address(base + 56).value
+        if (nin, nout, nargs, ntypes, name) != (1, 1, 2, u.ntypes, b"exp"):
+            return None
+        codes = {"e": 23, "f": 11, "d": 12, "g": 13, "F": 14, "D": 15, "G": 16, "O": 17}
+        want = [(codes.get(t[0], -1), codes.get(t[-1], -1)) for t in u.types]
+        types = (ctypes.c_char * (2 * ntypes)).from_address(ctypes.c_void_p.from_address(base + 64).value).raw
+        got = [(types[2 * i], types[2 * i + 1]) for i in range(ntypes)]
+        if got != want or (12, 12) not in got:
+            return None
+        i = got.index((12, 12))
+        fn = ctypes.c_void_p.from_address(ctypes.c_void_p.from_address(base + 32).value + 8 * i).value
+        data = ctypes.c_void_p.from_address(ctypes.c_void_p.from_address(base + 40).value + 8 * i).value
+        if not fn:
+            return None
+        loop = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)(fn)
+        x = np.concatenate([np.random.default_rng(3).uniform(-40.0, 0.0, 1001), [0.0, -np.inf, -1e-300, -745.2]])
+        y = np.empty_like(x)
+        args = (ctypes.c_void_p * 2)(x.ctypes.data, y.ctypes.data)
+        dims, steps = (ctypes.c_ssize_t * 1)(len(x)), (ctypes.c_ssize_t * 2)(8, 8)
+        loop(ctypes.addressof(args), ctypes.addressof(dims), ctypes.addressof(steps), data)
+        if np.array_equal(y, np.exp(x)):
+            _NUMPY_EXP_LOOP = (fn, data)
+    except Exception:
+        _NUMPY_EXP_LOOP = None
+    return _NUMPY_EXP_LOOP
 
 
 class BuiltModel(object):
@@ -245,7 +307,7 @@ class BuiltModel(object):
             pass
 
 
-BUILD_ALIGN_REPEATS = 1
+BUILD_ALIGN_REPEATS, BUILD_EXP_STRIDED_LOOP = 1, 2
 
 
 def align_repeats(units):
@@ -282,9 +344,10 @@ def upload_built_models(built, threads=0):
 
 
 def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp="numpy", threads=0, align=False):
-    """advntr_build_read_matchers over n loci -> list of BuiltModel.  exp: "numpy" passes numpy.exp for the two
-    probability round trips (what the reference calls; bit-identical parameters on the same machine), "libm" lets
-    the library use its own exp (no callback, <= 1 ulp away)."""
+    """advntr_build_read_matchers over n loci -> list of BuiltModel.  exp: "numpy" uses numpy.exp for the two
+    probability round trips (what the reference calls; bit-identical parameters on the same machine) -- numpy's own
+    inner loop called straight from the worker threads when it can be located (_numpy_exp_loop), a Python callback
+    otherwise ("numpy-callback" forces the callback); "libm" lets the library use its own exp (<= 1 ulp away)."""
     L = load()
     n = len(lefts)
     enc = lambda strs: (ctypes.c_char_p * max(len(strs), 1))(*[x.encode("ascii") for x in strs])
@@ -294,11 +357,18 @@ def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp
         off[i + 1] = len(flat)
     cp = np.ascontiguousarray(copies, np.int32)
     out = (ctypes.c_void_p * max(n, 1))()
-    fn = ctypes.cast(_NUMPY_EXP, ctypes.c_void_p) if exp == "numpy" else None
-    if exp not in ("numpy", "libm"):
-        raise ValueError("exp must be 'numpy' or 'libm'")
+    if exp not in ("numpy", "numpy-callback", "libm"):
+        raise ValueError("exp must be 'numpy', 'numpy-callback' or 'libm'")
+    fn, user, flags = None, None, BUILD_ALIGN_REPEATS if align else 0
+    if exp != "libm":
+        loop = _numpy_exp_loop() if exp == "numpy" else None
+        if loop is not None:                        # numpy's own inner loop, called by the worker threads directly
+            fn, user = ctypes.c_void_p(loop[0]), ctypes.c_void_p(loop[1])
+            flags |= BUILD_EXP_STRIDED_LOOP
+        else:
+            fn = ctypes.cast(_NUMPY_EXP, ctypes.c_void_p)
     rc = L.advntr_build_read_matchers(n, enc(lefts), enc(rights), enc(flat), ptr(off), ptr(cp), float(max_error_rate),
-                                      fn, None, int(threads), BUILD_ALIGN_REPEATS if align else 0, out)
+                                      fn, user, int(threads), flags, out)
     built = [BuiltModel(h) if h else None for h in list(out)[:n]]
     if rc != OK:
         msg = last_error()
@@ -317,23 +387,27 @@ def _handles(models):
 
 
 def viterbi_batch(models, bases, read_off, read_model, flags=0, want_paths=False, want_summary=True):
-    """One-shot scoring from host buffers.  Returns (logp, summary|None, paths|None)."""
+    """One-shot scoring from host buffers.  Returns (logp, summary|None, paths|None).  With FLAG_BOTH_STRANDS the arrays
+    describe the forward reads and every result holds 2n entries: entry n + i = the reverse complement of read i."""
     L = load()
-    n = len(read_off) - 1
+    n_in = len(read_off) - 1
     bases = np.ascontiguousarray(bases, np.uint8)
     read_off = np.ascontiguousarray(read_off, np.int64)
     read_model = np.ascontiguousarray(read_model, np.int32)
+    n = 2 * n_in if (flags & FLAG_BOTH_STRANDS) else n_in
     logp = np.zeros(n, np.float64)
     summ = np.zeros((n, SUMMARY_INTS), np.int32) if want_summary else None
     out_path = out_off = out_len = None
     if want_paths:
         flags |= FLAG_PATH
         caps = (read_off[1:] - read_off[:-1]) + np.array([models[i].m for i in read_model], np.int64) + 2
+        if flags & FLAG_BOTH_STRANDS:
+            caps = np.concatenate([caps, caps])
         out_off = np.zeros(n + 1, np.int64)
         np.cumsum(caps, out=out_off[1:])
         out_path = np.zeros(max(int(out_off[-1]), 1), np.int32)
         out_len = np.zeros(n, np.int32)
-    check(L.advntr_viterbi_batch(_handles(models), len(models), ptr(bases), ptr(read_off), ptr(read_model), n,
+    check(L.advntr_viterbi_batch(_handles(models), len(models), ptr(bases), ptr(read_off), ptr(read_model), n_in,
                                  ptr(logp), ptr(summ), ptr(out_path), ptr(out_off), ptr(out_len), flags))
     paths = None
     if want_paths:
@@ -364,13 +438,14 @@ class DeviceBatch(object):
     def __init__(self, models, bases, read_off, read_model, flags=0):
         L = load()
         self.models = list(models)
-        self.n_reads = len(read_off) - 1
+        n_in = len(read_off) - 1
+        self.n_reads = 2 * n_in if (flags & FLAG_BOTH_STRANDS) else n_in        # calls = entries of every result array
         bases = np.ascontiguousarray(bases, np.uint8)
         read_off = np.ascontiguousarray(read_off, np.int64)
         read_model = np.ascontiguousarray(read_model, np.int32)
         self.flags = flags
         self._h = L.advntr_batch_create(_handles(self.models), len(self.models), ptr(bases), ptr(read_off),
-                                        ptr(read_model), self.n_reads, flags)
+                                        ptr(read_model), n_in, flags)
         if not self._h:
             msg = last_error()
             if "base code" in msg:
@@ -422,6 +497,24 @@ class DeviceBatch(object):
             self.close()
         except Exception:
             pass
+
+
+GENOTYPE_ACCURACY_FILTER, GENOTYPE_HAPLOID = 1, 2
+
+
+def genotype_illumina(summaries, locus_off, accuracy_filter=False, is_haploid=False, min_left=5, min_right=5, threads=0):
+    """advntr_genotype_illumina: per-locus genotypes from the summary records of the selected reads, grouped by locus.
+    Returns (genotype int32[n_loci][2] with -1 for None, max_prob float64[n_loci], counts int32[n_loci][3])."""
+    summaries = np.ascontiguousarray(summaries, np.int32).reshape(-1, SUMMARY_INTS)
+    locus_off = np.ascontiguousarray(locus_off, np.int64)
+    n = len(locus_off) - 1
+    geno = np.zeros((max(n, 0), 2), np.int32)
+    prob = np.zeros(max(n, 0), np.float64)
+    counts = np.zeros((max(n, 0), 3), np.int32)
+    flags = (GENOTYPE_ACCURACY_FILTER if accuracy_filter else 0) | (GENOTYPE_HAPLOID if is_haploid else 0)
+    check(load().advntr_genotype_illumina(ptr(summaries), ptr(locus_off), n, flags, int(min_left), int(min_right), int(threads),
+                                          ptr(geno), ptr(prob), ptr(counts)))
+    return geno, prob, counts
 
 
 def flank_align(reads, flanks, pair_read, pair_flank):

@@ -6,7 +6,9 @@
 // Native model builder (model_builder.h) behind the C ABI
 // ------------------------------------------------------------------------------------------------
 struct advntr_built {
-    mb::Built b;
+    // shared with the device models made from it (they read its CSR in place instead of copying it)
+    std::shared_ptr<mb::Built> sp = std::make_shared<mb::Built>();
+    mb::Built &b = *sp;
 };
 
 // Host threads for the per-locus jobs (model build, table preparation).  These jobs are allocation-heavy (thousands of
@@ -40,6 +42,16 @@ extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *lef
         std::lock_guard<std::mutex> lk(s->exp_mu);
         s->fn(in, o, n, s->user);
     };
+    // ... or call it as the thread-safe strided loop it was declared to be
+    auto strided_exp = [](const double *in, double *o, int64_t n, void *u) {
+        Shared *s = (Shared *)u;
+        typedef void (*Loop)(char **, const intptr_t *, const intptr_t *, void *);
+        char *args[2] = {(char *)const_cast<double *>(in), (char *)o};
+        const intptr_t dims[1] = {(intptr_t)n}, steps[2] = {(intptr_t)sizeof(double), (intptr_t)sizeof(double)};
+        ((Loop)(void *)s->fn)(args, dims, steps, s->user);
+    };
+    const mb::ExpFn exp_call = !exp_fn ? (mb::ExpFn) nullptr
+                               : (flags & ADVNTR_BUILD_EXP_STRIDED_LOOP) ? (mb::ExpFn)strided_exp : (mb::ExpFn)locked_exp;
     std::atomic<int> next(0);
     auto work = [&]() {
         for (;;) {
@@ -56,7 +68,7 @@ extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *lef
                 }
                 advntr_built *B = new advntr_built;
                 B->b = mb::build_read_matcher(left_flank[i], right_flank[i], rows, copies[i], max_error_rate,
-                                              exp_fn ? (mb::ExpFn)locked_exp : nullptr, &sh);
+                                              exp_call, &sh);
                 out[i] = B;
             } catch (const std::exception &e) {
                 std::lock_guard<std::mutex> lk(sh.err_mu);
@@ -99,23 +111,33 @@ extern "C" int advntr_built_export(const advntr_built *B, int32_t *in_ptr, int32
 extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
 {
     if (!B) { fail(ADVNTR_ERR_ARG, "advntr_built_upload: null model"); return nullptr; }
-    const mb::Built &b = B->b;
-    return advntr_hmm_create(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
-                             b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data());
+    advntr_hmm *H = nullptr;
+    if (advntr_built_upload_many(&B, 1, 1, &H) != ADVNTR_OK) return nullptr;
+    return H;
 }
 
+// Bulk upload.  Host threads turn every model into its device blob (validation, column-program compilation,
+// serialization); a thread appends its blobs to 16 MiB segments of its own, so no model allocates a buffer of its own and
+// nothing is staged twice; the segments then go to ONE device allocation with one copy each.  The models keep reading the
+// builder's CSR arrays in place (shared ownership), so the only per-model host memory is the small handle.
 extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out)
 {
     if (n < 0 || (n && (!built || !out))) return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: bad argument");
     for (int i = 0; i < n; ++i) out[i] = nullptr;
     if (n == 0) return ADVNTR_OK;
     if (n_threads <= 0) n_threads = default_host_threads();
-    n_threads = std::min(n_threads, n);
+    n_threads = std::max(1, std::min(n_threads, n));
+    constexpr size_t kSegment = (size_t)16 << 20;
+    struct Segment { std::unique_ptr<uint8_t[]> mem; size_t cap = 0, used = 0, device_off = 0; };
+    struct Placed { int thread = -1, segment = -1; size_t off = 0; };
+    std::vector<std::vector<Segment>> segments(n_threads);
+    std::vector<Placed> placed(n);
     std::mutex err_mu;
     int first_bad = -1;
     std::string msg;
     std::atomic<int> next(0);
-    auto work = [&]() {
+    auto work = [&](int t) {
+        std::vector<Segment> &mine = segments[t];
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
@@ -124,19 +146,32 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
             if (built[i]) {
                 const mb::Built &b = built[i]->b;
                 H = hmm_prepare(b.m, b.silent_start, b.start_index, b.end_index, (int32_t)b.in_src.size(), b.in_ptr.data(),
-                                b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data(), err);
+                                b.in_src.data(), b.in_logp.data(), b.emis.data(), b.state_class.data(), err, built[i]->sp, false);
             }
-            if (H) out[i] = H;
-            else {
+            if (!H) {
                 std::lock_guard<std::mutex> lk(err_mu);
                 if (first_bad < 0 || i < first_bad) { first_bad = i; msg = err; }
+                continue;
             }
+            const size_t need = (H->blob_bytes + 255) & ~size_t(255);           // 256-B aligned sub-blobs
+            if (mine.empty() || mine.back().used + need > mine.back().cap) {
+                Segment sgm;
+                sgm.cap = std::max(kSegment, need);
+                sgm.mem.reset(new uint8_t[sgm.cap]);                            // uninitialised: pages are touched as they fill
+                mine.push_back(std::move(sgm));
+            }
+            Segment &sgm = mine.back();
+            memcpy(sgm.mem.get() + sgm.used, tls_blob().bytes.data(), H->blob_bytes);
+            memset(sgm.mem.get() + sgm.used + H->blob_bytes, 0, need - H->blob_bytes);
+            placed[i].thread = t; placed[i].segment = (int)mine.size() - 1; placed[i].off = sgm.used;
+            sgm.used += need;
+            out[i] = H;
         }
     };
-    if (n_threads == 1) work();
+    if (n_threads == 1) work(0);
     else {
         std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
         for (auto &t : pool) t.join();
     }
     auto drop_all = [&]() {
@@ -146,24 +181,26 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
         drop_all();
         return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
     }
-    // one slab, 256-B aligned sub-blobs, one copy
-    std::vector<size_t> at(n);
     size_t total = 0;
-    for (int i = 0; i < n; ++i) { at[i] = total; total += (out[i]->blob_bytes + 255) & ~size_t(255); }
-    std::vector<uint8_t> staging(total);
-    for (int i = 0; i < n; ++i) memcpy(staging.data() + at[i], out[i]->host_blob.data(), out[i]->blob_bytes);
+    for (auto &list : segments)
+        for (Segment &sgm : list) { sgm.device_off = total; total += sgm.used; }
     ModelSlab *slab = new ModelSlab;
-    if (hipMalloc(&slab->d, total) != hipSuccess || hipMemcpy(slab->d, staging.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+    bool ok = hipMalloc(&slab->d, total) == hipSuccess;
+    for (auto &list : segments)
+        for (Segment &sgm : list)
+            ok = ok && hipMemcpy((uint8_t *)slab->d + sgm.device_off, sgm.mem.get(), sgm.used, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
         if (slab->d) (void)hipFree(slab->d);
         delete slab;
         drop_all();
         return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
     }
     slab->refs = n;
+    const int dev = current_device();
     for (int i = 0; i < n; ++i) {
         out[i]->slab = slab;
-        out[i]->device = current_device();
-        hmm_bind(out[i], (const uint8_t *)slab->d + at[i]);
+        out[i]->device = dev;
+        hmm_bind(out[i], (const uint8_t *)slab->d + segments[placed[i].thread][placed[i].segment].device_off + placed[i].off);
     }
     return ADVNTR_OK;
 }

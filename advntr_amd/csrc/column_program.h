@@ -80,6 +80,17 @@ struct ColProgramHost {
     std::vector<double> fwd;               // n_cols * 2
     std::vector<double> fv0;               // per silent state
 
+    void reset()
+    {
+        valid = false;
+        why.clear();
+        n_cols = n_sinks = m = P = 0;
+        classes.clear(); emis.clear(); info.clear(); state.clear(); pred0.clear(); v0.clear();
+        tail_state.clear(); tail_ptr.clear(); tail_edges.clear();
+        end_tail = -1;
+        fwd.clear(); fv0.clear();
+    }
+
     size_t lds_bytes() const
     {
         return classes.size() * sizeof(ColClass) + emis.size() * sizeof(double) + info.size() * sizeof(ColInfo) +
@@ -88,7 +99,15 @@ struct ColProgramHost {
 
     std::vector<uint8_t> serialize() const
     {
-        std::vector<uint8_t> out(sizeof(ColProgram), 0);
+        std::vector<uint8_t> out;
+        serialize_into(out);
+        return out;
+    }
+
+    // (the caller's buffer keeps its capacity across models: no allocation in the steady state of a bulk upload)
+    void serialize_into(std::vector<uint8_t> &out) const
+    {
+        out.assign(sizeof(ColProgram), 0);
         auto add = [&](const void *p, size_t bytes) -> int32_t {
             size_t off = (out.size() + 15) & ~size_t(15);
             out.resize(off + bytes + 16, 0);
@@ -111,7 +130,6 @@ struct ColProgramHost {
         h.off_tail_edge = add(tail_edges.data(), tail_edges.size() * sizeof(TailEdge));
         h.off_fwd = add(fwd.data(), fwd.size() * sizeof(double));
         memcpy(out.data(), &h, sizeof h);
-        return out;
     }
 };
 
@@ -135,9 +153,10 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     using namespace colprog_detail;
     const double NINF = -INFINITY;
     const int m = H.m, P = H.P, S = m - P;
-    const std::vector<int32_t> &in_ptr = H.in_ptr, &in_src = H.in_src;
-    const std::vector<double> &in_logp = H.in_logp;
-    out = ColProgramHost();
+    const auto &in_ptr = H.in_ptr;
+    const auto &in_src = H.in_src;
+    const auto &in_logp = H.in_logp;
+    out.reset();                          // keeps the vectors' capacity: `out` may be a per-thread scratch object
     out.m = m; out.P = P;
     auto fail = [&](const std::string &why) { out.valid = false; out.why = why; return false; };
     if (!H.finite) return fail("model has no end state in-edges (infinite model)");

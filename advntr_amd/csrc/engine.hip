@@ -9,6 +9,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -165,14 +166,36 @@ extern "C" int advntr_set_device(int device)
 // ------------------------------------------------------------------------------------------------
 // Model
 // ------------------------------------------------------------------------------------------------
+// read-only view of an array that is either owned by the model (advntr_hmm_create copies the caller's CSR) or shared
+// with the native builder's result (advntr_built_upload*: no copy, the Built stays alive through a shared_ptr)
+template <class T> struct ArrayView {
+    const T *p = nullptr;
+    size_t n = 0;
+    const T &operator[](size_t i) const { return p[i]; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    void set(const std::vector<T> &v) { p = v.data(); n = v.size(); }
+};
+
+// what stays of a model's column program on the host once its tables are serialized into the device blob
+struct ColProgramSummary {
+    bool valid = false;
+    int32_t n_cols = 0;
+    std::string why;
+};
+
 struct advntr_hmm {
     int32_t m = 0, P = 0, start = 0, end = 0, finite = 0, n_edges = 0;
     int32_t bp_width = 1, max_indeg = 0;
-    std::vector<int32_t> in_ptr, in_src;
-    std::vector<double> in_logp, emis;
-    std::vector<uint16_t> sclass;
+    ArrayView<int32_t> in_ptr, in_src;
+    ArrayView<double> in_logp, emis;
+    ArrayView<uint16_t> sclass;
+    std::vector<int32_t> own_in_ptr, own_in_src;          // storage behind the views when the model owns its CSR
+    std::vector<double> own_in_logp, own_emis;
+    std::vector<uint16_t> own_sclass;
+    std::shared_ptr<const mb::Built> built;               // ... or the builder's result they point into
     bool has_class = false;
-    ColProgramHost colprog;       // empty when the model is not a recognised read matcher
+    ColProgramSummary colprog;    // valid = false when the model is not a recognised read matcher
     int32_t col_lds_bytes = 0;     // LDS-resident tables of the column program: classes, emissions, column info, states
     int32_t col_lds_core = 0;      // ... without the state table (only the traceback reads it)
     int32_t col_lds_min = 0;       // ... without the column-info table either (the sweep indexes a padded copy of it)
@@ -200,16 +223,25 @@ namespace {
 
 struct BlobBuilder {
     std::vector<uint8_t> bytes;
-    template <class T> size_t add(const std::vector<T> &v)
+    size_t add_raw(const void *p, size_t n_bytes, size_t elem)
     {
         size_t off = (bytes.size() + 15) & ~size_t(15);
-        bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T) + 16, 0);
-        if (!v.empty()) memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+        bytes.resize(off + std::max<size_t>(n_bytes, elem) + 16, 0);
+        if (n_bytes) memcpy(bytes.data() + off, p, n_bytes);
         return off;
     }
+    template <class T> size_t add(const std::vector<T> &v) { return add_raw(v.data(), v.size() * sizeof(T), sizeof(T)); }
+    template <class T> size_t add(const ArrayView<T> &v) { return add_raw(v.data(), v.size() * sizeof(T), sizeof(T)); }
 };
 
 }  // namespace
+
+// the calling thread's serialization buffer: hmm_prepare leaves the model's blob in it (capacity kept across models)
+static BlobBuilder &tls_blob()
+{
+    static thread_local BlobBuilder B;
+    return B;
+}
 
 // Tables of the generic-CSR kernel, appended to `B`; o[0..11] receive their offsets.
 static void generic_tables(const advntr_hmm &H, BlobBuilder &B, size_t *o)
@@ -266,7 +298,8 @@ static void generic_tables(const advntr_hmm &H, BlobBuilder &B, size_t *o)
 // no global state: safe to run on many threads (errors come back through `err`).
 static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index, int32_t n_edges,
                                const int32_t *in_ptr, const int32_t *in_src, const double *in_logp,
-                               const double *emis_logp, const uint16_t *state_class, std::string &err)
+                               const double *emis_logp, const uint16_t *state_class, std::string &err,
+                               const std::shared_ptr<const mb::Built> &shared = nullptr, bool own_blob = true)
 {
     auto fail = [&err](int, const char *fmt, ...) {
         char buf[512];
@@ -300,16 +333,33 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
     const int P = silent_start;
     advntr_hmm *H = new advntr_hmm();
     H->m = m; H->P = P; H->start = start_index; H->end = end_index; H->n_edges = n_edges;
-    H->in_ptr.assign(in_ptr, in_ptr + m + 1);
-    H->in_src.assign(in_src, in_src + n_edges);
-    H->in_logp.assign(in_logp, in_logp + n_edges);
-    H->emis.assign(emis_logp, emis_logp + (size_t)P * 4);
-    H->finite = (in_ptr[end_index + 1] - in_ptr[end_index]) != 0;   // hmm.pyx:977-980
-    H->sclass.assign(m, 0);
-    if (state_class) {
-        H->sclass.assign(state_class, state_class + m);
-        H->has_class = true;
+    if (shared) {
+        // the arrays live in the builder's result, which this model keeps alive: nothing is copied
+        H->built = shared;
+        H->in_ptr.p = in_ptr; H->in_ptr.n = (size_t)m + 1;
+        H->in_src.p = in_src; H->in_src.n = (size_t)n_edges;
+        H->in_logp.p = in_logp; H->in_logp.n = (size_t)n_edges;
+        H->emis.p = emis_logp; H->emis.n = (size_t)P * 4;
+        H->sclass.p = state_class; H->sclass.n = (size_t)m;
+        H->has_class = state_class != nullptr;
+    } else {
+        H->own_in_ptr.assign(in_ptr, in_ptr + m + 1);
+        H->own_in_src.assign(in_src, in_src + n_edges);
+        H->own_in_logp.assign(in_logp, in_logp + n_edges);
+        H->own_emis.assign(emis_logp, emis_logp + (size_t)P * 4);
+        H->own_sclass.assign(m, 0);
+        if (state_class) {
+            H->own_sclass.assign(state_class, state_class + m);
+            H->has_class = true;
+        }
+        H->in_ptr.set(H->own_in_ptr); H->in_src.set(H->own_in_src); H->in_logp.set(H->own_in_logp);
+        H->emis.set(H->own_emis); H->sclass.set(H->own_sclass);
     }
+    if (!H->sclass.p) {            // shared arrays without class words (not produced by the builder; kept for safety)
+        H->own_sclass.assign(m, 0);
+        H->sclass.set(H->own_sclass);
+    }
+    H->finite = (in_ptr[end_index + 1] - in_ptr[end_index]) != 0;   // hmm.pyx:977-980
 
     // widest in-edge list the generic kernel will see (decides its back-pointer width)
     {
@@ -324,8 +374,13 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
         H->bp_width = max_indeg > 255 ? 2 : 1;
     }
 
-    // column program for flank-repeats-flank read matchers (optional fast path)
-    build_column_program(*H, H->colprog);
+    // column program for flank-repeats-flank read matchers (optional fast path); its tables are scratch of this thread
+    // (they end up in the blob), only the summary stays with the model
+    static thread_local ColProgramHost prog;
+    build_column_program(*H, prog);
+    H->colprog.valid = prog.valid;
+    H->colprog.n_cols = prog.n_cols;
+    H->colprog.why = prog.why;
     // the generic kernel keeps 2 fp64 trellis rows in the 160 KiB LDS of one CU; a bigger model is only
     // usable through its column program
     H->generic_ok = (size_t)m * 16 <= 160 * 1024;
@@ -339,20 +394,22 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
     // the generic kernel's tables are three quarters of a read matcher's device data and are only needed when a read
     // cannot take the column kernel (forced, or longer than 65 536 bases): models with a column program upload them on
     // first use (hmm_ensure_generic), generic-only models carry them from the start
-    BlobBuilder B;
+    BlobBuilder &B = tls_blob();
+    B.bytes.clear();
     size_t offs[14] = {0};
     H->gen_in_blob = !H->colprog.valid;
     if (H->gen_in_blob) generic_tables(*H, B, offs);
     offs[12] = B.add(H->sclass);
     if (H->colprog.valid) {
-        const std::vector<uint8_t> colblob = H->colprog.serialize();
+        static thread_local std::vector<uint8_t> colblob;
+        prog.serialize_into(colblob);
         H->col_lds_bytes = ((const ColProgram *)colblob.data())->lds_bytes;
         H->col_lds_core = (((const ColProgram *)colblob.data())->off_state - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
         H->col_lds_min = (((const ColProgram *)colblob.data())->off_info - ((const ColProgram *)colblob.data())->off_class + 15) & ~15;
         offs[13] = B.add(colblob);
     }
     H->blob_bytes = B.bytes.size();
-    H->host_blob.swap(B.bytes);
+    if (own_blob) H->host_blob.assign(B.bytes.begin(), B.bytes.end());      // (a bulk upload copies it out of tls_blob() itself)
     memcpy(H->off, offs, sizeof offs);
     return H;
 }
@@ -505,13 +562,44 @@ static int device_cus()
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
-static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
-                       const int64_t *read_off, const int32_t *read_model, int32_t n_reads, uint32_t flags)
+// second strand of a both-strands batch: call n_fwd + i = reverse complement of read i (one wavefront per read)
+__global__ void __launch_bounds__(256) reverse_complement_kernel(uint8_t *bases, const int64_t *read_off, const int n_fwd)
 {
-    if (!models || n_models <= 0 || !read_off || !read_model || n_reads < 0 || (n_reads && !bases && read_off[n_reads] > 0))
+    const int lane = threadIdx.x & 63;
+    const int64_t total = read_off[n_fwd];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < n_fwd; r += gridDim.x * 4) {
+        const int64_t o = read_off[r], n = read_off[r + 1] - o;
+        for (int64_t j = lane; j < n; j += 64) bases[total + o + j] = (uint8_t)(3 - bases[o + n - 1 - j]);
+    }
+}
+
+static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
+                       const int64_t *read_off_in, const int32_t *read_model_in, int32_t n_reads_in, uint32_t flags)
+{
+    if (!models || n_models <= 0 || !read_off_in || !read_model_in || n_reads_in < 0 ||
+        (n_reads_in && !bases && read_off_in[n_reads_in] > 0))
         return fail(ADVNTR_ERR_ARG, "batch: bad argument");
     for (int i = 0; i < n_models; ++i)
         if (!models[i]) return fail(ADVNTR_ERR_ARG, "batch: null model %d", i);
+    // ADVNTR_FLAG_BOTH_STRANDS: the caller passes the forward reads; calls n .. 2n-1 are their reverse complements
+    // (process_unmapped_read scores both, vntr_finder.py:239-242), made on the device from the uploaded forward bases
+    const bool both = (flags & ADVNTR_FLAG_BOTH_STRANDS) != 0 && n_reads_in > 0;
+    std::vector<int64_t> off2;
+    std::vector<int32_t> model2;
+    if (both) {
+        if (n_reads_in > 0x3fffffff) return fail(ADVNTR_ERR_TOO_LARGE, "batch: too many reads for a both-strands batch");
+        if (read_off_in[0] != 0) return fail(ADVNTR_ERR_ARG, "batch: read_off[0] must be 0");
+        off2.assign(read_off_in, read_off_in + n_reads_in + 1);
+        off2.resize((size_t)2 * n_reads_in + 1);
+        model2.assign(read_model_in, read_model_in + n_reads_in);
+        model2.insert(model2.end(), read_model_in, read_model_in + n_reads_in);
+        const int64_t fwd = read_off_in[n_reads_in];
+        for (int r = 0; r < n_reads_in; ++r) off2[(size_t)n_reads_in + 1 + r] = fwd + read_off_in[r + 1];
+    }
+    const int64_t *read_off = both ? off2.data() : read_off_in;
+    const int32_t *read_model = both ? model2.data() : read_model_in;
+    const int32_t n_reads = both ? 2 * n_reads_in : n_reads_in;
+    const int64_t total_given = read_off_in[n_reads_in];          // bytes the caller's `bases` holds
     B->models.assign(models, models + n_models);
     B->n_reads = n_reads;
     B->flags = flags;
@@ -526,14 +614,14 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     {   // symbol check, eight codes per test (a valid code has no bit above the low two)
         uint64_t bad = 0;
         int64_t i = 0;
-        for (; i + 8 <= total; i += 8) {
+        for (; i + 8 <= total_given; i += 8) {
             uint64_t w;
             memcpy(&w, bases + i, 8);
             bad |= w & 0xFCFCFCFCFCFCFCFCull;
         }
-        for (; i < total; ++i) bad |= (uint64_t)(bases[i] & 0xFC);
+        for (; i < total_given; ++i) bad |= (uint64_t)(bases[i] & 0xFC);
         if (bad)
-            for (i = 0; i < total; ++i)
+            for (i = 0; i < total_given; ++i)
                 if (bases[i] > 3)   // the reference raises ValueError("Symbol ... not defined") (hmm.pyx:72,79)
                     return fail(ADVNTR_ERR_SYMBOL, "batch: base code %d at offset %lld is not one of A,C,G,T", (int)bases[i],
                                 (long long)i);
@@ -548,15 +636,19 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
 
     int rc;
     if ((rc = B->dmalloc(&B->d_bases, (size_t)total + 16))) return rc;
-    if (total) HIP_TRY(hipMemcpy(B->d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
+    if (total_given) HIP_TRY(hipMemcpy(B->d_bases, bases, (size_t)total_given, hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_read_off, (size_t)n_reads + 1))) return rc;
     HIP_TRY(hipMemcpy(B->d_read_off, read_off, ((size_t)n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (both && total_given) {
+        const int grid = (int)std::min<int64_t>(((int64_t)n_reads_in + 3) / 4, 65536);
+        hipLaunchKernelGGL(reverse_complement_kernel, dim3(grid), dim3(256), 0, B->stream, B->d_bases, B->d_read_off, n_reads_in);
+        HIP_TRY(hipGetLastError());
+    }
     if ((rc = B->dmalloc(&B->d_read_model, (size_t)n_reads))) return rc;
     if (n_reads) HIP_TRY(hipMemcpy(B->d_read_model, read_model, (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = B->dmalloc(&B->d_logp, (size_t)n_reads))) return rc;
     if ((rc = B->dmalloc(&B->d_summary, (size_t)n_reads * ADVNTR_SUMMARY_INTS))) return rc;
     if ((rc = B->dmalloc(&B->d_counter, 12))) return rc;
-
     // split: reads the anti-diagonal kernel can take vs. the generic kernel
     std::vector<int32_t> col_reads, gen_reads;
     for (int r = 0; r < n_reads; ++r) {
@@ -594,15 +686,33 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (use_rows_long && n > ROWS_MAX_READ && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) return 3;
         return 3 + (int)std::min<int64_t>(5, (n + 63) / 64);
     };
-    {   // one 64-bit key per read (bucket | model | inverted length), index in the low bits keeps the sort stable
-        std::vector<std::pair<uint64_t, int32_t>> keyed(col_reads.size());
-        for (size_t i = 0; i < col_reads.size(); ++i) {
+    {   // order: bucket, then model, then longest first, then read index.  A counting sort over (bucket, model) -- both
+        // small ranges -- followed by a stable sort by length inside the bins that are not already ordered (reads of one
+        // locus mostly share a length): O(n) instead of the comparison sort that took 100 ms per 1.6 M reads
+        const size_t n_col = col_reads.size();
+        const size_t n_bins = (size_t)9 * (size_t)n_models;
+        std::vector<uint32_t> bin_of(n_col);
+        std::vector<int64_t> start(n_bins + 1, 0);
+        for (size_t i = 0; i < n_col; ++i) {
             const int r = col_reads[i];
-            const uint64_t len = (uint64_t)(read_off[r + 1] - read_off[r]);
-            keyed[i] = {((uint64_t)kof(r) << 56) | ((uint64_t)(uint32_t)read_model[r] << 24) | (uint64_t)(0xFFFFFFu - std::min<uint64_t>(len, 0xFFFFFFu)), r};
+            bin_of[i] = (uint32_t)((size_t)kof(r) * (size_t)n_models + (size_t)read_model[r]);
+            start[bin_of[i] + 1]++;
         }
-        std::sort(keyed.begin(), keyed.end());
-        for (size_t i = 0; i < keyed.size(); ++i) col_reads[i] = keyed[i].second;
+        for (size_t b = 0; b < n_bins; ++b) start[b + 1] += start[b];
+        std::vector<int32_t> sorted(n_col);
+        {
+            std::vector<int64_t> at(start.begin(), start.end() - 1);
+            for (size_t i = 0; i < n_col; ++i) sorted[(size_t)at[bin_of[i]]++] = col_reads[i];      // stable: index order kept
+        }
+        auto len_of = [&](int r) { return read_off[r + 1] - read_off[r]; };
+        for (size_t b = 0; b < n_bins; ++b) {
+            const int64_t lo = start[b], hi = start[b + 1];
+            bool ordered = true;
+            for (int64_t i = lo + 1; i < hi && ordered; ++i) ordered = len_of(sorted[i - 1]) >= len_of(sorted[i]);
+            if (!ordered)
+                std::stable_sort(sorted.begin() + lo, sorted.begin() + hi, [&](int a, int c) { return len_of(a) > len_of(c); });
+        }
+        col_reads.swap(sorted);
     }
     // generic reads: heaviest (n+1)*E first (dynamic dequeue in-kernel)
     std::stable_sort(gen_reads.begin(), gen_reads.end(), [&](int a, int b) {
@@ -641,7 +751,6 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         HIP_TRY(hipMemcpy(B->d_path_off, B->path_off.data(), ((size_t)n_reads + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
         if ((rc = B->dmalloc(&B->d_path_len, (size_t)n_reads))) return rc;
     }
-
     const int cus = device_cus();
     B->path_cap = B->n_max + B->m_max + 2;
 
@@ -1030,3 +1139,4 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
 #include "abi_model_builder.h"
 #include "abi_flank_align.h"
 #include "abi_comm.h"
+#include "abi_genotype.h"

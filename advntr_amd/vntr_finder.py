@@ -147,40 +147,35 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
                  recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
     if n_all == 0:
         return empty
-    # one buffer for every read: upper-case, encode and find the reads holding 'N' without a Python loop per read
-    all_len = np.fromiter(map(len, flat), dtype=np.int64, count=n_all)
-    all_off = np.zeros(n_all + 1, np.int64)
-    np.cumsum(all_len, out=all_off[1:])
-    raw = np.frombuffer("".join(flat).upper().encode("latin-1", "replace"), dtype=np.uint8)
-    n_count = np.add.reduceat(np.concatenate([raw == ord('N'), [False]]).astype(np.int64),
-                              np.minimum(all_off[:-1], len(raw)))
-    n_count[all_len == 0] = 0
-    keep = n_count <= 0
+    # one buffer for every read; case folding, encoding and the test for symbols outside ACGT run on host threads in the
+    # library (advntr_encode_ascii).  Reads holding 'N' are dropped as the reference does (vntr_finder.py:237); any other
+    # foreign symbol raises, as the reference's viterbi does (hmm.pyx:72,79).
+    codes, all_off, bad = _lib.encode_ascii(flat)
+    if np.any(bad == 2):
+        raise ValueError("Symbol is not defined in a distribution (read %d holds a symbol outside ACGTN)" % int(np.argmax(bad == 2)))
+    all_len = np.diff(all_off)
+    keep = bad == 0
     locus_all = np.repeat(np.arange(n_loci, dtype=np.int32), counts)
     index_all = (np.arange(n_all, dtype=np.int64) - np.repeat(np.cumsum(counts) - counts, counts)).astype(np.int32)
-    out = dict(locus=locus_all[keep], index=index_all[keep])
     nf = int(keep.sum())
     if nf == 0:
         return empty
-    lens = all_len[keep]
-    bases = _lib._CODE[raw] if nf == n_all else _lib._CODE[raw[np.repeat(keep, all_len)]]
-    off = np.zeros(nf + 1, np.int64)
-    np.cumsum(lens, out=off[1:])
+    if nf == n_all:
+        out = dict(locus=locus_all, index=index_all)
+        lens, bases, off = all_len, codes, all_off
+    else:
+        out = dict(locus=locus_all[keep], index=index_all[keep])
+        lens = all_len[keep]
+        bases = codes[np.repeat(keep, all_len)]
+        off = np.zeros(nf + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
     which = out["locus"]
+    # both strands in one engine batch: the reverse complements are made on the device (ADVNTR_FLAG_BOTH_STRANDS), call
+    # nf + i = reverse complement of read i
+    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, which, want_paths=False, want_summary=True,
+                                       flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
     if compute_reverse:
-        # reverse complements without index arithmetic: complementing and reversing the WHOLE code array gives the
-        # reverse complement of every read, the reads themselves in reverse order
-        rc = (3 - bases)[::-1]
-        rlens = lens[::-1]
-        roff = np.zeros(nf + 1, np.int64)
-        np.cumsum(rlens, out=roff[1:])
-        bases = np.concatenate([bases, rc])
-        off = np.concatenate([off, off[-1] + roff[1:]])
-        which = np.concatenate([which, which[::-1]])
-    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, which, want_paths=False,
-                                       want_summary=True)
-    if compute_reverse:
-        rlogp, rsumm = logp[nf:][::-1], summ[nf:][::-1]
+        rlogp, rsumm = logp[nf:], summ[nf:]
         use_rev = logp[:nf] < rlogp
         logp = np.where(use_rev, rlogp, logp[:nf])
         summ = np.where(use_rev[:, None], rsumm, summ[:nf])
@@ -190,6 +185,25 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
     out.update(logp=logp, summary=summ, reversed=use_rev, length=lens,
                recruited=recruit_mask(logp, summ, lens, min_scores))
     return out
+
+
+def genotype_loci(models, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False, compute_reverse=True,
+                  threads=0):
+    """The Illumina path after candidate selection, for many loci at once and without a Python object per read: both
+    strands of every candidate read scored in one engine batch (process_unmapped_read, vntr_finder.py:235-254), the
+    recruit rule on the summary records (:179-190), reads with more than two repeat bases selected (:251), and the
+    per-locus aggregation + maximum-likelihood genotype (:807-887, :473-532) in the library's host threads
+    (advntr_genotype_illumina).  Returns one GenotypeResult per locus."""
+    n_loci = len(models)
+    res = score_reads_arrays(models, read_lists, scaled_scores, compute_reverse)
+    keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
+    locus = res["locus"][keep]                       # ascending already: reads are laid out locus by locus
+    summ = res["summary"][keep]
+    if len(locus) and np.any(np.diff(locus) < 0):
+        order = np.argsort(locus, kind="stable")
+        locus, summ = locus[order], summ[order]
+    bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
+    return find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
 
 
 def get_conditional_likelihood(ck, ci, cj, r, r_e):
@@ -294,6 +308,19 @@ def find_repeat_count_from_selected_reads(summaries, accuracy_filter=False, aver
     haplotypes = 1 if is_haploid else 2
     estimate = [int(occurrences / (float(average_coverage) * haplotypes))] * 2
     return GenotypeResult(estimate, len(summaries), len(covered), len(flanking), 0)
+
+
+def find_repeat_counts_of_loci(summaries, locus_off, accuracy_filter=False, is_haploid=False, minimum_left_flanking_size=5,
+                               minimum_right_flanking_size=5, threads=0):
+    """find_repeat_count_from_selected_reads for many loci at once (advntr_genotype_illumina: the same arithmetic in C++ on
+    host threads): summaries = the 8-int records of the selected reads grouped by locus, locus i = rows
+    locus_off[i]:locus_off[i+1].  Returns a list of GenotypeResult (copy_numbers None where the reference returns None)."""
+    geno, prob, counts = _lib.genotype_illumina(summaries, locus_off, accuracy_filter, is_haploid,
+                                                minimum_left_flanking_size, minimum_right_flanking_size, threads)
+    out = []
+    for (a, b), p, (rec, span, flank) in zip(geno.tolist(), prob.tolist(), counts.tolist()):
+        out.append(GenotypeResult(None if a < 0 else (a, b), rec, span, flank, p))
+    return out
 
 
 def build_vntr_matcher_hmm(left_flanking_region, right_flanking_region, repeat_segments, copies, flanking_region_size=100):

@@ -39,6 +39,10 @@ extern "C" {
                                          instead of one read per wavefront bucketed by length */
 #define ADVNTR_FLAG_ANTIDIAGONAL 16u  /* keep short reads of a large batch on the one-read-per-wavefront kernel instead of
                                          the row-blocked one (several reads per wavefront); results are identical */
+#define ADVNTR_FLAG_BOTH_STRANDS 32u  /* the n_reads given are forward strands; the engine also scores their reverse
+                                         complements (made on the device) as calls n_reads .. 2*n_reads-1, call n_reads+i
+                                         against read i's model: every output array then holds 2*n_reads entries
+                                         (process_unmapped_read scores both strands, vntr_finder.py:239-242) */
 
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8
@@ -157,13 +161,18 @@ int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const in
  * NUL-terminated ACGT strings (already trimmed to the wanted length), aligned repeat units
  * repeats[repeat_off[i] .. repeat_off[i+1]) (equal-length rows over ACGT and '-'), copies[i] repeat copies.
  * exp_fn: the exponential applied to log-probabilities where the reference calls numpy.exp (hmm.pyx:514); NULL =
- * libm exp.  It is called from the worker threads, one call at a time.  flags: ADVNTR_BUILD_ALIGN_REPEATS aligns
+ * libm exp.  It is called from the worker threads, one call at a time -- unless ADVNTR_BUILD_EXP_STRIDED_LOOP says that
+ * exp_fn is really a strided inner loop `void loop(char **args, const intptr_t *n, const intptr_t *steps, void *user)`
+ * (args = {in, out}, steps in bytes: the form of a NumPy ufunc inner loop), which must be thread-safe and is called from
+ * all worker threads concurrently (a Python callback is serialised by the interpreter lock; numpy's own loop is not).
+ * flags: ADVNTR_BUILD_ALIGN_REPEATS aligns
  * repeat units of unequal length with the built-in progressive aligner (the reference shells out to `muscle` there,
  * profile_hmm.py:166-171; parity with muscle is NOT claimed, see csrc/repeat_msa.h) -- without it they are an error.
  * out[i] receives the model or NULL; returns ADVNTR_OK or the first error (advntr_last_error names the locus).       */
 typedef struct advntr_built advntr_built;
 typedef void (*advntr_exp_fn)(const double *in, double *out, int64_t n, void *user);
 #define ADVNTR_BUILD_ALIGN_REPEATS 0x1u
+#define ADVNTR_BUILD_EXP_STRIDED_LOOP 0x2u
 int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
                                const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,
                                double max_error_rate, advntr_exp_fn exp_fn, void *user, int32_t n_threads,
@@ -196,6 +205,30 @@ void advntr_built_destroy(advntr_built *built);
 int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_reads, const uint8_t *flank_bases,
                        const int32_t *flank_off, int32_t n_flanks, const int32_t *pair_read, const int32_t *pair_flank,
                        int32_t n_pairs, int32_t *out_score, int32_t *out_begin, int32_t *out_end, float *kernel_ms);
+
+/* ---- read encoding (host threads) ---------------------------------------------------------------------------
+ * ASCII reads (concatenated, read r = ascii[read_off[r] .. read_off[r+1])) -> the base codes the scoring calls take:
+ * A,C,G,T in either case -> 0..3, N/n -> 254, anything else -> 255; out_bad[r] = 0 for a clean read, 1 when it holds
+ * N (the reference skips such reads before scoring, vntr_finder.py:237), 2 when it holds any other symbol (the
+ * reference's Model.viterbi raises ValueError on those, hmm.pyx:72,79).                                          */
+int advntr_encode_ascii(const char *ascii, const int64_t *read_off, int32_t n_reads, int32_t n_threads,
+                        uint8_t *out_codes, uint8_t *out_bad);
+
+/* ---- genotype caller on the summary records (the step downstream of scoring; host threads, no GPU) -----------
+ * Replaces, for many loci at once, the Illumina aggregation of VNTRFinder.find_repeat_count_from_alignment_file after
+ * read selection (/root/reference/advntr/vntr_finder.py:807-887: spanning / flanking split by
+ * read_flanks_repeats_with_confidence :311-322, the >= 5 agreeing flanking reads rule, the accuracy filter's >= 3
+ * spanning reads per RU count) and the maximum-likelihood diploid / haploid call of
+ * find_genotype_based_on_observed_repeats (:473-532).  summaries: the ADVNTR_SUMMARY_INTS records of the SELECTED
+ * (recruited, > 2 repeat bases) reads grouped by locus, locus i = records locus_off[i] .. locus_off[i+1].
+ * out_genotype[i] = the two RU counts in the reference's order, or -1, -1 for None; out_prob[i] = its probability
+ * (1e-20 when None; bit-equal to the reference's arithmetic); out_counts[i] (may be NULL) = recruited, spanning,
+ * flanking read counts of its GenotypeResult.  The coverage-based estimate (average_coverage) stays with the caller. */
+#define ADVNTR_GENOTYPE_ACCURACY_FILTER 1u
+#define ADVNTR_GENOTYPE_HAPLOID         2u
+int advntr_genotype_illumina(const int32_t *summaries, const int64_t *locus_off, int32_t n_loci, uint32_t flags,
+                             int32_t min_left_flank, int32_t min_right_flank, int32_t n_threads,
+                             int32_t *out_genotype, double *out_prob, int32_t *out_counts);
 
 /* ---- multi-GPU: the gather of the result records over RCCL / xGMI --------------------------------------------
  * One process per GPU; whole loci (with all their reads) are assigned to ranks (advntr_amd/sharding.py), so scoring

@@ -28,21 +28,25 @@ t0 = time.perf_counter()
 models = hmm_utils.build_read_matcher_models([(l.left, l.right, l.units, l.copies) for l in loci])
 T["build_models"] = time.perf_counter() - t0
 t1 = time.perf_counter()
+from advntr_amd.pomegranate import device_models
+device_models(models)                                   # bulk upload (otherwise done inside the scoring call)
+T["upload_models"] = time.perf_counter() - t1
+t1 = time.perf_counter()
 res = vntr_finder.score_reads_arrays(models, per_locus, None, compute_reverse=True)
 T["encode_score_recruit"] = time.perf_counter() - t1
 t2 = time.perf_counter()
 keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
-order = np.argsort(res["locus"][keep], kind="stable")
-summ = res["summary"][keep][order]
-bounds = np.searchsorted(res["locus"][keep][order], np.arange(n_loci + 1))
-genotypes = []
-for i in range(n_loci):
-    g = vntr_finder.find_repeat_count_from_selected_reads(summ[bounds[i]:bounds[i + 1]])
-    genotypes.append(g.copy_numbers)
+locus, summ = res["locus"][keep], res["summary"][keep]
+bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
+results = vntr_finder.find_repeat_counts_of_loci(summ, bounds)                   # advntr_genotype_illumina, host threads
+genotypes = [g.copy_numbers for g in results]
 T["aggregate_genotype"] = time.perf_counter() - t2
 total = time.perf_counter() - t0
 calls = 2 * len(res["logp"])
 called = sum(g is not None for g in genotypes)
+# the same through the one-call driver (vntr_finder.genotype_loci) must give the same genotypes
+again = [g.copy_numbers for g in vntr_finder.genotype_loci(models, per_locus)]
+assert again == genotypes
 print(json.dumps({"loci": n_loci, "viterbi_calls": calls, "recruited_reads": int(keep.sum()), "loci_with_genotype": called,
                   "seconds": {k: round(v, 3) for k, v in T.items()}, "total_s": round(total, 3),
                   "calls_per_s_end_to_end": round(calls / total)}))

@@ -29,6 +29,10 @@ def test_header_constants_match_binding():
     assert val("ADVNTR_SUMMARY_INTS") == _lib.SUMMARY_INTS
     assert (val("ADVNTR_FLAG_PATH"), val("ADVNTR_FLAG_FORCE_GENERIC"), val("ADVNTR_FLAG_NO_SUMMARY")) == \
         (_lib.FLAG_PATH, _lib.FLAG_FORCE_GENERIC, _lib.FLAG_NO_SUMMARY)
+    assert (val("ADVNTR_FLAG_STREAM"), val("ADVNTR_FLAG_ANTIDIAGONAL"), val("ADVNTR_FLAG_BOTH_STRANDS")) == \
+        (_lib.FLAG_STREAM, _lib.FLAG_ANTIDIAGONAL, _lib.FLAG_BOTH_STRANDS)
+    assert (val("ADVNTR_BUILD_ALIGN_REPEATS"), val("ADVNTR_BUILD_EXP_STRIDED_LOOP")) == (_lib.BUILD_ALIGN_REPEATS, _lib.BUILD_EXP_STRIDED_LOOP)
+    assert (val("ADVNTR_GENOTYPE_ACCURACY_FILTER"), val("ADVNTR_GENOTYPE_HAPLOID")) == (_lib.GENOTYPE_ACCURACY_FILTER, _lib.GENOTYPE_HAPLOID)
     for k in ("EMIT", "MATCH", "SUFFIX", "PREFIX", "UNIT_START", "UNIT_END", "SKIP", "FIX", "BASE_VALID"):
         assert val("ADVNTR_SC_" + k) == getattr(_lib, "SC_" + k)
     assert val("ADVNTR_ERR_SYMBOL") == _lib.ERR_SYMBOL

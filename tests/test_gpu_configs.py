@@ -197,3 +197,34 @@ def test_c3_rccl_communicator_world_size_1(tmp_path):
     finally:
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ADVNTR_RDZV_DIR"):
             os.environ.pop(k, None)
+
+
+def test_both_strands_flag_equals_explicit_reverse_complements():
+    """ADVNTR_FLAG_BOTH_STRANDS (reverse complements made on the device, calls n .. 2n-1) == scoring the forward reads and
+    their host-made reverse complements explicitly -- what process_unmapped_read does (vntr_finder.py:239-242); ragged
+    lengths, several loci, paths included, both the one-shot and the device-resident API."""
+    from advntr_amd import _lib, workloads, vntr_finder
+    from advntr_amd.pomegranate import device_models
+    rng = np.random.default_rng(808)
+    loci = [workloads.make_locus(rng, 150, int(L), vntr_finder.get_copies_for_hmm(150, int(L))) for L in (7, 23, 61)]
+    workloads.build_models(loci)
+    dms = device_models([l.model for l in loci])
+    reads, which = [], []
+    for k, loc in enumerate(loci):
+        for n in (150, 150, 150, 149, 90, 64, 33, 1, 200, 301):
+            reads += workloads.make_reads(rng, loc, 3, n, locus_fraction=0.7)
+            which += [k] * 3
+    which = np.asarray(which, np.int32)
+    bases, off = _lib.encode_reads(reads)
+    lp2, sm2, paths2 = _lib.viterbi_batch(dms, bases, off, which, flags=_lib.FLAG_BOTH_STRANDS, want_paths=True)
+    n = len(reads)
+    assert len(lp2) == 2 * n and sm2.shape == (2 * n, 8) and len(paths2) == 2 * n
+    both = reads + [vntr_finder.reverse_complement(s) for s in reads]
+    b2, o2 = _lib.encode_reads(both)
+    lp, sm, paths = _lib.viterbi_batch(dms, b2, o2, np.concatenate([which, which]), want_paths=True)
+    assert np.array_equal(lp, lp2) and np.array_equal(sm, sm2) and paths == paths2
+    B = _lib.DeviceBatch(dms, bases, off, which, flags=_lib.FLAG_BOTH_STRANDS)
+    B.run()
+    lp3, sm3 = B.fetch()
+    B.close()
+    assert np.array_equal(lp3, lp) and np.array_equal(sm3, sm)
