@@ -47,6 +47,7 @@ SYMBOLS = {
     "advntr_kwfilter_create": (_vp, [_vp, _vp, _vp, _i32]),
     "advntr_kwfilter_destroy": (None, [_vp]),
     "advntr_kwfilter_scan": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "advntr_kwfilter_scan_text": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp]),
     "advntr_build_read_matchers": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp, _vp, _i32, _u32, _vp]),
     "advntr_align_repeats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "advntr_flank_align": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -56,6 +57,8 @@ SYMBOLS = {
     "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
     "advntr_built_destroy": (None, [_vp]),
     "advntr_encode_ascii": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
+    "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "advntr_comm_unique_id": (ctypes.c_int, [_vp]),
     "advntr_comm_create": (_vp, [_i32, _i32, _vp]),
@@ -161,6 +164,41 @@ def encode_ascii(seqs, threads=0):
     codes = np.empty(len(raw), np.uint8)
     bad = np.zeros(n, np.uint8)
     check(load().advntr_encode_ascii(raw, ptr(off), n, int(threads), ptr(codes), ptr(bad)))
+    return codes, off, bad
+
+
+ENCODE_CASE_SENSITIVE = 1
+
+
+def line_index(text_bytes, threads=0):
+    """advntr_line_index: int64 start offsets of the lines of a bytes object, plus the total length as a last entry."""
+    n = len(text_bytes)
+    cap = max(16, text_bytes.count(b"\n", 0, min(n, 1 << 16)) * (n // max(1, min(n, 1 << 16)) + 1) + 16)
+    n_lines = ctypes.c_int64(0)
+    while True:
+        starts = np.empty(cap + 1, np.int64)
+        rc = load().advntr_line_index(text_bytes, n, int(threads), ptr(starts), cap, ctypes.byref(n_lines))
+        if rc == ERR_TOO_LARGE and n_lines.value > cap:
+            cap = int(n_lines.value)
+            continue
+        check(rc)
+        break
+    k = int(n_lines.value)
+    starts[k] = n
+    return starts[:k + 1]
+
+
+def encode_spans(text_bytes, span_start, span_end, case_sensitive=False, threads=0):
+    """advntr_encode_spans: (codes over the concatenated spans, read_off int64, bad uint8[n])."""
+    span_start = np.ascontiguousarray(span_start, np.int64)
+    span_end = np.ascontiguousarray(span_end, np.int64)
+    n = len(span_start)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(span_end - span_start, out=off[1:])
+    codes = np.empty(int(off[-1]), np.uint8)
+    bad = np.zeros(n, np.uint8)
+    check(load().advntr_encode_spans(text_bytes, ptr(span_start), ptr(span_end), n, ENCODE_CASE_SENSITIVE if case_sensitive else 0,
+                                     int(threads), ptr(off), ptr(codes), ptr(bad)))
     return codes, off, bad
 
 

@@ -25,26 +25,44 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
         fail(ADVNTR_ERR_ARG, "advntr_kwfilter_create: bad argument");
         return nullptr;
     }
-    // group keyword strings: packed key -> owners (in keyword order)
-    std::map<uint64_t, std::vector<int32_t>> groups;
-    std::vector<int> lengths;
+    // group keyword strings: packed key -> owners (in keyword order).  A keyword of more than 29 bases is filed under the
+    // key of its 29-base prefix (tag KWF_LONG_TAG) with a record of what follows the prefix.
+    std::map<uint64_t, std::vector<int32_t>> groups;          // short keys: owners; long-prefix keys: indices into long_recs_h
+    std::vector<KwfLongRec> long_recs_h;
+    std::vector<uint8_t> long_bases;
+    std::vector<std::pair<int, int>> lengths;                 // (window length, tag)
     for (int w = 0; w < n_keywords; ++w) {
         const int64_t L = kw_off[w + 1] - kw_off[w];
-        if (L < 1 || L > 29) {
-            fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: keyword %d has length %lld (supported: 1..29)", w, (long long)L);
+        if (L < 1 || L > 0x7fffffff) {
+            fail(ADVNTR_ERR_ARG, "advntr_kwfilter_create: keyword %d has length %lld", w, (long long)L);
             return nullptr;
         }
-        uint64_t key = 0;
-        for (int64_t i = kw_off[w]; i < kw_off[w + 1]; ++i) {
+        for (int64_t i = kw_off[w]; i < kw_off[w + 1]; ++i)
             if (kw_bases[i] > 3) {
                 fail(ADVNTR_ERR_SYMBOL, "advntr_kwfilter_create: keyword %d holds a non-ACGT symbol", w);
                 return nullptr;
             }
-            key = (key << 2) | kw_bases[i];
+        const int win = (int)std::min<int64_t>(L, KWF_MAX_PACKED);
+        const int tag = L > KWF_MAX_PACKED ? KWF_LONG_TAG : (int)L;
+        uint64_t key = 0;
+        for (int64_t i = kw_off[w]; i < kw_off[w] + win; ++i) key = (key << 2) | kw_bases[i];
+        key |= (uint64_t)tag << 58;
+        if (tag == KWF_LONG_TAG) {
+            KwfLongRec rec{};
+            rec.rest_off = (uint32_t)long_bases.size();
+            rec.rest_len = (uint32_t)(L - win);
+            rec.owner = kw_vntr[w];
+            if (long_bases.size() + (size_t)(L - win) > 0xffffffffu) {
+                fail(ADVNTR_ERR_TOO_LARGE, "advntr_kwfilter_create: more than 4 GiB of long keywords");
+                return nullptr;
+            }
+            long_bases.insert(long_bases.end(), kw_bases + kw_off[w] + win, kw_bases + kw_off[w + 1]);
+            groups[key].push_back((int32_t)long_recs_h.size());
+            long_recs_h.push_back(rec);
+        } else {
+            groups[key].push_back(kw_vntr[w]);
         }
-        key |= (uint64_t)L << 58;
-        groups[key].push_back(kw_vntr[w]);
-        if (std::find(lengths.begin(), lengths.end(), (int)L) == lengths.end()) lengths.push_back((int)L);
+        if (std::find(lengths.begin(), lengths.end(), std::make_pair(win, tag)) == lengths.end()) lengths.emplace_back(win, tag);
     }
     if ((int)lengths.size() > KWF_MAX_LENGTHS) {
         fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: %zu distinct keyword lengths (max %d)", lengths.size(), KWF_MAX_LENGTHS);
@@ -55,13 +73,22 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     while (slots < groups.size() * 4) slots <<= 1;
     std::vector<uint64_t> keys(slots, KWF_EMPTY);
     std::vector<uint32_t> vals(slots, 0), bitset(KWF_BITSET_BITS / 32, 0);
-    size_t fp_slots = 4096;
-    while (fp_slots < groups.size() * 3 && fp_slots < (1u << 20)) fp_slots <<= 1;     // <= 2 MiB of uint16
-    std::vector<uint16_t> fps(fp_slots, 0);
-    std::vector<int32_t> ids;
+    // fingerprint table: buckets of eight 16-bit fingerprints, on average <= 2.5 keys per bucket at any keyword count (2 MiB,
+    // L2-resident, for the ~320 k keywords of the 6 719-locus set; it simply grows beyond that).  A bucket that receives more
+    // than seven keys gets the overflow marker in its last slot: every key that hashes there then goes to the exact table.
+    size_t n_buckets = 512;
+    while (n_buckets * 5 < groups.size() * 2) n_buckets <<= 1;
+    std::vector<uint16_t> fps(n_buckets * 8, 0);
+    std::vector<int32_t> ids;                                  // short keys: owners
+    std::vector<KwfLongRec> long_recs;                         // long-prefix keys: their records, contiguous per key
     for (auto &kv : groups) {
-        if (kv.second.size() > 255 || ids.size() > 0xffffffu) {
-            fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: keyword shared by more than 255 VNTRs");
+        const bool is_long = (kv.first >> 58) == KWF_LONG_TAG;
+        if (kv.second.size() > 255) {
+            fail(ADVNTR_ERR_UNSUPPORTED, "advntr_kwfilter_create: a keyword (or 29-base prefix) is shared by more than 255 VNTRs");
+            return nullptr;
+        }
+        if ((is_long ? long_recs.size() : ids.size()) + kv.second.size() > 0xffffffu) {
+            fail(ADVNTR_ERR_TOO_LARGE, "advntr_kwfilter_create: more than 2^24 (keyword, VNTR) pairs");
             return nullptr;
         }
         const uint64_t h = kwf_hash(kv.first);
@@ -69,14 +96,23 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
         bitset[b >> 5] |= 1u << (b & 31);
         const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
         bitset[b2 >> 5] |= 1u << (b2 & 31);
-        size_t fs = kwf_fp_slot(h, (uint32_t)(fp_slots - 1));
-        while (fps[fs] != 0) fs = (fs + 1) & (fp_slots - 1);
-        fps[fs] = kwf_fp(h);
+        {
+            uint16_t *bucket = fps.data() + (size_t)kwf_fp_bucket(h, (uint32_t)(n_buckets - 1)) * 8;
+            int at = 0;
+            while (at < 8 && bucket[at] != 0) ++at;
+            if (at < 7) bucket[at] = kwf_fp(h);                         // (slot 7 is kept for the marker)
+            else bucket[7] = KWF_FP_OVERFLOW;                           // eighth key (or later): the bucket answers "maybe" from now on
+        }
         size_t s = (h & 0xffffffffull) & (slots - 1);
-        while (keys[s] != KWF_EMPTY) s = (s + 1) & (slots - 1);
+        while (keys[s] != KWF_EMPTY) s = (s + 1) & (slots - 1);         // terminates: at most a quarter of the slots are taken
         keys[s] = kv.first;
-        vals[s] = (uint32_t)ids.size() | ((uint32_t)kv.second.size() << 24);
-        ids.insert(ids.end(), kv.second.begin(), kv.second.end());
+        if (is_long) {
+            vals[s] = (uint32_t)long_recs.size() | ((uint32_t)kv.second.size() << 24);
+            for (int32_t i : kv.second) long_recs.push_back(long_recs_h[i]);
+        } else {
+            vals[s] = (uint32_t)ids.size() | ((uint32_t)kv.second.size() << 24);
+            ids.insert(ids.end(), kv.second.begin(), kv.second.end());
+        }
     }
     advntr_kwfilter *F = new advntr_kwfilter();
     F->n_keys = (int64_t)groups.size();
@@ -90,7 +126,8 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     void *dk = up(keys.data(), keys.size() * 8), *dv = up(vals.data(), vals.size() * 4);
     void *di = up(ids.data(), ids.size() * 4), *db = up(bitset.data(), bitset.size() * 4);
     void *df = up(fps.data(), fps.size() * 2);
-    if (!dk || !dv || !di || !db || !df) {
+    void *dl = up(long_recs.data(), long_recs.size() * sizeof(KwfLongRec)), *dlb = up(long_bases.data(), long_bases.size());
+    if (!dk || !dv || !di || !db || !df || !dl || !dlb) {
         fail(ADVNTR_ERR_DEVICE, "advntr_kwfilter_create: device upload failed");
         advntr_kwfilter_destroy(F);
         return nullptr;
@@ -98,53 +135,73 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     KwfDevice &D = F->dev;
     D.n_lengths = (int32_t)lengths.size();
     for (size_t i = 0; i < lengths.size(); ++i) {
-        D.length[i] = lengths[i];
-        D.mask[i] = lengths[i] >= 32 ? ~0ull : ((1ull << (2 * lengths[i])) - 1ull);
+        D.length[i] = lengths[i].first;
+        D.tag[i] = lengths[i].second;
+        D.mask[i] = (1ull << (2 * lengths[i].first)) - 1ull;
     }
+    D.long_recs = (const KwfLongRec *)dl; D.long_bases = (const uint8_t *)dlb;
     D.table_mask = slots - 1;
     D.keys = (const uint64_t *)dk; D.vals = (const uint32_t *)dv; D.ids = (const int32_t *)di; D.bitset = (const uint32_t *)db;
-    D.fps = (const uint16_t *)df; D.fp_mask = (uint32_t)(fp_slots - 1);
+    D.fp_buckets = (const uint4 *)df; D.bucket_mask = (uint32_t)(n_buckets - 1);
     return F;
 }
 
-extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, const int64_t *read_off, int32_t n_reads,
-                                    int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity,
-                                    int64_t *n_out, float *kernel_ms)
+// reads = spans [span_start[r], span_end[r]) of `bytes` (n_bytes long): base codes, or with `ascii` the text of a FASTA file
+static int kwfilter_scan_spans(advntr_kwfilter *F, const uint8_t *bytes, int64_t n_bytes, const int64_t *span_start,
+                               const int64_t *span_end, int32_t n_reads, bool ascii, int32_t *out_read, int32_t *out_vntr,
+                               int32_t *out_count, int64_t capacity, int64_t *n_out, float *kernel_ms)
 {
-    if (!F || !read_off || n_reads < 0 || !n_out || capacity < 0 || (capacity && (!out_read || !out_vntr || !out_count)))
-        return fail(ADVNTR_ERR_ARG, "advntr_kwfilter_scan: bad argument");
     *n_out = 0;
     if (n_reads == 0) return ADVNTR_OK;
-    const int64_t total = read_off[n_reads];
+    for (int r = 0; r < n_reads; ++r)
+        if (span_start[r] < 0 || span_end[r] < span_start[r] || span_end[r] > n_bytes || span_end[r] - span_start[r] > 0x7fffffff)
+            return fail(ADVNTR_ERR_ARG, "keyword prefilter: read %d is not a span of the %lld bytes given", r, (long long)n_bytes);
     uint8_t *d_bases = nullptr;
-    int64_t *d_off = nullptr;
+    int64_t *d_start = nullptr, *d_end = nullptr;
     int32_t *d_r = nullptr, *d_v = nullptr, *d_c = nullptr;
     unsigned long long *d_n = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // buffers, like a batch's, come from the per-device cache (a scan per FASTA chunk would otherwise spend more time in
+    // hipMalloc / hipFree than in the kernel)
+    const int dev = current_device();
+    std::vector<std::pair<void *, size_t>> held;
+    auto take = [&](size_t bytes_wanted) -> void * {
+        size_t got = 0;
+        void *p = g_cache.get(dev, bytes_wanted, &got);
+        if (p) held.emplace_back(p, got);
+        return p;
+    };
     auto cleanup = [&]() {
-        (void)hipFree(d_bases); (void)hipFree(d_off); (void)hipFree(d_r); (void)hipFree(d_v); (void)hipFree(d_c); (void)hipFree(d_n);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
+        for (auto &h : held) g_cache.put(dev, h.first, h.second);
+        if (e0) g_cache.put_event(dev, e0);
+        if (e1) g_cache.put_event(dev, e1);
     };
     int rc = [&]() -> int {
-        HIP_TRY(hipMalloc(&d_bases, (size_t)total + 16));
-        HIP_TRY(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
-        HIP_TRY(hipMalloc(&d_r, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_v, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_c, std::max<int64_t>(capacity, 1) * 4));
-        HIP_TRY(hipMalloc(&d_n, 8));
+        const size_t cap = (size_t)std::max<int64_t>(capacity, 1);
+        const bool contiguous = span_end == span_start + 1;                 // read_off form: one array serves both
+        d_bases = (uint8_t *)take((size_t)n_bytes + 80);                    // (+ slack: the kernel fetches whole 64-byte sectors
+        d_start = (int64_t *)take(((size_t)n_reads + 1) * 8);               //  only when they lie inside a read)
+        d_end = contiguous ? d_start + 1 : (int64_t *)take((size_t)n_reads * 8);
+        d_r = (int32_t *)take(cap * 4); d_v = (int32_t *)take(cap * 4); d_c = (int32_t *)take(cap * 4);
+        d_n = (unsigned long long *)take(8);
+        if (!d_bases || !d_start || !d_end || !d_r || !d_v || !d_c || !d_n)
+            return fail(ADVNTR_ERR_DEVICE, "keyword prefilter: device allocation failed");
         HIP_TRY(hipMemset(d_n, 0, 8));
-        if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
+        if (n_bytes) HIP_TRY(hipMemcpy(d_bases, bytes, (size_t)n_bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_start, span_start, ((size_t)n_reads + (contiguous ? 1 : 0)) * 8, hipMemcpyHostToDevice));
+        if (!contiguous) HIP_TRY(hipMemcpy(d_end, span_end, (size_t)n_reads * 8, hipMemcpyHostToDevice));
+        e0 = g_cache.get_event(dev);
+        e1 = g_cache.get_event(dev);
+        if (!e0 || !e1) return fail(ADVNTR_ERR_DEVICE, "keyword prefilter: event creation failed");
         KwfArgs a{};
-        a.f = F->dev; a.bases = d_bases; a.read_off = d_off; a.n_reads = n_reads;
+        a.f = F->dev; a.bases = d_bases; a.span_start = d_start; a.span_end = d_end; a.n_reads = n_reads;
         a.out_read = d_r; a.out_vntr = d_v; a.out_count = d_c; a.n_out = d_n; a.capacity = capacity;
         const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus()));
-        HIP_TRY(hipFuncSetAttribute((const void *)keyword_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
+        const void *kernel = ascii ? (const void *)keyword_filter_kernel<true> : (const void *)keyword_filter_kernel<false>;
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(keyword_filter_kernel, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
+        if (ascii) hipLaunchKernelGGL(keyword_filter_kernel<true>, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
+        else hipLaunchKernelGGL(keyword_filter_kernel<false>, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));
@@ -152,7 +209,7 @@ extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, co
         unsigned long long n = 0;
         HIP_TRY(hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost));
         *n_out = (int64_t)n;
-        if ((int64_t)n > capacity) return fail(ADVNTR_ERR_TOO_LARGE, "advntr_kwfilter_scan: %llu records, capacity %lld", n, (long long)capacity);
+        if ((int64_t)n > capacity) return fail(ADVNTR_ERR_TOO_LARGE, "keyword prefilter: %llu records, capacity %lld", n, (long long)capacity);
         if (n) {
             HIP_TRY(hipMemcpy(out_read, d_r, n * 4, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(out_vntr, d_v, n * 4, hipMemcpyDeviceToHost));
@@ -166,4 +223,24 @@ extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, co
     return rc;
 }
 
+extern "C" int advntr_kwfilter_scan(advntr_kwfilter *F, const uint8_t *bases, const int64_t *read_off, int32_t n_reads,
+                                    int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity,
+                                    int64_t *n_out, float *kernel_ms)
+{
+    if (!F || !read_off || n_reads < 0 || !n_out || capacity < 0 || (capacity && (!out_read || !out_vntr || !out_count)))
+        return fail(ADVNTR_ERR_ARG, "advntr_kwfilter_scan: bad argument");
+    if (n_reads && read_off[n_reads] > 0 && !bases) return fail(ADVNTR_ERR_ARG, "advntr_kwfilter_scan: null bases");
+    return kwfilter_scan_spans(F, bases, n_reads ? read_off[n_reads] : 0, read_off, read_off + 1, n_reads, false, out_read, out_vntr,
+                               out_count, capacity, n_out, kernel_ms);
+}
 
+extern "C" int advntr_kwfilter_scan_text(advntr_kwfilter *F, const char *text, int64_t n_bytes, const int64_t *span_start,
+                                         const int64_t *span_end, int32_t n_reads, int32_t *out_read, int32_t *out_vntr,
+                                         int32_t *out_count, int64_t capacity, int64_t *n_out, float *kernel_ms)
+{
+    if (!F || n_bytes < 0 || n_reads < 0 || !n_out || capacity < 0 || (capacity && (!out_read || !out_vntr || !out_count)) ||
+        (n_reads && (!span_start || !span_end || !text)))
+        return fail(ADVNTR_ERR_ARG, "advntr_kwfilter_scan_text: bad argument");
+    return kwfilter_scan_spans(F, (const uint8_t *)text, n_bytes, span_start, span_end, n_reads, true, out_read, out_vntr,
+                               out_count, capacity, n_out, kernel_ms);
+}

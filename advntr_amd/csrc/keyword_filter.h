@@ -3,7 +3,8 @@
 // Replaces the scan loop of the reference's Aho-Corasick filter (/root/reference/filtering/main.cc:247-283):
 // for every read, count per VNTR how many (position, keyword) matches occur.  With keywords of a few fixed
 // lengths (adVNTR cuts 15-mers, vntr_finder.py:140-153 / genome_analyzer.py:180) the automaton is equivalent to
-// exact k-mer lookup: a thread slides a 2-bit-packed window over its read (any symbol other than A,C,G,T -- code 4
+// exact k-mer lookup; keywords of more than 29 bases (the long-read mode's two 80-base flanks per VNTR,
+// vntr_finder.py:151-152) are found through their 29-base prefix and verified base by base on the (rare) hits: a thread slides a 2-bit-packed window over its read (any symbol other than A,C,G,T -- code 4
 // -- restarts the window, like symbol 4 in main.cc:44-55), tests a 64 KiB bit-set staged in LDS and, on a set bit,
 // probes an open-addressing table of packed keywords in HBM/L2.  Hits are rare; they are tallied in four
 // per-thread (vntr, count) slots, overflow goes out as single events.  Everything that depends on read ORDER
@@ -17,24 +18,38 @@
 #define KWF_BITSET_BITS (1u << 20)          // 128 KiB of LDS: one 1024-thread workgroup per CU, two bits per keyword
 #define KWF_EMPTY 0xffffffffffffffffull
 #define KWF_SLOTS 4
+#ifndef KWF_BATCH
+#define KWF_BATCH 4                          // positions whose fingerprint loads are in flight together (4 or 8)
+#endif
+
+#define KWF_MAX_PACKED 29                    // bases in a 64-bit key (58 bits + a 6-bit tag)
+#define KWF_LONG_TAG 30                      // tag of the 29-base prefix of a longer keyword
+
+struct KwfLongRec {                          // a keyword of more than 29 bases: what follows its 29-base prefix
+    uint32_t rest_off, rest_len;             // long_bases[rest_off .. rest_off + rest_len)
+    int32_t owner, pad;
+};
 
 struct KwfDevice {
     int32_t n_lengths;
-    int32_t length[KWF_MAX_LENGTHS];
+    int32_t length[KWF_MAX_LENGTHS];         // window length in bases (29 for the prefixes of longer keywords)
+    int32_t tag[KWF_MAX_LENGTHS];            // key tag: the length itself, or KWF_LONG_TAG
     uint64_t mask[KWF_MAX_LENGTHS];          // 2*L low bits
     uint64_t table_mask;                     // slots - 1 (one table for all lengths; the length is mixed into the key hash)
     const uint64_t *keys;                    // slots, KWF_EMPTY = free; key = packed bases | length << 58
     const uint32_t *vals;                    // slots: first index into ids[] | count << 24
     const int32_t *ids;                      // vntr index per (keyword string, owner) pair
     const uint32_t *bitset;                  // KWF_BITSET_BITS / 32 words
-    const uint16_t *fps;                     // second-level filter: 16-bit fingerprints, open addressing (0 = free),
-    uint32_t fp_mask;                        // small enough (<= 2 MiB) to stay resident in every XCD's L2
+    const uint4 *fp_buckets;                 // second-level filter: buckets of eight 16-bit fingerprints (0 = free), ONE 16-byte
+    uint32_t bucket_mask;                    // load per tested position, no probe chain; 2 MiB (L2-resident) at ~320 k keywords
+    const KwfLongRec *long_recs;             // keywords longer than 29 bases (the reference's long-read mode cuts two
+    const uint8_t *long_bases;               // 80-base flanks per VNTR, vntr_finder.py:151-152), chained off their prefix
 };
 
 struct KwfArgs {
     KwfDevice f;
-    const uint8_t *bases;                    // codes 0..3, 4 = anything else
-    const int64_t *read_off;
+    const uint8_t *bases;                    // codes 0..3, anything above = any other symbol; or (ASCII kernel) the text itself
+    const int64_t *span_start, *span_end;    // read r = bases[span_start[r] .. span_end[r])
     int32_t n_reads;
     int32_t *out_read, *out_vntr, *out_count;
     unsigned long long *n_out;               // atomic cursor
@@ -53,22 +68,27 @@ __host__ __device__ __forceinline__ uint64_t kwf_hash(uint64_t k)
     return ((uint64_t)y << 40) | x;
 }
 
-// fingerprint of a key (never 0) and its home slot in the fingerprint table
-__host__ __device__ __forceinline__ uint16_t kwf_fp(uint64_t h) { return (uint16_t)(((h >> 24) & 0xffffu) | 1u); }
-__host__ __device__ __forceinline__ uint32_t kwf_fp_slot(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 8) & mask; }
-
-// true if the fingerprint table may hold the key (linear probing until a free slot)
-__device__ __forceinline__ bool kwf_fp_maybe(const KwfDevice &f, uint64_t h, uint16_t first)
+// fingerprint of a key (odd, never 0 and never the overflow marker) and its bucket in the fingerprint table
+#define KWF_FP_OVERFLOW 0xffffu              // in a bucket's last slot: more keys hashed here than fit -> "maybe" for every key
+__host__ __device__ __forceinline__ uint16_t kwf_fp(uint64_t h)
 {
-    const uint16_t want = kwf_fp(h);
-    uint32_t s = kwf_fp_slot(h, f.fp_mask);
-    uint16_t v = first;
-    for (;;) {
-        if (v == 0) return false;
-        if (v == want) return true;
-        s = (s + 1) & f.fp_mask;
-        v = f.fps[s];
+    const uint16_t f = (uint16_t)(((h >> 24) & 0xffffu) | 1u);
+    return f == KWF_FP_OVERFLOW ? (uint16_t)0xfffdu : f;
+}
+__host__ __device__ __forceinline__ uint32_t kwf_fp_bucket(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 8) & mask; }
+
+// true if the key's bucket holds its fingerprint (or has overflowed): one 16-byte load, compared in registers
+__device__ __forceinline__ bool kwf_fp_maybe(const uint4 b, const uint64_t h)
+{
+    const unsigned want = kwf_fp(h), w2 = want | (want << 16);
+    unsigned hit = 0;
+    const unsigned words[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned x = words[i] ^ w2;                             // a 16-bit half is zero where a slot equals the fingerprint
+        hit |= ((x & 0xffffu) == 0u) | ((x >> 16) == 0u);
     }
+    return hit != 0u || (b.w >> 16) == KWF_FP_OVERFLOW;
 }
 
 __device__ __forceinline__ void kwf_emit(const KwfArgs &a, int read, int vntr, int count)
@@ -97,18 +117,69 @@ __device__ __forceinline__ void kwf_tally(const KwfArgs &a, const uint32_t v, co
     }
 }
 
+// ASCII text -> the code of a base: upper-case A, C, G, T -> 0..3, anything else -> 4 (the reference's char_to_num,
+// filtering/main.cc:44-55, is case sensitive)
+__device__ __forceinline__ unsigned kwf_code_of_ascii(const unsigned c)
+{
+    const unsigned t = c - 0x41u;                                     // 'A' 0, 'C' 2, 'G' 6, 'T' 19
+    const bool valid = t < 20u && ((0x80045u >> t) & 1u);
+    const unsigned x = (c >> 1) & 3u;                                 // A 0, C 1, G 3, T 2
+    return valid ? (x ^ (x >> 1)) : 4u;
+}
+
+// one owner's count
+__device__ __forceinline__ void kwf_tally_one(const KwfArgs &a, const int vid, const int r, int (&svid)[KWF_SLOTS],
+                                              int (&scnt)[KWF_SLOTS])
+{
+    bool done = false;
+#pragma unroll
+    for (int s = 0; s < KWF_SLOTS; ++s) {
+        if (!done && (svid[s] == vid || svid[s] < 0)) { svid[s] = vid; scnt[s] += 1; done = true; }
+    }
+    if (!done) kwf_emit(a, r, vid, 1);
+}
+
+// the window ending at read position `pos` equals the 29-base prefix of one or more long keywords: compare what follows
+template <bool ASCII>
+__device__ __forceinline__ void kwf_tally_long(const KwfArgs &a, const uint32_t v, const int r, const uint8_t *__restrict__ seq,
+                                               const int pos, const int n, int (&svid)[KWF_SLOTS], int (&scnt)[KWF_SLOTS])
+{
+    const int first = (int)(v & 0xffffffu), cnt = (int)(v >> 24);
+    for (int q = 0; q < cnt; ++q) {
+        const KwfLongRec rec = a.f.long_recs[first + q];
+        if (pos + 1 + (int64_t)rec.rest_len > n) continue;
+        const uint8_t *want = a.f.long_bases + rec.rest_off;
+        bool same = true;
+        for (uint32_t i = 0; i < rec.rest_len && same; ++i)
+            same = (ASCII ? kwf_code_of_ascii(seq[pos + 1 + i]) : (unsigned)seq[pos + 1 + i]) == (unsigned)want[i];
+        if (same) kwf_tally_one(a, rec.owner, r, svid, scnt);
+    }
+}
+
+template <bool ASCII>
 __device__ __forceinline__ void kwf_probe(const KwfArgs &a, const uint64_t key, uint64_t slot, uint64_t k, const int r,
+                                          const uint8_t *__restrict__ seq, const int pos, const int n,
                                           int (&svid)[KWF_SLOTS], int (&scnt)[KWF_SLOTS])
 {
-    for (;;) {
+    for (uint64_t probes = 0; probes <= a.f.table_mask; ++probes) {
         if (k == KWF_EMPTY) return;
-        if (k == key) { kwf_tally(a, a.f.vals[slot], r, svid, scnt); return; }
+        if (k == key) {
+            if ((key >> 58) == KWF_LONG_TAG) kwf_tally_long<ASCII>(a, a.f.vals[slot], r, seq, pos, n, svid, scnt);
+            else kwf_tally(a, a.f.vals[slot], r, svid, scnt);
+            return;
+        }
         slot = (slot + 1) & a.f.table_mask;
         k = a.f.keys[slot];
     }
 }
 
-#define KWF_BLOCK 1024      // 16 waves share one 64 KiB bit-set: two workgroups fill a CU (32 waves)
+#define KWF_BLOCK 1024      // 16 waves share one 128 KiB bit-set (one workgroup per CU)
+// ASCII: the reads are spans of the uploaded FASTA text and are mapped to codes on the fly (no encoded copy exists
+// anywhere: the host only indexes the lines)
+// (Tried and measured on the 2 M-read bench, kernel ms: this structure 1.50; the same with all eight positions of a word in
+// one batch 1.50; a branch-free version -- every position hashed and tested, hits handled by one out-of-line function,
+// 8 k instead of 44 k instructions -- 2.12: skipping the work of positions that cannot match beats the smaller code.)
+template <bool ASCII>
 __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t bits[];
@@ -116,10 +187,10 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
     __syncthreads();
     const bool single = a.f.n_lengths == 1;
     const int L0 = a.f.length[0];
-    const uint64_t mask0 = a.f.mask[0];
+    const uint64_t mask0 = a.f.mask[0], tag0 = (uint64_t)a.f.tag[0] << 58;
     for (int r = blockIdx.x * KWF_BLOCK + threadIdx.x; r < a.n_reads; r += gridDim.x * KWF_BLOCK) {
-        const uint8_t *seq = a.bases + a.read_off[r];
-        const int n = (int)(a.read_off[r + 1] - a.read_off[r]);
+        const uint8_t *seq = a.bases + a.span_start[r];
+        const int n = (int)(a.span_end[r] - a.span_start[r]);
         int svid[KWF_SLOTS], scnt[KWF_SLOTS];
 #pragma unroll
         for (int s = 0; s < KWF_SLOTS; ++s) { svid[s] = -1; scnt[s] = 0; }
@@ -144,56 +215,58 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
             if (p0 >= n) break;
             const uint64_t word = sector[wi];
             if (single) {
-                // per half-word (4 positions): phase 1 keys + LDS bit-set test; phase 2 the fingerprint loads of the
+                // per half-word (KWF_BATCH positions): phase 1 keys + LDS bit-set test; phase 2 the bucket loads of the
                 // survivors issued together (memory-level parallelism instead of one dependent L2 round trip per
                 // base); phase 3 full-key probes of the (rare) fingerprint matches
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint64_t key[4], hh[4];
-                    uint16_t f0[4];
+                for (int half = 0; half < 8 / KWF_BATCH; ++half) {
+                    uint64_t key[KWF_BATCH], hh[KWF_BATCH];
+                    uint4 f0[KWF_BATCH];
                     unsigned live = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int qq = half * 4 + q;
-                        const unsigned c = (unsigned)(word >> (8 * qq)) & 0xffu;
+                    for (int q = 0; q < KWF_BATCH; ++q) {
+                        const int qq = half * KWF_BATCH + q;
+                        unsigned c = (unsigned)(word >> (8 * qq)) & 0xffu;
+                        if (ASCII) c = kwf_code_of_ascii(c);
                         const bool inside = p0 + qq < n;
                         if (!inside || c > 3u) { run = 0; win = 0; continue; }
                         win = (win << 2) | c;
                         ++run;
                         if (run < L0) continue;
-                        key[q] = (win & mask0) | ((uint64_t)L0 << 58);
+                        key[q] = (win & mask0) | tag0;
                         const uint64_t h = kwf_hash(key[q]);
                         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
                         const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
                         if (((bits[b >> 5] >> (b & 31)) & (bits[b2 >> 5] >> (b2 & 31))) & 1u) { live |= 1u << q; hh[q] = h; }
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (live & (1u << q)) f0[q] = a.f.fps[kwf_fp_slot(hh[q], a.f.fp_mask)];
+                    for (int q = 0; q < KWF_BATCH; ++q)
+                        if (live & (1u << q)) f0[q] = a.f.fp_buckets[kwf_fp_bucket(hh[q], a.f.bucket_mask)];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((live & (1u << q)) && kwf_fp_maybe(a.f, hh[q], f0[q])) {
+                    for (int q = 0; q < KWF_BATCH; ++q)
+                        if ((live & (1u << q)) && kwf_fp_maybe(f0[q], hh[q])) {
                             const uint64_t slot = (hh[q] & 0xffffffffull) & a.f.table_mask;
-                            kwf_probe(a, key[q], slot, a.f.keys[slot], r, svid, scnt);
+                            kwf_probe<ASCII>(a, key[q], slot, a.f.keys[slot], r, seq, p0 + half * KWF_BATCH + q, n, svid, scnt);
                         }
                 }
             } else {
                 for (int q = 0; q < 8 && p0 + q < n; ++q) {
-                    const unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
+                    unsigned c = (unsigned)(word >> (8 * q)) & 0xffu;
+                    if (ASCII) c = kwf_code_of_ascii(c);
                     if (c > 3u) { run = 0; win = 0; continue; }
                     win = (win << 2) | c;
                     ++run;
                     for (int li = 0; li < a.f.n_lengths; ++li) {
                         const int L = a.f.length[li];
                         if (run < L) continue;
-                        const uint64_t key = (win & a.f.mask[li]) | ((uint64_t)L << 58);
+                        const uint64_t key = (win & a.f.mask[li]) | ((uint64_t)a.f.tag[li] << 58);
                         const uint64_t h = kwf_hash(key);
                         const unsigned b = (unsigned)(h >> 40) & (KWF_BITSET_BITS - 1);
                         const unsigned b2 = (unsigned)(h >> 4) & (KWF_BITSET_BITS - 1);
                         if (!(((bits[b >> 5] >> (b & 31)) & (bits[b2 >> 5] >> (b2 & 31))) & 1u)) continue;
-                        if (!kwf_fp_maybe(a.f, h, a.f.fps[kwf_fp_slot(h, a.f.fp_mask)])) continue;
+                        if (!kwf_fp_maybe(a.f.fp_buckets[kwf_fp_bucket(h, a.f.bucket_mask)], h)) continue;
                         const uint64_t slot = (h & 0xffffffffull) & a.f.table_mask;
-                        kwf_probe(a, key, slot, a.f.keys[slot], r, svid, scnt);
+                        kwf_probe<ASCII>(a, key, slot, a.f.keys[slot], r, seq, p0 + q, n, svid, scnt);
                     }
                 }
             }

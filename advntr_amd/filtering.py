@@ -91,47 +91,97 @@ class KeywordFilter(object):
         except Exception:
             pass
 
-    def count_matches(self, seqs):
-        """{read index: {vntr_id: occurrences}} for reads with at least one keyword hit (GPU)."""
+    def scan_codes(self, bases, off):
+        """One advntr_kwfilter_scan over encoded reads -> (read index, vntr index, occurrences) arrays, one row per
+        (read, VNTR) pair with at least one hit, sorted by read then VNTR index (= VNTR id order)."""
         L = _lib.load()
-        off = np.zeros(len(seqs) + 1, np.int64)
-        for i, s in enumerate(seqs):
-            off[i + 1] = off[i] + len(s)
-        flat = "".join(seqs).encode("latin-1", "replace")
-        bases = np.ascontiguousarray(_CODE5[np.frombuffer(flat, dtype=np.uint8)]) if flat else np.zeros(0, np.uint8)
-        cap = max(1024, 4 * len(seqs))
+        off = np.ascontiguousarray(off, np.int64)
+        return self._scan(len(off) - 1, lambda o_r, o_v, o_c, cap, n_out, ms: L.advntr_kwfilter_scan(
+            self._h, _lib.ptr(bases), _lib.ptr(off), len(off) - 1, _lib.ptr(o_r), _lib.ptr(o_v), _lib.ptr(o_c), cap, n_out, ms))
+
+    def scan_text(self, text, span_start, span_end):
+        """advntr_kwfilter_scan_text: the reads are spans of `text` (bytes of a FASTA file), uploaded as they are and mapped
+        to base codes on the device (upper-case ACGT only, like the reference's char_to_num).  Same result as scan_codes."""
+        L = _lib.load()
+        span_start = np.ascontiguousarray(span_start, np.int64)
+        span_end = np.ascontiguousarray(span_end, np.int64)
+        n = len(span_start)
+        return self._scan(n, lambda o_r, o_v, o_c, cap, n_out, ms: L.advntr_kwfilter_scan_text(
+            self._h, text, len(text), _lib.ptr(span_start), _lib.ptr(span_end), n, _lib.ptr(o_r), _lib.ptr(o_v), _lib.ptr(o_c),
+            cap, n_out, ms))
+
+    def _scan(self, n_reads, call):
+        cap = max(1024, n_reads // 4)
         while True:
-            o_r, o_v, o_c = (np.zeros(cap, np.int32) for _ in range(3))
+            o_r, o_v, o_c = (np.empty(cap, np.int32) for _ in range(3))
             n_out = ctypes.c_int64(0)
             ms = ctypes.c_float(0)
-            rc = L.advntr_kwfilter_scan(self._h, _lib.ptr(bases), _lib.ptr(off), len(seqs), _lib.ptr(o_r), _lib.ptr(o_v),
-                                        _lib.ptr(o_c), cap, ctypes.byref(n_out), ctypes.byref(ms))
+            rc = call(o_r, o_v, o_c, cap, ctypes.byref(n_out), ctypes.byref(ms))
             if rc == _lib.ERR_TOO_LARGE and n_out.value > cap:
                 cap = int(n_out.value) + 1024
                 continue
             _lib.check(rc)
             break
         self.kernel_ms = ms.value
-        n = n_out.value
+        n = int(n_out.value)
+        if n == 0:
+            z = np.zeros(0, np.int64)
+            return z, z, z
+        # the kernel may split a (read, VNTR) pair over several records: sum them
+        key = o_r[:n].astype(np.int64) * len(self.uniq_ids) + o_v[:n]
+        uniq, inverse = np.unique(key, return_inverse=True)
+        counts = np.bincount(inverse, weights=o_c[:n], minlength=len(uniq)).astype(np.int64)
+        return uniq // len(self.uniq_ids), uniq % len(self.uniq_ids), counts
+
+    def count_matches(self, seqs):
+        """{read index: {vntr_id: occurrences}} for reads with at least one keyword hit (GPU)."""
+        seqs = list(seqs)
+        off = np.zeros(len(seqs) + 1, np.int64)
+        if seqs:
+            np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), out=off[1:])
+        flat = "".join(seqs).encode("latin-1", "replace")
+        # (case sensitive like the reference's char_to_num, filtering/main.cc:44-55: anything but upper-case ACGT is "N")
+        bases, _, _ = _lib.encode_spans(flat, off[:-1], off[1:], case_sensitive=True)
+        reads, vntrs, counts = self.scan_codes(bases, off)
         out = {}
-        for r, v, c in zip(o_r[:n].tolist(), o_v[:n].tolist(), o_c[:n].tolist()):
-            d = out.setdefault(r, {})
-            vid = self.uniq_ids[v]
-            d[vid] = d.get(vid, 0) + c
+        for r, v, c in zip(reads.tolist(), vntrs.tolist(), counts.tolist()):
+            out.setdefault(r, {})[self.uniq_ids[v]] = c
         return out
 
     def select(self, names, seqs, min_matches=5, max_reads=2000):
         """The bookkeeping of main.cc:284-331 on top of the GPU counts -> the reference's stdout text."""
         counts = self.count_matches(seqs)
+        recs = [(r, vid, c) for r in sorted(counts) for vid, c in sorted(counts[r].items())]
+        return self._select_records(recs, lambda r: names[r], lambda r: seqs[r], min_matches, max_reads)
+
+    def select_fasta(self, text, min_matches=5, max_reads=2000):
+        """select() straight from the bytes of a two-line FASTA file (what adVNTR-Filtering reads, main.cc:247-252): line
+        index, encoding and scan on arrays; Python only touches the reads that have hits."""
+        starts = _lib.line_index(text)
+        n_lines = len(starts) - 1
+        n_rec = n_lines // 2 if n_lines % 2 == 0 else (n_lines - 1) // 2
+        ends = starts[1:] - 1                                           # exclusive end of each line (before its newline)
+        if n_lines and not text.endswith(b"\n"):
+            ends = ends.copy()
+            ends[-1] = len(text)
+        seq_lines = np.arange(n_rec) * 2 + 1
+        reads, vntrs, counts = self.scan_text(text, starts[seq_lines], ends[seq_lines])
+        recs = [(r, self.uniq_ids[v], c) for r, v, c in zip(reads.tolist(), vntrs.tolist(), counts.tolist())]
+        name_of = lambda r: text[starts[2 * r] + 1:ends[2 * r]].decode("latin-1")
+        seq_of = lambda r: text[starts[2 * r + 1]:ends[2 * r + 1]].decode("latin-1")
+        return self._select_records(recs, name_of, seq_of, min_matches, max_reads)
+
+    def _select_records(self, recs, name_of, seq_of, min_matches, max_reads):
+        """recs = (read index, vntr id, occurrences) in read order, VNTR ids ascending within a read."""
         vntr_read_list, read_sequences = {}, {}
-        for r in sorted(counts):                                   # reads in file order
-            for vid in sorted(counts[r]):
-                lst = vntr_read_list.setdefault(vid, {})
-                if len(lst) > max_reads * 3:
-                    continue
-                if counts[r][vid] >= min_matches:
-                    lst[names[r]] = counts[r][vid]
-                    read_sequences[names[r]] = seqs[r]
+        for r, vid, c in recs:                                         # reads in file order
+            lst = vntr_read_list.setdefault(vid, {})
+            if len(lst) > max_reads * 3:
+                continue
+            if c >= min_matches:
+                nm = name_of(r)
+                lst[nm] = c
+                read_sequences[nm] = seq_of(r)
         out, filtered, acc = [], set(), {}
         for vid in self.vntr_ids:
             vec = acc.setdefault(vid, [])
@@ -152,15 +202,12 @@ class KeywordFilter(object):
 
 
 def run(fasta_text, keywords_text, min_matches=5):
-    """Drop-in for `adVNTR-Filtering reads.fa [--min_matches N] < keywords.txt`: returns its stdout text."""
-    lines = fasta_text.split("\n")
-    if lines and lines[-1] == "":
-        lines.pop()
-    names = [lines[k][1:] for k in range(0, len(lines) - 1, 2)]
-    seqs = [lines[k + 1] for k in range(0, len(lines) - 1, 2)]
+    """Drop-in for `adVNTR-Filtering reads.fa [--min_matches N] < keywords.txt`: returns its stdout text.  fasta_text: str
+    or bytes of the two-line FASTA file."""
+    text = fasta_text if isinstance(fasta_text, (bytes, bytearray)) else fasta_text.encode("latin-1", "replace")
     f = KeywordFilter.from_text(keywords_text)
     try:
-        return f.select(names, seqs, min_matches=min_matches)
+        return f.select_fasta(bytes(text), min_matches=min_matches)
     finally:
         f.close()
 

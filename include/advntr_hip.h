@@ -139,7 +139,8 @@ int advntr_batch_info(const advntr_batch *batch, char *buf, int32_t capacity);
 /* ---- keyword prefilter (the stage upstream of the scoring path) ------------------------------------
  * Replaces the scan loop of the reference's adVNTR-Filtering binary (/root/reference/filtering/main.cc:
  * automaton build :56-157, per-read matching :247-283).  Keywords: concatenated base codes 0..3 with offsets
- * (lengths 1..29), kw_vntr[w] = caller's VNTR index of keyword w (the same string may belong to several VNTRs).
+ * (any length >= 1; up to four distinct lengths of <= 29 bases, longer ones share one slot: they are found through
+ * their 29-base prefix and verified on the hits), kw_vntr[w] = caller's VNTR index of keyword w (the same string may belong to several VNTRs).
  * scan(): reads as base codes 0..3, 4 = any other symbol (resets a match, main.cc:44-55); returns unordered
  * (read, vntr, count) records with count >= 1 -- a read/vntr pair may be split over several records, sum them.
  * The order-dependent selection and printing (main.cc:286-331) is host logic (advntr_amd/filtering.py).
@@ -148,6 +149,12 @@ typedef struct advntr_kwfilter advntr_kwfilter;
 advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, const int64_t *kw_off, const int32_t *kw_vntr,
                                         int32_t n_keywords);
 void advntr_kwfilter_destroy(advntr_kwfilter *filter);
+/* scan_text: the reads are spans [span_start[r], span_end[r]) of the text of a FASTA file (its sequence lines, found with
+ * advntr_line_index); the text is uploaded as it is and mapped to base codes on the device the way the reference's
+ * char_to_num does (main.cc:44-55: upper-case A,C,G,T; every other byte resets a match).                          */
+int advntr_kwfilter_scan_text(advntr_kwfilter *filter, const char *text, int64_t n_bytes, const int64_t *span_start,
+                              const int64_t *span_end, int32_t n_reads, int32_t *out_read, int32_t *out_vntr,
+                              int32_t *out_count, int64_t capacity, int64_t *n_out, float *kernel_ms);
 int advntr_kwfilter_scan(advntr_kwfilter *filter, const uint8_t *bases, const int64_t *read_off, int32_t n_reads,
                          int32_t *out_read, int32_t *out_vntr, int32_t *out_count, int64_t capacity, int64_t *n_out,
                          float *kernel_ms);
@@ -213,6 +220,16 @@ int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_
  * reference's Model.viterbi raises ValueError on those, hmm.pyx:72,79).                                          */
 int advntr_encode_ascii(const char *ascii, const int64_t *read_off, int32_t n_reads, int32_t n_threads,
                         uint8_t *out_codes, uint8_t *out_bad);
+/* The same for reads that are spans of a larger text (the sequence lines of a FASTA file): read r =
+ * ascii[span_start[r] .. span_end[r]) -> out_codes[out_off[r] .. out_off[r+1]).  ADVNTR_ENCODE_CASE_SENSITIVE: only upper-
+ * case A,C,G,T,N are symbols (what the reference's filter does, filtering/main.cc:44-55: lower case matches nothing).
+ * advntr_line_index: start offsets of the lines of a text (a final line without newline counts), for the two-line FASTA
+ * records that binary reads (main.cc:247-252); returns ADVNTR_ERR_TOO_LARGE with *n_lines set when capacity is short. */
+#define ADVNTR_ENCODE_CASE_SENSITIVE 1u
+int advntr_encode_spans(const char *ascii, const int64_t *span_start, const int64_t *span_end, int32_t n_reads,
+                        uint32_t flags, int32_t n_threads, const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
+int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_threads, int64_t *line_start, int64_t capacity,
+                      int64_t *n_lines);
 
 /* ---- genotype caller on the summary records (the step downstream of scoring; host threads, no GPU) -----------
  * Replaces, for many loci at once, the Illumina aggregation of VNTRFinder.find_repeat_count_from_alignment_file after

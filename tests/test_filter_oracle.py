@@ -9,7 +9,7 @@ import pytest
 from conftest import ROOT, load_golden
 from oracle import filter_oracle as F
 
-CASES = ["filter_small", "filter_min2", "filter_dup_id"]
+CASES = ["filter_small", "filter_min2", "filter_dup_id", "filter_long80", "filter_long_mixed"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -8,7 +8,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["filter_small", "filter_min2", "filter_dup_id"])
+@pytest.mark.parametrize("name", ["filter_small", "filter_min2", "filter_dup_id", "filter_long80", "filter_long_mixed"])
 def test_goldens_byte_for_byte(name):
     from advntr_amd import filtering
     g = load_golden(name)
@@ -68,3 +68,24 @@ def test_generator_and_consumer_view():
     fasta = ">x\n" + "CCGGTTAACCGGTTA" + "ACGTT" * 6 + "GGATCCGGATCCGGA" + "\n>y\n" + "T" * 60 + "\n"
     reads, ids = filtering.get_filtered_read_ids(fasta, {42: kws}, min_matches=3)
     assert ids[42] == {"x"} and reads == [("x", fasta.split("\n")[1])]
+
+
+def test_text_scan_equals_code_scan_and_list_api():
+    """advntr_kwfilter_scan_text (FASTA bytes uploaded as they are, mapped on the device) == advntr_kwfilter_scan on host-
+    encoded codes == the list-of-strings API, on reads with lower case, N, other symbols, empty lines and no final newline."""
+    from advntr_amd import _lib, filtering
+    g = load_golden("filter_long_mixed")
+    f = filtering.KeywordFilter.from_text(g["keywords"])
+    text = (g["fasta"] + ">odd\nACGTNNNNacgtRYK-*\n>empty\n\n>last\n" + g["fasta"].split("\n")[1]).encode()
+    starts = _lib.line_index(text)
+    ends = starts[1:] - 1
+    ends = ends.copy(); ends[-1] = len(text)
+    k = (len(starts) - 1) // 2
+    a = f.scan_text(text, starts[1:2 * k:2], ends[1:2 * k:2])
+    codes, off, _ = _lib.encode_spans(text, starts[1:2 * k:2], ends[1:2 * k:2], case_sensitive=True)
+    b = f.scan_codes(codes, off)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[0]) > 100
+    seqs = [text[starts[2 * i + 1]:ends[2 * i + 1]].decode() for i in range(k)]
+    d = f.count_matches(seqs)
+    assert sum(len(v) for v in d.values()) == len(a[0])
+    f.close()
