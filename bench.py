@@ -176,6 +176,15 @@ def main(argv=None):
     if "RANK" not in os.environ and args.gpus > 1:
         return spawn_ranks(args, argv)
 
+    # stdout carries exactly ONE line, the JSON record: anything a library prints while the bench runs (RCCL's version
+    # banner, HIP warnings) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+
     from advntr_amd import comm as comm_mod
     rank, local_rank, world = comm_mod.env_world()
     if world != args.gpus and rank == 0:
@@ -218,10 +227,10 @@ def main(argv=None):
             got = comm.allreduce_max(float(rank))
             assert got == float(world - 1), got
         if rank == 0:
-            print(json.dumps({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
-                              "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload == "c3" else "weak",
-                              "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
-                                              "comm": comm.backend if comm else None}, **plan_info)}), flush=True)
+            emit({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
+                  "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload == "c3" else "weak",
+                  "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
+                                  "comm": comm.backend if comm else None}, **plan_info)})
         if comm:
             comm.close()
         return 0
@@ -425,7 +434,7 @@ def main(argv=None):
                                              "cpu_model": cpu_model_name(),
                                              "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
                                                        "bit-equal on the sample" % (n_mt, cores)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     batch.close()
     if comm:
         comm.close()

@@ -47,7 +47,13 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                              "spanning_found": int(((score[0::2] >= 70) & (score[1::2] >= 70) & (begin[1::2] >= begin[0::2])).sum())},
                   "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                "frac": bytes_alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                               "note": "algorithmic bytes = one pass over the read per alignment; the recurrence is VALU-bound"},
+                               "note": "tier rule (HBM) only: the binding roof is int32 VALU issue, see bound_actual",
+                               "bound_actual": {"bound": "valu_int32", "unit": "DP cells/s",
+                                                "achieved": cells / (ms * 1e-3),
+                                                # 37 wave64 VALU instructions per 64-cell chunk-step at
+                                                # the nominal 2 cycles each on 1024 SIMDs at 2.4 GHz
+                                                "peak": 64.0 / (37 * 2) * 1024 * 2.4e9,
+                                                "frac": cells / (ms * 1e-3) / (64.0 / (37 * 2) * 1024 * 2.4e9)}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
                                              "unpinned); results equal to the GPU's" % n_cpu}}))

@@ -23,6 +23,42 @@ def test_restatement_hand_checked_cases():
     assert O.flank_align("TTTTACGNACGTTTTT", "ACGTACGT")[0] == 6
 
 
+def test_restatement_score_is_optimal_by_brute_force():
+    """Property check for the unpinned row: on short inputs the restatement's score equals the best local-alignment score
+    found by exhaustive search over all substring pairs (global alignment of every pair under +1 / -1 / gap -1), and the
+    reported end is a cell where that score is reached."""
+    rng = np.random.default_rng(31337)
+
+    def global_score(a, b):
+        prev = [-j for j in range(len(b) + 1)]
+        for i in range(1, len(a) + 1):
+            cur = [-i] + [0] * len(b)
+            for j in range(1, len(b) + 1):
+                cur[j] = max(prev[j - 1] + (1 if a[i - 1] == b[j - 1] and a[i - 1] != "N" else -1), prev[j] - 1, cur[j - 1] - 1)
+            prev = cur
+        return prev[len(b)]
+
+    for _ in range(60):
+        read = "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04]) for _ in range(int(rng.integers(1, 10))))
+        flank = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 8))))
+        best, ends = 0, set()
+        for i0 in range(len(read)):
+            for i1 in range(i0 + 1, len(read) + 1):
+                for j0 in range(len(flank)):
+                    for j1 in range(j0 + 1, len(flank) + 1):
+                        sc = global_score(read[i0:i1], flank[j0:j1])
+                        if sc > best:
+                            best, ends = sc, {i1 - 1}
+                        elif sc == best and sc > 0:
+                            ends.add(i1 - 1)
+        score, begin, end = O.flank_align(read, flank)
+        assert score == best, (read, flank, score, best)
+        if best > 0:
+            assert end in ends and 0 <= begin <= end + len(flank)
+        else:
+            assert (begin, end) == (-1, -1)
+
+
 def _noisy(rng, s, rate):
     out = []
     for ch in s:
