@@ -1066,6 +1066,59 @@ extern "C" int advntr_batch_fetch_paths(advntr_batch *B, int32_t *out_path, cons
     return ADVNTR_OK;
 }
 
+// One-shot call on a large batch: the host side of a batch (validation, routing sort, tile lists, uploads: 1.7 ms per
+// 100 000 reads) would sit in front of its 10 ms of kernels.  The reads are cut into up to four contiguous chunks, each a
+// batch with its own stream: chunk i+1 is prepared and uploaded while chunk i computes, and the results of a chunk are
+// downloaded while the next one still runs.  Reads are independent, so the records are the ones a single batch gives.
+static const int32_t kOneShotChunk = 16384;
+static int viterbi_batch_chunked(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases, const int64_t *read_off,
+                                 const int32_t *read_model, int32_t n_reads, double *out_logp, int32_t *out_summary,
+                                 uint32_t flags)
+{
+    if (read_off[0] != 0) return fail(ADVNTR_ERR_ARG, "batch: read_off[0] must be 0");
+    const int n_chunks = (int)std::min<int64_t>(4, n_reads / kOneShotChunk);
+    const bool both = (flags & ADVNTR_FLAG_BOTH_STRANDS) != 0;
+    std::vector<advntr_batch *> batches(n_chunks, nullptr);
+    std::vector<int32_t> first(n_chunks + 1);
+    for (int c = 0; c <= n_chunks; ++c) first[c] = (int32_t)((int64_t)n_reads * c / n_chunks);
+    int rc = ADVNTR_OK;
+    std::vector<int64_t> off;
+    for (int c = 0; c < n_chunks && rc == ADVNTR_OK; ++c) {
+        const int32_t r0 = first[c], m = first[c + 1] - r0;
+        off.resize((size_t)m + 1);
+        for (int32_t i = 0; i <= m; ++i) off[i] = read_off[r0 + i] - read_off[r0];
+        if (off[m] < 0) { rc = fail(ADVNTR_ERR_ARG, "batch: read_off not monotone"); break; }
+        batches[c] = new advntr_batch();
+        rc = batch_build(batches[c], models, n_models, bases ? bases + read_off[r0] : nullptr, off.data(), read_model + r0, m, flags);
+        if (rc == ADVNTR_OK) rc = advntr_batch_run(batches[c]);
+    }
+    std::vector<double> lp;
+    std::vector<int32_t> sm;
+    for (int c = 0; c < n_chunks && rc == ADVNTR_OK; ++c) {
+        const int32_t r0 = first[c], m = first[c + 1] - r0;
+        if (!both) {
+            rc = advntr_batch_fetch(batches[c], out_logp + r0, out_summary ? out_summary + (size_t)r0 * ADVNTR_SUMMARY_INTS : nullptr);
+        } else {            // the chunk's batch holds its forward calls, then their reverse complements
+            lp.resize((size_t)2 * m);
+            if (out_summary) sm.resize((size_t)2 * m * ADVNTR_SUMMARY_INTS);
+            rc = advntr_batch_fetch(batches[c], lp.data(), out_summary ? sm.data() : nullptr);
+            if (rc != ADVNTR_OK) break;
+            memcpy(out_logp + r0, lp.data(), (size_t)m * sizeof(double));
+            memcpy(out_logp + n_reads + r0, lp.data() + m, (size_t)m * sizeof(double));
+            if (out_summary) {
+                const size_t row = ADVNTR_SUMMARY_INTS * sizeof(int32_t);
+                memcpy(out_summary + (size_t)r0 * ADVNTR_SUMMARY_INTS, sm.data(), (size_t)m * row);
+                memcpy(out_summary + ((size_t)n_reads + r0) * ADVNTR_SUMMARY_INTS, sm.data() + (size_t)m * ADVNTR_SUMMARY_INTS, (size_t)m * row);
+            }
+        }
+    }
+    std::string keep = g_err;
+    for (advntr_batch *B : batches)
+        if (B) advntr_batch_destroy(B);
+    g_err = keep;
+    return rc;
+}
+
 extern "C" int advntr_viterbi_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
                                     const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
                                     double *out_logp, int32_t *out_summary, int32_t *out_path,
@@ -1075,6 +1128,8 @@ extern "C" int advntr_viterbi_batch(advntr_hmm *const *models, int32_t n_models,
     if ((flags & ADVNTR_FLAG_PATH) && (!out_path || !out_path_off || !out_path_len))
         return fail(ADVNTR_ERR_ARG, "advntr_viterbi_batch: ADVNTR_FLAG_PATH needs out_path/out_path_off/out_path_len");
     if (!out_summary) flags |= ADVNTR_FLAG_NO_SUMMARY;
+    if (n_reads >= 2 * kOneShotChunk && !(flags & ADVNTR_FLAG_PATH) && read_off && read_model)
+        return viterbi_batch_chunked(models, n_models, bases, read_off, read_model, n_reads, out_logp, out_summary, flags);
     advntr_batch *B = new advntr_batch();
     int rc = batch_build(B, models, n_models, bases, read_off, read_model, n_reads, flags);
     if (rc == ADVNTR_OK) rc = advntr_batch_run(B);
