@@ -188,30 +188,42 @@ extern "C" int advntr_comm_barrier(advntr_comm *C)
 }
 
 // gather-v of `count_bytes[r]` bytes from every rank r to `root`, all on C->stream (no sync): rank r's bytes start at
-// dst + sum(count_bytes[0..r))
-static int comm_gatherv(advntr_comm *C, int root, const void *src, void *dst, const int64_t *count_bytes)
+// dst + sum(count_bytes[0..r)).  comm_gatherv_post only posts the sends / receives (inside the caller's ncclGroup, so that
+// several arrays travel in ONE group = one RCCL launch per rank); comm_gatherv_own copies the root's own share.
+static int comm_gatherv_post(advntr_comm *C, int root, const void *src, void *dst, const int64_t *count_bytes)
 {
     RcclApi *api = rccl_api();
     if (C->rank == root) {
         size_t at = 0;
-        RCCL_TRY(api->GroupStart());
         for (int r = 0; r < C->world; ++r) {
             const size_t nb = (size_t)count_bytes[r];
-            if (r != root && nb) {
-                const ncclResult_t e = api->Recv((uint8_t *)dst + at, nb, ncclUint8, r, C->comm, C->stream);
-                if (e != ncclSuccess) { (void)api->GroupEnd(); RCCL_TRY(e); }
-            }
+            if (r != root && nb) RCCL_TRY(api->Recv((uint8_t *)dst + at, nb, ncclUint8, r, C->comm, C->stream));
             at += nb;
         }
-        RCCL_TRY(api->GroupEnd());
-        size_t mine_at = 0;
-        for (int r = 0; r < root; ++r) mine_at += (size_t)count_bytes[r];
-        if (count_bytes[root])
-            HIP_TRY(hipMemcpyAsync((uint8_t *)dst + mine_at, src, (size_t)count_bytes[root], hipMemcpyDeviceToDevice, C->stream));
     } else if (count_bytes[C->rank]) {
         RCCL_TRY(api->Send(src, (size_t)count_bytes[C->rank], ncclUint8, root, C->comm, C->stream));
     }
     return ADVNTR_OK;
+}
+
+static int comm_gatherv_own(advntr_comm *C, int root, const void *src, void *dst, const int64_t *count_bytes)
+{
+    if (C->rank != root || !count_bytes[root]) return ADVNTR_OK;
+    size_t mine_at = 0;
+    for (int r = 0; r < root; ++r) mine_at += (size_t)count_bytes[r];
+    HIP_TRY(hipMemcpyAsync((uint8_t *)dst + mine_at, src, (size_t)count_bytes[root], hipMemcpyDeviceToDevice, C->stream));
+    return ADVNTR_OK;
+}
+
+static int comm_gatherv(advntr_comm *C, int root, const void *src, void *dst, const int64_t *count_bytes)
+{
+    RcclApi *api = rccl_api();
+    RCCL_TRY(api->GroupStart());
+    const int rc = comm_gatherv_post(C, root, src, dst, count_bytes);
+    const ncclResult_t e = api->GroupEnd();
+    if (rc != ADVNTR_OK) return rc;
+    RCCL_TRY(e);
+    return comm_gatherv_own(C, root, src, dst, count_bytes);
 }
 
 // Start the gather of the batch's result records (as they are after the kernels queued on the batch's stream so far)
@@ -250,11 +262,21 @@ extern "C" int advntr_comm_gather_results_start(advntr_comm *C, advntr_batch *B,
     }
     HIP_TRY(hipEventRecord(C->staged, B->stream));
     HIP_TRY(hipStreamWaitEvent(C->stream, C->staged, 0));
-    std::vector<int64_t> bytes(C->world);
-    for (int r = 0; r < C->world; ++r) bytes[r] = counts[r] * (int64_t)sizeof(double);
-    if ((rc = comm_gatherv(C, root, C->d_stage_logp, C->d_all_logp, bytes.data()))) return rc;
-    for (int r = 0; r < C->world; ++r) bytes[r] = counts[r] * (int64_t)(8 * sizeof(int32_t));
-    if ((rc = comm_gatherv(C, root, C->d_stage_sum, C->d_all_sum, bytes.data()))) return rc;
+    // both arrays in one group: one RCCL launch per rank and pass
+    std::vector<int64_t> bytes_l(C->world), bytes_s(C->world);
+    for (int r = 0; r < C->world; ++r) {
+        bytes_l[r] = counts[r] * (int64_t)sizeof(double);
+        bytes_s[r] = counts[r] * (int64_t)(8 * sizeof(int32_t));
+    }
+    RcclApi *api = rccl_api();
+    RCCL_TRY(api->GroupStart());
+    rc = comm_gatherv_post(C, root, C->d_stage_logp, C->d_all_logp, bytes_l.data());
+    if (rc == ADVNTR_OK) rc = comm_gatherv_post(C, root, C->d_stage_sum, C->d_all_sum, bytes_s.data());
+    const ncclResult_t ge = api->GroupEnd();
+    if (rc != ADVNTR_OK) return rc;
+    RCCL_TRY(ge);
+    if ((rc = comm_gatherv_own(C, root, C->d_stage_logp, C->d_all_logp, bytes_l.data()))) return rc;
+    if ((rc = comm_gatherv_own(C, root, C->d_stage_sum, C->d_all_sum, bytes_s.data()))) return rc;
     C->counts.assign(counts, counts + C->world);
     C->root = root;
     C->in_flight = true;

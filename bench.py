@@ -196,12 +196,18 @@ def main(argv=None):
     entry.build()
     from advntr_amd import _lib, sharding, workloads
 
-    comm = None
-    if world > 1 or "RANK" in os.environ:
-        # (under a launcher the RCCL path is exercised even with one rank, so the gather code runs on a 1-GPU box too)
-        comm = comm_mod.init_from_env(backend="host" if args.dry_run else None, set_device=not args.dry_run)
-    elif not args.dry_run:
-        _lib.check(_lib.load().advntr_set_device(local_rank))
+    # The GPU and RCCL are touched only AFTER the synthetic reads exist: their generators fork a process pool, and a child
+    # forked from a process that holds an initialised HIP runtime and an RCCL communicator (proxy threads, shared-memory
+    # segments) must not be left to tear those down at its exit.
+    def join_job():
+        if world > 1 or "RANK" in os.environ:
+            # (under a launcher the RCCL path is exercised even with one rank, so the gather code runs on a 1-GPU box too)
+            return comm_mod.init_from_env(backend="host" if args.dry_run else None, set_device=not args.dry_run)
+        if not args.dry_run:
+            _lib.check(_lib.load().advntr_set_device(local_rank))
+        return None
+
+    comm = join_job() if args.dry_run else None
 
     # ---------------------------------------------------------------- workload
     n = 150
@@ -234,8 +240,6 @@ def main(argv=None):
         if comm:
             comm.close()
         return 0
-    _lib.require_gpu()
-
     if workload in ("c2", "c3", "c4"):
         if workload == "c4":
             loci, reads, which = workloads.make_c4(n_loci, seed=20240603 + rank, workers=host_workers)
@@ -248,6 +252,8 @@ def main(argv=None):
         t_build = time.perf_counter() - t_build
         locus = loci[0]
         bases, off = _lib.encode_reads(reads)
+        comm = join_job()
+        _lib.require_gpu()
         from advntr_amd.pomegranate import device_models
         dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
         n_reads = len(reads)
@@ -268,6 +274,8 @@ def main(argv=None):
         n_reads = args.reads
         reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, n_reads, n)
         bases, off = _lib.encode_reads(reads)
+        comm = join_job()
+        _lib.require_gpu()
         batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(n_reads, np.int32), flags=flags)
         alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
         relax_total = float(n_reads) * (n + 1) * E
