@@ -560,15 +560,15 @@ def flank_align(reads, flanks, pair_read, pair_flank):
     (score, begin, end) int32 arrays and the kernel time in ms.  Symbols outside ACGT match nothing."""
     L = load()
     require_gpu()
+    # reads: case folding + encoding on host threads (N -> 254, other symbols -> 255; the library clamps them to "matches
+    # nothing"); flanks are a few hundred bytes
+    rb, roff, _ = encode_ascii(list(reads))
     code = _CODE.copy()
     code[code == 255] = 4
-    def enc(seqs, off_dtype):
-        off = np.zeros(len(seqs) + 1, off_dtype)
-        np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)), out=off[1:])
-        raw = np.frombuffer("".join(seqs).upper().encode("latin-1", "replace"), dtype=np.uint8)
-        return np.ascontiguousarray(code[raw]), off
-    rb, roff = enc(list(reads), np.int64)
-    fb, foff = enc(list(flanks), np.int32)
+    flanks = list(flanks)
+    foff = np.zeros(len(flanks) + 1, np.int32)
+    np.cumsum(np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks)), out=foff[1:])
+    fb = np.ascontiguousarray(code[np.frombuffer("".join(flanks).upper().encode("latin-1", "replace"), dtype=np.uint8)])
     pr = np.ascontiguousarray(pair_read, np.int32)
     pf = np.ascontiguousarray(pair_flank, np.int32)
     n = len(pr)

@@ -26,21 +26,33 @@ extern "C" int advntr_flank_align(const uint8_t *bases, const int64_t *read_off,
     const int dev = current_device();
     void *d_bases = nullptr, *d_off = nullptr, *d_fb = nullptr, *d_fo = nullptr, *d_pr = nullptr, *d_pf = nullptr, *d_out = nullptr;
     hipEvent_t e0 = g_cache.get_event(dev), e1 = g_cache.get_event(dev);
+    std::vector<std::pair<void *, size_t>> held;          // buffers from the per-device cache, like a batch's
+    auto take = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *q = g_cache.get(dev, bytes, &got);
+        if (q) held.emplace_back(q, got);
+        return q;
+    };
     auto cleanup = [&]() {
-        for (void *q : {d_bases, d_off, d_fb, d_fo, d_pr, d_pf, d_out}) (void)hipFree(q);
+        for (auto &h : held) g_cache.put(dev, h.first, h.second);
         if (e0) g_cache.put_event(dev, e0);
         if (e1) g_cache.put_event(dev, e1);
     };
     int rc = [&]() -> int {
         if (!e0 || !e1) return fail(ADVNTR_ERR_DEVICE, "advntr_flank_align: event creation failed");
-        HIP_TRY(hipMalloc(&d_bases, (size_t)total + 16));
-        HIP_TRY(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
-        HIP_TRY(hipMalloc(&d_fb, (size_t)ftotal + 16));
-        HIP_TRY(hipMalloc(&d_fo, ((size_t)n_flanks + 1) * 4));
-        HIP_TRY(hipMalloc(&d_pr, (size_t)n_pairs * 4));
-        HIP_TRY(hipMalloc(&d_pf, (size_t)n_pairs * 4));
-        HIP_TRY(hipMalloc(&d_out, (size_t)n_pairs * 12));
+        d_bases = take((size_t)total + 16); d_off = take(((size_t)n_reads + 1) * 8);
+        d_fb = take((size_t)ftotal + 16); d_fo = take(((size_t)n_flanks + 1) * 4);
+        d_pr = take((size_t)n_pairs * 4); d_pf = take((size_t)n_pairs * 4); d_out = take((size_t)n_pairs * 12);
+        if (!d_bases || !d_off || !d_fb || !d_fo || !d_pr || !d_pf || !d_out)
+            return fail(ADVNTR_ERR_DEVICE, "advntr_flank_align: device allocation failed");
         if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
+        // any read code above 3 (N = 4 from this repo's hosts, 254 / 255 from advntr_encode_ascii) becomes 4: the kernel's
+        // equality test then never matches it against a flank symbol (flank N is 5 there)
+        if (total) {
+            hipLaunchKernelGGL(fa_clamp_codes_kernel, dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 65535)), dim3(256), 0,
+                               nullptr, (uint8_t *)d_bases, total);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
         if (ftotal) HIP_TRY(hipMemcpy(d_fb, flank_bases, (size_t)ftotal, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_fo, flank_off, ((size_t)n_flanks + 1) * 4, hipMemcpyHostToDevice));

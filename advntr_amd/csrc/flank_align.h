@@ -46,6 +46,15 @@ __device__ __forceinline__ int fa_shr1_from(int v, int prev_chunk)  // lane 0 <-
     return __builtin_amdgcn_update_dpp(r, v, 0x138, 0xf, 0xf, false);
 }
 
+// read codes above 3 -> 4 (in place, before the alignment kernel)
+__global__ void __launch_bounds__(256) fa_clamp_codes_kernel(uint8_t *bases, const int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4; i < n; i += (int64_t)gridDim.x * 1024)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q < n && bases[i + q] > 3) bases[i + q] = 4;
+}
+
 __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
 {
     const int lane = threadIdx.x & 63;
