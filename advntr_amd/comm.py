@@ -96,6 +96,7 @@ class FileRendezvous(object):
 class HostComm(object):
     """The communicator interface over the rendezvous directory only (no GPU involved)."""
     backend = "host"
+    fallback_reason = None
 
     def __init__(self, rdzv):
         self.rdzv, self.rank, self.world = rdzv, rdzv.rank, rdzv.world
@@ -112,6 +113,20 @@ class HostComm(object):
     def gather_bytes(self, data, root=0):
         """list of every rank's bytes on `root` (rank order), None elsewhere."""
         return self.rdzv.gather(bytes(data), root)
+
+    def gather_results(self, batch, counts, root=0):
+        """The records of a device batch to `root` through host memory and the rendezvous directory (what RcclComm does
+        device to device): (logp, summary) of all ranks in rank order on root, (None, None) elsewhere."""
+        logp, summ = batch.fetch()
+        parts = self.rdzv.gather(logp.tobytes() + summ.tobytes(), root)
+        if self.rank != root:
+            return None, None
+        lps, sms = [], []
+        for p, c in zip(parts, counts):
+            c = int(c)
+            lps.append(np.frombuffer(p[:8 * c], np.float64))
+            sms.append(np.frombuffer(p[8 * c:], np.int32).reshape(c, -1))
+        return np.concatenate(lps), np.concatenate(sms)
 
     def close(self):
         self.rdzv.close()
@@ -210,4 +225,28 @@ def init_from_env(backend=None, set_device=True):
                 raise _lib.EngineError(_lib.ERR_DEVICE, "LOCAL_RANK %d but only %d GPUs are visible" % (local, n))
             _lib.check(_lib.load().advntr_set_device(local % n))
     rdzv = FileRendezvous(rank, world)
-    return RcclComm(rdzv) if backend == "rccl" else HostComm(rdzv)
+    if backend == "host":
+        return HostComm(rdzv)
+    # RCCL, agreed on by all ranks: if the communicator cannot be created on some rank (driver / IPC configuration), every
+    # rank drops to the host communicator together instead of leaving the others waiting in a collective.  The choice is
+    # visible in `.backend` and in `.fallback_reason`; ADVNTR_COMM_FALLBACK=0 turns the fallback into an error.
+    c, err = None, b""
+    try:
+        c = RcclComm(rdzv)
+    except Exception as e:          # noqa: BLE001 -- whatever went wrong is reported, not swallowed
+        err = ("rank %d: %s" % (rank, e)).encode("utf-8", "replace")
+    failures = [x for x in rdzv.allgather(err) if x]
+    if not failures:
+        return c
+    if c is not None:
+        c._lib.load().advntr_comm_destroy(c._h)
+        c._h = None
+    reason = failures[0].decode("utf-8", "replace")
+    if os.environ.get("ADVNTR_COMM_FALLBACK", "1") == "0":
+        raise RuntimeError("RCCL communicator could not be created: " + reason)
+    import sys
+    if rank == 0:
+        sys.stderr.write("advntr_amd.comm: RCCL unavailable (%s); the result gather goes through the host communicator\n" % reason)
+    h = HostComm(rdzv)
+    h.fallback_reason = reason
+    return h

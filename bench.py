@@ -287,6 +287,10 @@ def main(argv=None):
     use_gather = comm is not None and comm.backend == "rccl"
     state = {"pending": False}
 
+    # (only when RCCL could not be set up on a multi-GPU node and comm.py fell back: the gather then goes through host
+    # memory inside the timed region, unoverlapped -- slower, but the line stays a measurement of the whole path)
+    host_gather = comm is not None and comm.backend == "host" and world > 1 and comm.fallback_reason is not None
+
     def step():
         batch.run()
         if use_gather:
@@ -294,6 +298,8 @@ def main(argv=None):
                 comm.gather_results_finish(fetch=False)
             comm.gather_results_start(batch, counts, root=0)      # queued behind this pass; the next pass overlaps it
             state["pending"] = True
+        elif host_gather:
+            state["host"] = comm.gather_results(batch, counts, root=0)
 
     def drain(fetch=False):
         out = (None, None)
@@ -323,6 +329,9 @@ def main(argv=None):
     if use_gather:
         step()
         gathered = drain(fetch=True)
+    elif host_gather:
+        step()
+        gathered = state["host"]
     # kernel-only duration, HIP events on the engine's launch stream
     kernel_ms = batch.run_timed(max(1, min(args.steps, 3)))
     logp, summ = batch.fetch()
@@ -333,7 +342,7 @@ def main(argv=None):
         parts_json = comm.gather_bytes(rec, 0)
         if rank == 0:
             per_rank = [json.loads(p) for p in parts_json]
-    if use_gather and rank == 0:
+    if (use_gather or host_gather) and rank == 0:
         at = 0                                              # rank 0's own records sit first
         assert np.array_equal(gathered[0][at:at + n_reads], logp), "RCCL gather returned different log-probabilities"
         assert np.array_equal(gathered[1][at:at + n_reads], summ), "RCCL gather returned different summaries"
@@ -400,7 +409,7 @@ def main(argv=None):
                                  "roof that actually binds this max-plus recurrence is fp64 VALU issue -> bound_actual"},
         }
         if comm:
-            out["config"]["comm"] = comm.backend
+            out["config"]["comm"] = comm.backend if comm.fallback_reason is None else "host (RCCL unavailable: %s)" % comm.fallback_reason
             out["config"]["world_size_seen_by_comm"] = comm.world
             out["config"]["per_rank"] = per_rank
         if valu_insts:
