@@ -61,7 +61,10 @@ struct ColProgram {
     int32_t n_cols, n_tclass, n_eclass, n_tail, n_sinks, end_tail, m, P;
     int32_t off_class, off_emis, off_info, off_state, off_pred0, off_tail_ptr, off_tail_state, off_tail_edge;
     int32_t off_v0, lds_bytes, off_fwd, pad1;     // off_fwd: n_cols x {fwd row-0 value of b_c, fwd entry term of M_c}
+    int32_t off_epair, n_epair, off_pair_of_col, pad2;   // emission pair table (LDS-resident, between emis and info) and the
+                                                         // pair class of every column (n_cols + 2 x uint16, read at staging)
 };
+#define COL_EPAIR_SYMBOLS 5   // A, C, G, T and the "row past the read" symbol (-inf)
 
 struct ColProgramHost {
     bool valid = false;
@@ -69,6 +72,12 @@ struct ColProgramHost {
     int32_t n_cols = 0, n_sinks = 0, m = 0, P = 0;
     std::vector<ColClass> classes;
     std::vector<double> emis;              // n_eclass * COL_EMIS_STRIDE
+    // Emission PAIR table of the row-blocked sweep: a column's match and insert emissions of one symbol side by side, symbol
+    // major -- epair[(s * n_epair + p) * 2 + {0: M, 1: I}] -- so that a lane reaches both with ONE address (per-row symbol
+    // base + per-step pair offset, a plain add) and ONE 16-byte LDS read instead of two SDWA adds and two 8-byte reads
+    std::vector<double> epair;             // COL_EPAIR_SYMBOLS * n_epair * 2
+    std::vector<uint16_t> pair_of_col;     // n_cols + 2
+    int32_t n_epair = 0;
     std::vector<ColInfo> info;             // n_cols + 2
     std::vector<ColState> state;           // n_cols + 2
     std::vector<int32_t> pred0;            // per silent state: row-0 predecessor state or -1
@@ -85,7 +94,8 @@ struct ColProgramHost {
         valid = false;
         why.clear();
         n_cols = n_sinks = m = P = 0;
-        classes.clear(); emis.clear(); info.clear(); state.clear(); pred0.clear(); v0.clear();
+        classes.clear(); emis.clear(); epair.clear(); pair_of_col.clear(); n_epair = 0;
+        info.clear(); state.clear(); pred0.clear(); v0.clear();
         tail_state.clear(); tail_ptr.clear(); tail_edges.clear();
         end_tail = -1;
         fwd.clear(); fv0.clear();
@@ -93,8 +103,8 @@ struct ColProgramHost {
 
     size_t lds_bytes() const
     {
-        return classes.size() * sizeof(ColClass) + emis.size() * sizeof(double) + info.size() * sizeof(ColInfo) +
-               state.size() * sizeof(ColState);
+        return classes.size() * sizeof(ColClass) + emis.size() * sizeof(double) + epair.size() * sizeof(double) +
+               info.size() * sizeof(ColInfo) + state.size() * sizeof(ColState);
     }
 
     std::vector<uint8_t> serialize() const
@@ -117,9 +127,11 @@ struct ColProgramHost {
         ColProgram h{};
         h.n_cols = n_cols; h.n_tclass = (int32_t)classes.size(); h.n_eclass = (int32_t)(emis.size() / COL_EMIS_STRIDE);
         h.n_tail = (int32_t)tail_state.size(); h.n_sinks = n_sinks; h.end_tail = end_tail; h.m = m; h.P = P;
-        // the four LDS-resident tables are contiguous and in this order
+        // the LDS-resident tables are contiguous and in this order
         h.off_class = add(classes.data(), classes.size() * sizeof(ColClass));
         h.off_emis = add(emis.data(), emis.size() * sizeof(double));
+        h.off_epair = add(epair.data(), epair.size() * sizeof(double));
+        h.n_epair = n_epair;
         h.off_info = add(info.data(), info.size() * sizeof(ColInfo));
         h.off_state = add(state.data(), state.size() * sizeof(ColState));
         h.lds_bytes = (int32_t)(((out.size() + 15) & ~size_t(15)) - (size_t)h.off_class);
@@ -129,6 +141,7 @@ struct ColProgramHost {
         h.off_tail_state = add(tail_state.data(), tail_state.size() * sizeof(int32_t));
         h.off_tail_edge = add(tail_edges.data(), tail_edges.size() * sizeof(TailEdge));
         h.off_fwd = add(fwd.data(), fwd.size() * sizeof(double));
+        h.off_pair_of_col = add(pair_of_col.data(), pair_of_col.size() * sizeof(uint16_t));
         memcpy(out.data(), &h, sizeof h);
     }
 };
@@ -473,6 +486,24 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         Sx = st[c];
     }
     if (out.classes.size() > 60000 || out.emis.size() / COL_EMIS_STRIDE > 60000) return fail("class table overflow");
+    {   // emission pair classes: distinct (emM, emI) combinations of the columns
+        std::map<std::pair<int, int>, int> pmap;
+        std::vector<std::pair<int, int>> pairs;
+        out.pair_of_col.resize(NC + 2);
+        for (int cc = 0; cc < NC + 2; ++cc) {
+            const std::pair<int, int> key(out.info[cc].emM, out.info[cc].emI);
+            auto it = pmap.find(key);
+            if (it == pmap.end()) { it = pmap.emplace(key, (int)pairs.size()).first; pairs.push_back(key); }
+            out.pair_of_col[cc] = (uint16_t)it->second;
+        }
+        out.n_epair = (int32_t)pairs.size();
+        out.epair.assign((size_t)COL_EPAIR_SYMBOLS * pairs.size() * 2, NINF);
+        for (int sy = 0; sy < COL_EPAIR_SYMBOLS; ++sy)
+            for (size_t q = 0; q < pairs.size(); ++q) {
+                out.epair[((size_t)sy * pairs.size() + q) * 2 + 0] = out.emis[(size_t)pairs[q].first * COL_EMIS_STRIDE + sy];
+                out.epair[((size_t)sy * pairs.size() + q) * 2 + 1] = out.emis[(size_t)pairs[q].second * COL_EMIS_STRIDE + sy];
+            }
+    }
     out.fwd.resize((size_t)NC * 2);
     for (int c = 0; c < NC; ++c) {
         out.fwd[2 * c] = out.fv0[backbone[c] - P];
@@ -482,7 +513,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     out.n_sinks = n_sinks;
     if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");
     // the sweep addresses class and emission records through 16-bit LDS addresses (tables start 16 B into LDS)
-    if (out.classes.size() * sizeof(ColClass) + out.emis.size() * sizeof(double) + 64 > 0x10000)
+    if (out.classes.size() * sizeof(ColClass) + (out.emis.size() + out.epair.size()) * sizeof(double) + 64 > 0x10000)
         return fail("class + emission tables larger than 64 KiB of LDS");
     out.valid = true;
     return true;

@@ -145,6 +145,8 @@ __device__ __forceinline__ double lse2(double x, double y)
 // an `and`/`add` instead of an unpack-multiply-add chain per table.
 typedef __attribute__((address_space(3))) const ColClass LdsClass;
 typedef __attribute__((address_space(3))) const double LdsDouble;
+typedef double adv_f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const adv_f64x2 LdsDouble2;
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
@@ -159,6 +161,7 @@ __device__ __forceinline__ uint2 lds_uint2(const unsigned addr)
 
 struct LdsTables {
     unsigned class_base, emis_base;   // LDS byte addresses of the two tables
+    unsigned epair_base, epair_sym_stride;   // emission pair table (row-blocked Viterbi sweep): base and bytes per symbol row
     unsigned fwd_lin;                 // sum-product kernel: LDS byte address of {row-0 value of b_c, entry term of M_c} per
                                       // column, in the linear domain (forward_columns.h)
     unsigned pinfo;                   // LDS byte address of the padded info copy (record c + 64K; 0 if it does not fit):
@@ -612,7 +615,9 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
 // Copy a model's class tables into LDS and build the padded info table (64*K dummy columns on either side, so a
 // lane can index it with c + 64*K without clamping; c runs from 1-64K to 64K+NC-2).  Returns whether the padded
 // copy fits.
-template <int K>
+// PAIR: the padded info records carry the column's emission PAIR offset (row-blocked Viterbi sweep) instead of the two
+// emission record addresses
+template <int K, bool PAIR = false>
 __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, uint8_t *tables, const int lds_tables,
                                             const int lds_level, LdsTables &L, const int tid)
 {
@@ -626,6 +631,8 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
     L.emis = (const double *)(tables + (cp->off_emis - cp->off_class));
     L.class_base = lds_addr(L.classes);
     L.emis_base = lds_addr(L.emis);
+    L.epair_base = lds_addr(tables + (cp->off_epair - cp->off_class));
+    L.epair_sym_stride = (unsigned)cp->n_epair * 16u;
     L.info0 = lds_level >= 1 ? (const ColInfo *)(tables + (cp->off_info - cp->off_class))
                              : (const ColInfo *)((const uint8_t *)cp + cp->off_info);
     L.pinfo = 0;
@@ -633,14 +640,16 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
                              : (const ColState *)((const uint8_t *)cp + cp->off_state);
     // (the 16-bit address fields need the class and emission tables below 64 KiB of LDS)
     const bool padded = (size_t)staged + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)lds_tables &&
-                        L.emis_base + (unsigned)cp->n_eclass * (COL_EMIS_STRIDE * 8u) <= 0x10000u;
+                        L.epair_base + (unsigned)COL_EPAIR_SYMBOLS * L.epair_sym_stride <= 0x10000u;
     if (padded) {
         __syncthreads();
         uint4 *pinfo = (uint4 *)(tables + staged);
         const int ncol = cp->n_cols;
+        const uint16_t *pair_of_col = (const uint16_t *)((const uint8_t *)cp + cp->off_pair_of_col);
         for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
             const int c = i - 64 * K;
-            const ColInfo inf = L.info0[(c >= 0 && c < ncol) ? c + 1 : 0];
+            const int ci = (c >= 0 && c < ncol) ? c + 1 : 0;
+            const ColInfo inf = L.info0[ci];
             uint4 w;
             const unsigned long long vb = (unsigned long long)__double_as_longlong(inf.v0b);
             w.x = (unsigned)vb;
@@ -648,6 +657,7 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
             w.z = (L.class_base + (unsigned)inf.tclass * (unsigned)sizeof(ColClass)) | ((unsigned)inf.flags << 16);
             w.w = (L.emis_base + (unsigned)inf.emM * (COL_EMIS_STRIDE * 8u)) |
                   ((L.emis_base + (unsigned)inf.emI * (COL_EMIS_STRIDE * 8u)) << 16);
+            if (PAIR) w.w = (unsigned)pair_of_col[ci] * 16u;            // offset inside a symbol row of the pair table
             pinfo[i] = w;
         }
         L.pinfo = lds_addr(pinfo);

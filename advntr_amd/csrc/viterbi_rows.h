@@ -92,19 +92,16 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
 {
     constexpr int W = 64 / G, WORDS = (R + 4) / 5;
     double I[R], M[R], B[R], er[R];
-    unsigned xp[(R + 3) / 4];          // byte k: 8 * base code of the lane's kth row (offset into an emission record)
-#pragma unroll
-    for (int q = 0; q < (R + 3) / 4; ++q) xp[q] = 0;
+    unsigned esym[R];                  // LDS address of the emission-pair row of the base in the lane's kth row
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         I[k] = M[k] = B[k] = er[k] = -INFINITY;
         const int t = R * lp + k + 1;
-        // rows past the read take the emission records' 5th slot, -inf: they stay at -inf in every state, so what the
+        // rows past the read take the pair table's 5th symbol row, -inf: they stay at -inf in every state, so what the
         // group's last lane hands to the next group's first (G = 2: wave_shr crosses the boundary) is the row-0 value
         // of I and M already
-        xp[k / 4] |= (unsigned)((t <= n) ? 8 * (int)seq[t - 1] : 32) << (8 * (k % 4));
+        esym[k] = L.epair_base + (unsigned)((t <= n) ? (int)seq[t - 1] : 4) * L.epair_sym_stride;
     }
-    auto xof = [&](const int k) { return (xp[k / 4] >> (8 * (k % 4))) & 0xffu; };
     // the lane that holds the read's last row, and the slot it sits in
     const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
     const bool first_lane = lp == 0 && (!TILED || row0 == 0);       // owner of the read's first row: entry edges
@@ -135,7 +132,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         const double v0b_next = *(LdsDouble *)(size_t)pa;
         LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
         const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
-        const unsigned eM0 = meta.y & 0xffffu, eI0 = meta.y >> 16;
+        const unsigned epo = meta.y;                 // this column's offset inside a symbol row of the emission pair table
         const unsigned fl = meta.x >> 16;
         const bool anysink = __ballot((fl & COL_FLAG_SINK) != 0) != 0;      // wave-uniform, rare
         // Fan-in (hmm.pyx order: the first maximum over the feeders, in column order): every row keeps the running
@@ -146,19 +143,15 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         const bool anyfeed = __ballot((fl & COL_FLAG_FEED) != 0) != 0;      // wave-uniform: false while the wave is in a flank
         int bits[WORDS];                          // comparison outcomes of the step's cells: one add-with-carry chain per word
         double *capq = rown + 3 * sstep + cap_lane;          // where this column's row-n values go (lane holding the last row)
-        // emission log-probs are fetched one cell ahead (all 2R up front costs registers: 11.6 ms instead of 11.4)
-        double eI_next = *(LdsDouble *)(size_t)(eI0 + xof(0));
-        double eM_next = *(LdsDouble *)(size_t)(eM0 + xof(0));
+        // emission log-probs {M, I} are fetched one cell ahead (all R up front costs registers), one 16-byte read per cell
+        adv_f64x2 e_next = *(LdsDouble2 *)(size_t)(esym[0] + epo);
         double dgI = nI, dgM = nM, dgB = nB;        // (t-1, c-1) of the lane's first row: shifted in at the previous step
         double upI = 0.0, upM = 0.0, upB = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int w = k / 5;
-            const double eI = eI_next, eM = eM_next;
-            if (k + 1 < R) {
-                eI_next = *(LdsDouble *)(size_t)(eI0 + xof(k + 1));
-                eM_next = *(LdsDouble *)(size_t)(eM0 + xof(k + 1));
-            }
+            const double eM = e_next.x, eI = e_next.y;
+            if (k + 1 < R) e_next = *(LdsDouble2 *)(size_t)(esym[k + 1] + epo);
             // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there.
             // Its inputs -- the previous values of the row above -- die here.
             double vM = (dgI + mI) + eM;
@@ -298,7 +291,7 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<1>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+            padded = stage_model<1, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
         const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;          // per read: padded row n + tail values
@@ -370,7 +363,7 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<1>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+            padded = stage_model<1, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
         const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;
