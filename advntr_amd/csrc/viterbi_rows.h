@@ -111,6 +111,10 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     // inputs), and only then shifts -- in place: the group-first lanes of nI / nM, which the shift never writes, hold the
     // row-0 value -inf for the whole sweep.
     double nI = -INFINITY, nM = -INFINITY, nB = -INFINITY;
+    // (untiled sweeps ping-pong between two register pairs for the shifted I / M values: a step reads the pair the previous
+    // step shifted into and shifts into the other one, whose group-first lanes also hold -inf for good -- no copy is needed
+    // to keep the diagonal inputs alive across the in-place DPP shift)
+    double qI = -INFINITY, qM = -INFINITY;
     unsigned pa = L.pinfo + (unsigned)(64 - lp) * 16u;          // padded info record of column c = -lp (64 dummies in front)
     uint2 meta = lds_uint2(pa + 8u);
     double v0b = *(LdsDouble *)(size_t)pa;
@@ -126,7 +130,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     const bool seamed = TILED && seam != nullptr;
     double wI = -INFINITY, wM = -INFINITY, wB = -INFINITY;
     const unsigned win0 = 4u * (sink_base + (unsigned)(row0 + R * lp + 1));
-    auto step = [&]() {
+    auto step = [&](double &nI, double &nM, double &qI, double &qM) {
         pa += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
         const double v0b_next = *(LdsDouble *)(size_t)pa;
@@ -174,12 +178,12 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                     nB = rows_shift<G>(B[R - 1], wB);
                     wI = rows_rol1(wI); wM = rows_rol1(wM); wB = rows_rol1(wB);
                 } else {
-                nI = rows_shift<G>(I[R - 1], nI);
-                nM = rows_shift<G>(M[R - 1], nM);
+                qI = rows_shift<G>(I[R - 1], qI);
+                qM = rows_shift<G>(M[R - 1], qM);
                 nB = rows_shift<G>(B[R - 1], v0b);               // row 0 is read independent (host precomputed)
                 }
                 if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
-                upI = nI; upM = nM; upB = nB;
+                upI = TILED && seamed ? nI : qI; upM = TILED && seamed ? nM : qM; upB = nB;
             }
             // I_c(t) <- [I_c, M_c, b_c](t-1): the values the row above just got
             double vI = (upI + iI) + eI;
@@ -230,8 +234,13 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     // two steps per loop iteration: the rotation of the loop-carried row values (a cell's old values stay live for the
     // row below while its new ones are produced) becomes register renaming instead of ~3 moves per cell
     int s = 0;
-    for (; s < s_end; s += 2) { step(); step(); }
-    if (s == s_end) step();
+    if (TILED && seamed) {              // the seam variant shifts in place (its `old` operand is the seam window)
+        for (; s < s_end; s += 2) { step(nI, nM, nI, nM); step(nI, nM, nI, nM); }
+        if (s == s_end) step(nI, nM, nI, nM);
+    } else {
+        for (; s < s_end; s += 2) { step(nI, nM, qI, qM); step(qI, qM, nI, nM); }
+        if (s == s_end) step(nI, nM, qI, qM);
+    }
 }
 
 // tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group
