@@ -1,0 +1,64 @@
+"""Host-side text helpers of the C ABI (no GPU): advntr_line_index, advntr_encode_ascii / advntr_encode_spans, and the
+builder's exp routes (numpy's own inner loop called from the worker threads vs the Python callback)."""
+import numpy as np
+import pytest
+
+from advntr_amd import _lib
+
+
+def test_line_index_equals_split():
+    rng = np.random.default_rng(4)
+    cases = [b"", b"\n", b"A", b"A\n", b"\n\nA\n\n", b">r1\nACGT\n>r2\nAC\n", b">r1\nACGT\n>r2\nAC"]
+    for _ in range(20):
+        n = int(rng.integers(0, 3000))
+        cases.append(bytes(rng.choice(np.frombuffer(b"ACGT\n\n>x", np.uint8), n).tolist()))
+    cases.append((b">name\n" + b"ACGT" * 50 + b"\n") * 40000)             # several threads' worth
+    for text in cases:
+        starts = _lib.line_index(text)
+        lines = text.split(b"\n")
+        if lines and lines[-1] == b"":
+            lines.pop()
+        assert len(starts) - 1 == len(lines), text[:40]
+        assert int(starts[-1]) == len(text)
+        at = 0
+        for i, l in enumerate(lines[:2000]):
+            assert int(starts[i]) == at
+            at += len(l) + 1
+
+
+def test_encode_ascii_and_spans():
+    seqs = ["ACGT", "acgt", "ACGNNT", "", "AC-T", "nnn", "TTTT" * 100]
+    codes, off, bad = _lib.encode_ascii(seqs)
+    assert off.tolist() == np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).tolist()
+    assert bad.tolist() == [0, 0, 1, 0, 2, 1, 0]
+    assert codes[:8].tolist() == [0, 1, 2, 3, 0, 1, 2, 3] and codes[11] == 254 and codes[off[4] + 2] == 255
+    text = b">a\nACGT\n>b\nacgN\n>c\nAC-T"
+    starts = _lib.line_index(text)
+    ends = (starts[1:] - 1).copy()
+    ends[-1] = len(text)
+    c, o, b = _lib.encode_spans(text, starts[1::2], ends[1::2], case_sensitive=True)
+    assert o.tolist() == [0, 4, 8, 12] and b.tolist() == [0, 2, 2]            # lower case is "another symbol" for the filter
+    assert c.tolist() == [0, 1, 2, 3, 255, 255, 255, 254, 0, 1, 255, 3]
+    c2, _, b2 = _lib.encode_spans(text, starts[1::2], ends[1::2], case_sensitive=False)
+    assert c2[4:8].tolist() == [0, 1, 2, 254] and b2.tolist() == [0, 1, 2]
+    with pytest.raises(_lib.EngineError):
+        _lib.check(_lib.load().advntr_encode_ascii(b"ACGT", np.array([0, 3, 2], np.int64).ctypes.data, 2, 1, None, None))
+
+
+def test_builder_exp_routes_agree():
+    """numpy.exp's inner loop located in the ufunc object and called by the worker threads == the ctypes callback around
+    numpy.exp (bit for bit); libm's exp differs in the last bit of some parameters (why the reference's route matters)."""
+    from advntr_amd import workloads
+    rng = np.random.default_rng(11)
+    loci = [workloads.make_locus(rng, int(rng.integers(20, 160)), int(rng.integers(5, 60)), int(rng.integers(2, 8)),
+                                 n_units=int(rng.integers(1, 6))) for _ in range(24)]
+    args = ([l.left for l in loci], [l.right for l in loci], [list(l.units) for l in loci], [l.copies for l in loci], 0.05)
+    by = {}
+    for route in ("numpy", "numpy-callback", "libm"):
+        built = _lib.build_read_matchers(*args, exp=route, threads=4)
+        by[route] = [b.arrays()["in_logp"] for b in built]
+    if _lib._numpy_exp_loop() is None:
+        pytest.skip("numpy's exp loop could not be located in this numpy build; the callback route is in use")
+    assert all(np.array_equal(a, b) for a, b in zip(by["numpy"], by["numpy-callback"]))
+    worst = max(float(np.max(np.abs(a - b)[np.isfinite(a)] / np.spacing(np.abs(b[np.isfinite(a)])))) for a, b in zip(by["libm"], by["numpy"]))
+    assert worst <= 4
