@@ -14,9 +14,8 @@
 //     lane is kept a padding lane whose rows stay at -inf, which is the row-0 value of I and M, and b takes one select.
 //     G = 4: a group is a DPP row of 16 lanes, `row_shr:1` never crosses groups and lanes 0/16/32/48 keep the `old`
 //     operand = the row-0 boundary, so there is no fix-up at all;
-//   * the six comparison outcomes of a cell are shifted into a running word across the lane's rows (relax_bit's
-//     add-with-carry chain simply continues into the next cell): 5 cells = 30 bits per dword, one 4-byte store per lane
-//     and step instead of one byte store per cell.
+//   * the six comparison outcomes of a cell are stored as the lane masks the comparisons produce, with scalar stores
+//     (below): no vector instruction is spent on packing back-pointers.
 //
 // Reads of a tile go G at a time to a wavefront; after the sweep the wave finishes them one by one (tail states,
 // cooperative traceback, path summary) with the code of viterbi_columns.h.
@@ -67,18 +66,49 @@ __device__ __forceinline__ double rows_rol1(const double v)          // lane i <
     return __hiloint2double(hi, lo);
 }
 
-// back-pointer byte of cell (t, c) in the row-blocked layout: R rows per lane, ceil(R/5) dwords per lane and step
+// Back-pointers of the row-blocked sweeps.  The six comparison outcomes of a cell leave the wavefront as the 64-bit LANE
+// MASKS the comparisons produce (v_cmp_gt_f64 into an SGPR pair), written with scalar stores: 48 bytes per cell of a step,
+// R cells per step, steps 256 * ceil(R / 5) bytes apart.  Shifting the outcomes into a per-lane word instead costs one
+// v_addc_co_u32 per comparison on a kernel that is bound by vector-instruction issue (SQ_INSTS_VALU per launch of the
+// bench workload 5.34 G -> 4.54 G, 10.0 -> 9.2 ms on the same box); the scalar stores issue from the scalar port.  The
+// traceback reads bit `lane` of the cell's six masks.
+typedef unsigned long long adv_u64x2 __attribute__((ext_vector_type(2)));
+// Two relaxations of one state -- if (cand > best) best = cand, strict '>' keeps the first maximum as the reference does
+// (hmm.pyx:2039,2060,2080) -- and their masks to byte offset OFF of the step's slab in one 16-byte store.
+__device__ __forceinline__ void relax_mask2(double &best, const double cand2, const double cand3, const unsigned *bps, const int OFF)
+{
+    unsigned long long m2, m3;
+    asm("v_cmp_gt_f64_e64 %1, %2, %0\n\t"
+        "v_max_f64 %0, %0, %2"
+        : "+v"(best), "=s"(m2)
+        : "v"(cand2));
+    asm("v_cmp_gt_f64_e64 %1, %2, %0\n\t"
+        "v_max_f64 %0, %0, %2"
+        : "+v"(best), "=s"(m3)
+        : "v"(cand3));
+    adv_u64x2 m;
+    m.x = m2; m.y = m3;
+    asm volatile("s_store_dwordx4 %0, %1, %2" : : "s"(m), "s"(bps), "i"(OFF) : "memory");
+}
+// Scalar stores sit in the scalar data cache until written back, and the traceback reads through the vector L1, which may
+// still hold lines of the previous reads' slab: write back, wait, invalidate.
+__device__ __forceinline__ void rows_bp_publish()
+{
+    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// back-pointer byte of cell (t, c): R rows per lane, lane lane0 + (t - 1) / R works on column c at step c + (t - 1) / R
 template <int R>
 __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc)
 {
     constexpr int WORDS = (R + 4) / 5;
     const int lp = (tt - 1) / R, k = (tt - 1) - lp * R;
-    const int w = k / 5, j = k - 5 * w;
-    const int cnt = (R - 5 * w) < 5 ? (R - 5 * w) : 5;
-    const unsigned word = bpw[((int64_t)(cc + lp) * 64 + lane0 + lp) * WORDS + w];
-    // the sweep relaxes M, then I, then b: aM bM aI bI aB bB -> the layout bp_ptr_* decode (aI bI aM bM aB bB)
-    const unsigned b = (word >> (6 * (cnt - 1 - j))) & 63u;
-    return (int)(((b << 2) & 0x30u) | ((b >> 2) & 0x0cu) | (b & 3u));
+    const int ln = lane0 + lp;
+    const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + (ln >> 5);
+    const int sh = ln & 31;
+    // masks in relaxation order aM bM aI bI aB bB -> the byte bp_ptr_* decode (aI bI aM bM aB bB)
+    const unsigned aM = cell[0] >> sh, bM = cell[2] >> sh, aI = cell[4] >> sh, bI = cell[6] >> sh, aB = cell[8] >> sh, bB = cell[10] >> sh;
+    return (int)(((aI & 1u) << 5) | ((bI & 1u) << 4) | ((aM & 1u) << 3) | ((bM & 1u) << 2) | ((aB & 1u) << 1) | (bB & 1u));
 }
 
 // TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
@@ -122,7 +152,6 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     // offsets from wave-uniform bases (scalar base + vector offset addressing, no 64-bit pointer arithmetic per step)
     // (the step index is wave-uniform: the per-step parts of these offsets are scalar arithmetic, the per-lane parts constants)
     const unsigned cap_lane = cap_base + (unsigned)(W - lp) * 3u;
-    const unsigned bp_lane = (unsigned)lane * WORDS;
     int sstep = 0;                                              // step index (scalar)
     // TILED, tiles after the first: lane l holds the seam values of column 64 * (s / 64) + ((l + s) % 64): a window of 64
     // columns, reloaded every 64 steps and rotated one lane per step (DPP wave_rol:1), so that lane 0 -- the only lane
@@ -145,68 +174,66 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         // column carry weight -inf and never win.
         const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
         const bool anyfeed = __ballot((fl & COL_FLAG_FEED) != 0) != 0;      // wave-uniform: false while the wave is in a flank
-        int bits[WORDS];                          // comparison outcomes of the step's cells: one add-with-carry chain per word
+        const unsigned *bps = bpw + (int64_t)sstep * (64 * WORDS);    // the step's back-pointer slab (scalar address)
         double *capq = rown + 3 * sstep + cap_lane;          // where this column's row-n values go (lane holding the last row)
-        // emission log-probs {M, I} are fetched one cell ahead (all R up front costs registers), one 16-byte read per cell
-        adv_f64x2 e_next = *(LdsDouble2 *)(size_t)(esym[0] + epo);
-        double dgI = nI, dgM = nM, dgB = nB;        // (t-1, c-1) of the lane's first row: shifted in at the previous step
-        double upI = 0.0, upM = 0.0, upB = 0.0;
+        // emission log-probs {M, I} of the lane's rows: one 16-byte read per cell, all requested before the first cell so
+        // that no LDS wait sits between the scalar stores of the step (they count in the same counter)
+        adv_f64x2 ev[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int w = k / 5;
-            const double eM = e_next.x, eI = e_next.y;
-            if (k + 1 < R) e_next = *(LdsDouble2 *)(size_t)(esym[k + 1] + epo);
-            // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place there.
-            // Its inputs -- the previous values of the row above -- die here.
-            double vM = (dgI + mI) + eM;
-            double cM = dgM + mM;
-            if (k == 0) cM = first_lane ? mX : cM;
-            const double cM2 = cM + eM, cM3 = (dgB + mD) + eM;
-            // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t): the lane's own previous values
-            const double oI = I[k], oM = M[k], oB = B[k];
-            double vB = oI + dI;
-            const double cB2 = oM + dM, cB3 = oB + dD;
-            if (k == 0) {
-                // row above the lane's first row, same column: the neighbouring lane's last row of the previous step
-                if (TILED && seamed) {
-                    if ((sstep & 63) == 0) {
-                        const int cw = min(sstep + lane, NC - 1) + 64;
-                        wI = seam[3 * cw]; wM = seam[3 * cw + 1]; wB = seam[3 * cw + 2];
+        for (int k = 0; k < R; ++k) ev[k] = *(LdsDouble2 *)(size_t)(esym[k] + epo);
+        {
+            double dgI = nI, dgM = nM, dgB = nB;        // (t-1, c-1) of the lane's first row: shifted in at the previous step
+            double upI = 0.0, upM = 0.0, upB = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double eM = ev[k].x, eI = ev[k].y;
+                // M_c(t) <- [I_{c-1}, M_{c-1}, X, b_{c-1}](t-1); X exists for row 1 only and takes the M candidate's place
+                // there.  Its inputs -- the previous values of the row above -- die here.
+                double vM = (dgI + mI) + eM;
+                double cM = dgM + mM;
+                if (k == 0) cM = first_lane ? mX : cM;
+                const double cM2 = cM + eM, cM3 = (dgB + mD) + eM;
+                // b_c(t) <- [I_{c-1}, M_{c-1}, b_{c-1}](t): the lane's own previous values
+                const double oI = I[k], oM = M[k], oB = B[k];
+                double vB = oI + dI;
+                const double cB2 = oM + dM, cB3 = oB + dD;
+                if (k == 0) {
+                    // row above the lane's first row, same column: the neighbouring lane's last row of the previous step
+                    if (TILED && seamed) {
+                        if ((sstep & 63) == 0) {
+                            const int cw = min(sstep + lane, NC - 1) + 64;
+                            wI = seam[3 * cw]; wM = seam[3 * cw + 1]; wB = seam[3 * cw + 2];
+                        }
+                        nI = rows_shift<G>(I[R - 1], wI);
+                        nM = rows_shift<G>(M[R - 1], wM);
+                        nB = rows_shift<G>(B[R - 1], wB);
+                        wI = rows_rol1(wI); wM = rows_rol1(wM); wB = rows_rol1(wB);
+                    } else {
+                        qI = rows_shift<G>(I[R - 1], qI);
+                        qM = rows_shift<G>(M[R - 1], qM);
+                        nB = rows_shift<G>(B[R - 1], v0b);               // row 0 is read independent (host precomputed)
                     }
-                    nI = rows_shift<G>(I[R - 1], wI);
-                    nM = rows_shift<G>(M[R - 1], wM);
-                    nB = rows_shift<G>(B[R - 1], wB);
-                    wI = rows_rol1(wI); wM = rows_rol1(wM); wB = rows_rol1(wB);
-                } else {
-                qI = rows_shift<G>(I[R - 1], qI);
-                qM = rows_shift<G>(M[R - 1], qM);
-                nB = rows_shift<G>(B[R - 1], v0b);               // row 0 is read independent (host precomputed)
+                    if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
+                    upI = TILED && seamed ? nI : qI; upM = TILED && seamed ? nM : qM; upB = nB;
                 }
-                if (G == 2) nB = fix ? *(LdsDouble *)(size_t)(pa - 16u) : nB;    // (I and M arrive as -inf from the padding lane)
-                upI = TILED && seamed ? nI : qI; upM = TILED && seamed ? nM : qM; upB = nB;
+                // I_c(t) <- [I_c, M_c, b_c](t-1): the values the row above just got
+                double vI = (upI + iI) + eI;
+                const double cI2 = (upM + iM) + eI, cI3 = (upB + iD) + eI;
+                // relaxations in the order M, I, b; the two masks of a state leave in one 16-byte scalar store
+                relax_mask2(vM, cM2, cM3, bps, 48 * k);
+                relax_mask2(vI, cI2, cI3, bps, 48 * k + 16);
+                relax_mask2(vB, cB2, cB3, bps, 48 * k + 32);
+                if (anysink) {
+                    asm volatile("; fan-in column" ::);          // keeps this a (wave-uniform) branch, not four selects per cell
+                    const bool sk = (fl & COL_FLAG_SINK) != 0;
+                    vB = sk ? er[k] : vB;
+                    er[k] = sk ? -INFINITY : er[k];
+                }
+                I[k] = vI; M[k] = vM; B[k] = vB;
+                if (kcap == k) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
+                upI = vI; upM = vM; upB = vB;
+                dgI = oI; dgM = oM; dgB = oB;
             }
-            // I_c(t) <- [I_c, M_c, b_c](t-1): the values the row above just got
-            double vI = (upI + iI) + eI;
-            const double cI2 = (upM + iM) + eI, cI3 = (upB + iD) + eI;
-            // relaxations in the order M, I, b (one carry chain; interleaving the three states or giving each its own chain
-            // measures the same)
-            if (k % 5 == 0) relax_bit_first(vM, bits[w], cM2);
-            else relax_bit(vM, bits[w], cM2);
-            relax_bit(vM, bits[w], cM3);
-            relax_bit(vI, bits[w], cI2);
-            relax_bit(vI, bits[w], cI3);
-            relax_bit(vB, bits[w], cB2);
-            relax_bit(vB, bits[w], cB3);
-            if (anysink) {
-                asm volatile("; fan-in column" ::);              // keeps this a (wave-uniform) branch, not four selects per cell
-                const bool sk = (fl & COL_FLAG_SINK) != 0;
-                vB = sk ? er[k] : vB;
-                er[k] = sk ? -INFINITY : er[k];
-            }
-            I[k] = vI; M[k] = vM; B[k] = vB;
-            if (kcap == k) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
-            upI = vI; upM = vM; upB = vB;
-            dgI = oI; dgM = oM; dgB = oB;
         }
         if (anyfeed) {                 // after the cells: the accumulators take the rows' final b values of this column
             asm volatile("; feeder column" ::);
@@ -219,13 +246,6 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 asm("v_max_f64 %0, %0, %1" : "+v"(er[k]) : "v"(cand));        // (fmax() adds two canonicalising self-maxima)
                 if (won) *(int32_t *)((char *)aux + (win + 4u * k)) = sstep - lp;      // this lane's column
             }
-        }
-        unsigned *bps = bpw + (int64_t)sstep * (64 * WORDS);    // scalar part of the address
-        if (WORDS == 1) bps[bp_lane] = (unsigned)bits[0];
-        else if (WORDS == 2) *(uint2 *)(bps + bp_lane) = make_uint2((unsigned)bits[0], (unsigned)bits[1]);
-        else {
-#pragma unroll
-            for (int w = 0; w < WORDS; ++w) bps[bp_lane + w] = (unsigned)bits[w];
         }
         ++sstep;
         meta = meta_next;
@@ -257,7 +277,7 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
     if (logp != -INFINITY) {
-        auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
+                auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
         len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
                                  1 << 30);
         len = __builtin_amdgcn_readfirstlane(len);
@@ -322,6 +342,7 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             }
             const int s_end = NC - 1 + (nmax - 1) / R;
             rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride);
+            rows_bp_publish();
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -394,6 +415,7 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
                 __threadfence_block();
                 __builtin_amdgcn_wave_barrier();
             }
+            rows_bp_publish();
             double *final_row = rown + (n_tiles & 1) * row_doubles + 3 * W;
             const double logp = col_tail(cp, final_row, tailwin, NC, lane);
             if (lane == 0) g.a.out_logp[r] = logp;
