@@ -503,7 +503,8 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 // are dominated by match->match moves, i.e. runs along a trellis diagonal: for those, the 64 lanes gather the
 // back-pointer bytes of (t-i, c-i), i = 0..63, in one round trip, a ballot gives the length of the M->M run
 // and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
-// bp_at(t, c) -> back-pointer byte of cell (t, c): the layout of the back-pointer store belongs to the sweep that wrote it
+// bp_at(t, c, st) -> back-pointer byte of cell (t, c), of which the walk uses the two bits of state st (0 = I, 1 = M, 2 = b):
+// the layout of the back-pointer store belongs to the sweep that wrote it
 template <class BpAt>
 __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                                   const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
@@ -535,7 +536,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             // diagonal gather: lane i looks at the M cell (t-i, c-i)
             const int tt = t - lane, cc = c - lane;
             const bool valid = tt >= 1 && cc >= 1;
-            const int byte = valid ? bp_at(tt, cc) : 0xff;
+            const int byte = valid ? bp_at(tt, cc, 1) : 0xff;
             const unsigned long long mm = __ballot(valid && tt > 1 && bp_ptr_M(byte) == 1);      // row 1: 1 = entry edge
             // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
@@ -562,7 +563,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             // of their length): vertical gather, lane i looks at the I cell (t-i, c)
             const int tt = t - lane;
             const bool valid = tt >= 1;
-            const int byte = valid ? bp_at(tt, c) : 0xff;
+            const int byte = valid ? bp_at(tt, c, 0) : 0xff;
             const unsigned long long ii = __ballot(valid && bp_ptr_I(byte) == 0);
             const int run = (~ii == 0ull) ? 64 : (__ffsll((long long)~ii) - 1);
             const int cells = min(run + 1, 64);
@@ -575,7 +576,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
         }
         if (lane == 0) rev[len] = cs.sB;
         ++len;
-        const int byte = bp_at(t, c);
+        const int byte = bp_at(t, c, 2);
         {
             const int p = (L.info0[c + 1].flags & COL_FLAG_SINK) ? 3 : bp_ptr_B(byte);
             if (p == 3) c = sinkbp[((L.info0[c + 1].flags >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
@@ -604,7 +605,7 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
 {
     constexpr int TPAD = 64 * K;
     // read row tt is stream row U0+tt-1; row tiles of 64K rows, slabs reused modulo `ring`
-    auto bp_at = [&](int tt, int cc) -> int {
+    auto bp_at = [&](int tt, int cc, int) -> int {
         const int u = U0 + tt - 1;
         const int tile = u / TPAD, lt = u - tile * TPAD + 1;
         return bp[(tile % ring) * slab + (int64_t)(lt + cc - 1) * TPAD + (lt - 1)];

@@ -97,18 +97,20 @@ __device__ __forceinline__ void rows_bp_publish()
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-// back-pointer byte of cell (t, c): R rows per lane, lane lane0 + (t - 1) / R works on column c at step c + (t - 1) / R
+// back-pointer bits of state st (0 = I, 1 = M, 2 = b) of cell (t, c), in the byte layout bp_ptr_* decode: R rows per lane,
+// lane lane0 + (t - 1) / R works on column c at step c + (t - 1) / R; the two masks of a state are 16 bytes of one line
 template <int R>
-__device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc)
+__device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc, const int st)
 {
     constexpr int WORDS = (R + 4) / 5;
     const int lp = (tt - 1) / R, k = (tt - 1) - lp * R;
     const int ln = lane0 + lp;
-    const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + (ln >> 5);
+    // masks of a cell in relaxation order: aM bM | aI bI | aB bB (a: the 2nd candidate won, b: the last one did)
+    const int grp = st == 1 ? 0 : (st == 0 ? 1 : 2);
+    const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + grp * 4 + (ln >> 5);
     const int sh = ln & 31;
-    // masks in relaxation order aM bM aI bI aB bB -> the byte bp_ptr_* decode (aI bI aM bM aB bB)
-    const unsigned aM = cell[0] >> sh, bM = cell[2] >> sh, aI = cell[4] >> sh, bI = cell[6] >> sh, aB = cell[8] >> sh, bB = cell[10] >> sh;
-    return (int)(((aI & 1u) << 5) | ((bI & 1u) << 4) | ((aM & 1u) << 3) | ((bM & 1u) << 2) | ((aB & 1u) << 1) | (bB & 1u));
+    const unsigned a = (cell[0] >> sh) & 1u, b = (cell[2] >> sh) & 1u;
+    return (int)((a << 1 | b) << (st == 1 ? 2 : (st == 0 ? 4 : 0)));
 }
 
 // TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
@@ -277,7 +279,7 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
     if (logp != -INFINITY) {
-                auto bp_at = [&](int tt, int cc) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc); };
+                auto bp_at = [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); };
         len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
                                  1 << 30);
         len = __builtin_amdgcn_readfirstlane(len);
@@ -421,9 +423,9 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
             if (lane == 0) g.a.out_logp[r] = logp;
             int len = 0;
             if (logp != -INFINITY) {
-                auto bp_at = [&](int tt, int cc) -> int {
+                auto bp_at = [&](int tt, int cc, int st) -> int {
                     const int tl = (tt - 1) / RT;
-                    return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc);
+                    return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc, st);
                 };
                 len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, aux + COL_MAX_TAIL, rev,
                                          g.a.path_cap, lane, 0, 1 << 30);
