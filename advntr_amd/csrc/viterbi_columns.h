@@ -467,20 +467,49 @@ __device__ __forceinline__ void col_sweep(const LdsTables &L, const bool padded,
     }
 }
 
+// The finish phase of a read (tail states, traceback) is a chain of small dependent reads of the model blob.  The blob is
+// read-only for the kernel and the addresses are wave-uniform, so they go through the scalar cache as constant-address-
+// space loads (s_load) -- as plain pointers the compiler issues a vector load and a full wait for each (cp->n_tail,
+// tptr[i], tstate[ti], edges[...], pred0[...]: 30-40 round trips per read).
+#define ADV_CONST_AS __attribute__((address_space(4)))
+struct ColFinishTables {
+    int n_cols, n_tail, end_tail;
+    const ADV_CONST_AS int32_t *tptr, *tstate, *pred0;
+    const ADV_CONST_AS TailEdge *edges_u;      // wave-uniform index
+    const TailEdge *edges;                     // lane-indexed
+};
+__device__ __forceinline__ ColFinishTables col_finish_tables(const ColProgram *__restrict__ cp)
+{
+    const unsigned long long v = (unsigned long long)cp;
+    const unsigned long long b = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    const ADV_CONST_AS ColProgram *h = (const ADV_CONST_AS ColProgram *)b;
+    ColFinishTables F;
+    F.n_cols = h->n_cols; F.n_tail = h->n_tail; F.end_tail = h->end_tail;
+    F.tptr = (const ADV_CONST_AS int32_t *)(b + (unsigned)h->off_tail_ptr);
+    F.tstate = (const ADV_CONST_AS int32_t *)(b + (unsigned)h->off_tail_state);
+    F.pred0 = (const ADV_CONST_AS int32_t *)(b + (unsigned)h->off_pred0);
+    F.edges_u = (const ADV_CONST_AS TailEdge *)(b + (unsigned)h->off_tail_edge);
+    F.edges = (const TailEdge *)(b + (unsigned)h->off_tail_edge);
+    return F;
+}
+
 // Tail states at the last row: first maximum over the reference-order in-edge list, wave-parallel.
 __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, double *__restrict__ rown,
                                            int32_t *__restrict__ tailwin, const int NC, const int lane)
 {
-    const uint8_t *base = (const uint8_t *)cp;
-    const int32_t *tptr = (const int32_t *)(base + cp->off_tail_ptr);
-    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
+    const ColFinishTables F = col_finish_tables(cp);
     double *tailv = rown + 3 * NC;
     double result = -INFINITY;
-    for (int i = 0; i < cp->n_tail; ++i) {
+    const int n_tail = F.n_tail, end_tail = F.end_tail;
+    int e1 = F.tptr[0];
+    for (int i = 0; i < n_tail; ++i) {
         double best = -INFINITY;
         int rank = 0x7fffffff;
-        for (int e = tptr[i] + lane; e < tptr[i + 1]; e += 64) {
-            const TailEdge ed = edges[e];
+        const int e0 = e1;
+        e1 = F.tptr[i + 1];
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const TailEdge ed = F.edges[e];
             const double v = ed.loc >= 0 ? rown[(ed.loc >> 2) * 3 + (ed.loc & 3)] : tailv[-ed.loc - 1];
             const double cand = v + ed.logp;
             if (cand > best) { best = cand; rank = e; }
@@ -494,7 +523,7 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
         if (lane == 0) { tailv[i] = best; tailwin[i] = rank; }
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
-        if (i == cp->end_tail) result = best;
+        if (i == end_tail) result = best;
     }
     return result;
 }
@@ -512,21 +541,18 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
                                                   int32_t *__restrict__ rev, const int cap, const int lane,
                                                   const int U0, const int W)
 {
-    const uint8_t *base = (const uint8_t *)cp;
-    const TailEdge *edges = (const TailEdge *)(base + cp->off_tail_edge);
-    const int32_t *tstate = (const int32_t *)(base + cp->off_tail_state);
-    const int32_t *pred0 = (const int32_t *)(base + cp->off_pred0);
+    const ColFinishTables F = col_finish_tables(cp);
     int len = 0;
-    int ti = cp->end_tail, t = n, c = 0, slot = 0;
+    int ti = F.end_tail, t = n, c = 0, slot = 0;
     // tail states (all in row n)
     for (;;) {
         if (len >= cap - 2) return -2;
-        if (lane == 0) rev[len] = tstate[ti];
+        if (lane == 0) rev[len] = F.tstate[ti];
         ++len;
-        const TailEdge ed = edges[tailwin[ti]];
-        if (ed.loc < 0) { ti = -ed.loc - 1; continue; }
-        c = ed.loc >> 2;
-        slot = ed.loc & 3;
+        const int loc = F.edges_u[__builtin_amdgcn_readfirstlane(tailwin[ti])].loc;
+        if (loc < 0) { ti = -loc - 1; continue; }
+        c = loc >> 2;
+        slot = loc & 3;
         break;
     }
     int s0 = -1;           // row-0 silent state to continue from
@@ -546,7 +572,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             len += cells;
             if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
-            const int lastbyte = __shfl(byte, run, 64);
+            const int lastbyte = __builtin_amdgcn_readlane(byte, run);
             int p = bp_ptr_M(lastbyte);
             if (p == 1) p = 2;                                         // only a first-row cell ends a run on pointer 1
             const ColState cs = L.state[c - run + 1];
@@ -570,16 +596,16 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             if (lane < cells) rev[len + lane] = cs.sI;
             len += cells;
             if (run >= 64) { t -= 64; continue; }
-            slot = bp_ptr_I(__shfl(byte, run, 64));                    // 1 -> M, 2 -> b of the same column
+            slot = bp_ptr_I(__builtin_amdgcn_readlane(byte, run));      // 1 -> M, 2 -> b of the same column
             t -= run + 1;
             continue;
         }
         if (lane == 0) rev[len] = cs.sB;
         ++len;
-        const int byte = bp_at(t, c, 2);
+        const int byte = __builtin_amdgcn_readfirstlane(bp_at(t, c, 2));
         {
             const int p = (L.info0[c + 1].flags & COL_FLAG_SINK) ? 3 : bp_ptr_B(byte);
-            if (p == 3) c = sinkbp[((L.info0[c + 1].flags >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1];   // fan-in winner
+            if (p == 3) c = __builtin_amdgcn_readfirstlane(sinkbp[((L.info0[c + 1].flags >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1]);   // fan-in winner
             else { c -= 1; slot = p; }
         }
     }
@@ -588,7 +614,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
         if (len >= cap - 2 || s0 < P) return -2;
         if (lane == 0) rev[len] = s0;
         ++len;
-        s0 = pred0[s0 - P];
+        s0 = F.pred0[s0 - P];
     }
     if (lane == 0) rev[len] = start_state;
     ++len;

@@ -90,12 +90,11 @@ __device__ __forceinline__ void relax_mask2(double &best, const double cand2, co
     m.x = m2; m.y = m3;
     asm volatile("s_store_dwordx4 %0, %1, %2" : : "s"(m), "s"(bps), "i"(OFF) : "memory");
 }
-// Scalar stores sit in the scalar data cache until written back, and the traceback reads through the vector L1, which may
-// still hold lines of the previous reads' slab: write back, wait, invalidate.
+// Scalar stores sit in the scalar data cache until written back; the traceback reads the masks with loads that bypass the
+// vector L1 (rows_bp_at), which may still hold lines of the previous reads' slab.
 __device__ __forceinline__ void rows_bp_publish()
 {
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // back-pointer bits of state st (0 = I, 1 = M, 2 = b) of cell (t, c), in the byte layout bp_ptr_* decode: R rows per lane,
 // lane lane0 + (t - 1) / R works on column c at step c + (t - 1) / R; the two masks of a state are 16 bytes of one line
@@ -109,7 +108,9 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     const int grp = st == 1 ? 0 : (st == 0 ? 1 : 2);
     const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + grp * 4 + (ln >> 5);
     const int sh = ln & 31;
-    const unsigned a = (cell[0] >> sh) & 1u, b = (cell[2] >> sh) & 1u;
+    // (the masks were written with scalar stores, which do not pass through the vector L1: read around it)
+    const unsigned a = (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
+    const unsigned b = (__hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
     return (int)((a << 1 | b) << (st == 1 ? 2 : (st == 0 ? 4 : 0)));
 }
 
@@ -350,9 +351,11 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
 #pragma unroll 1
             for (int q = 0; q < G; ++q) {
                 if (j + q >= tile.count) break;
-                const int rq = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j + q]);
-                const uint8_t *sq = g.a.bases + g.a.read_off[rq];
-                const int nq = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[rq + 1] - g.a.read_off[rq]));
+                // the read of group q: what its lanes loaded before the sweep
+                const int rq = __builtin_amdgcn_readlane(r, q * W), nq = __builtin_amdgcn_readlane(n, q * W);
+                const unsigned long long sa = (unsigned long long)seq;
+                const uint8_t *sq = (const uint8_t *)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(sa >> 32), q * W) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane((int)sa, q * W));
                 rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * row_doubles + 3 * W, bpw, q * W, tailwin,
                                     aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
             }
