@@ -600,13 +600,30 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             t -= run + 1;
             continue;
         }
-        if (lane == 0) rev[len] = cs.sB;
-        ++len;
-        const int byte = __builtin_amdgcn_readfirstlane(bp_at(t, c, 2));
+        // b runs (deletions, and the silent columns between repeat units: 11 of the 18 moves of a 150-base read on the bench
+        // model, in runs of three or four): horizontal gather, lane i < COL_B_RUN looks at the b cell (t, c-i) -- every cell of
+        // it is a line of its own in the back-pointer store, so the gather is kept as short as the runs are.  A fan-in sink
+        // column ends a run: its predecessor is the winner the sweep recorded, not a pointer
         {
-            const int p = (L.info0[c + 1].flags & COL_FLAG_SINK) ? 3 : bp_ptr_B(byte);
-            if (p == 3) c = __builtin_amdgcn_readfirstlane(sinkbp[((L.info0[c + 1].flags >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1]);   // fan-in winner
-            else { c -= 1; slot = p; }
+            constexpr int COL_B_RUN = 8;
+            const int cc = c - lane;
+            const bool valid = cc >= 0 && lane < COL_B_RUN;
+            const unsigned fl = valid ? L.info0[cc + 1].flags : 0u;
+            const bool sink = (fl & COL_FLAG_SINK) != 0;
+            const int byte = (valid && !sink) ? bp_at(t, cc, 2) : 0xff;
+            const unsigned long long bb = __ballot(valid && !sink && bp_ptr_B(byte) == 2) | (~0ull << COL_B_RUN);
+            const int run = (~bb == 0ull) ? COL_B_RUN : (__ffsll((long long)~bb) - 1);
+            const int cells = min(run + 1, COL_B_RUN);
+            if (lane < cells) rev[len + lane] = L.state[max(cc, 0) + 1].sB;
+            len += cells;
+            if (run >= COL_B_RUN) { c -= COL_B_RUN; continue; }
+            const unsigned flr = (unsigned)__builtin_amdgcn_readlane((int)fl, run);
+            if (flr & COL_FLAG_SINK) {
+                c = __builtin_amdgcn_readfirstlane(sinkbp[((flr >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1]);   // fan-in winner
+            } else {
+                slot = bp_ptr_B(__builtin_amdgcn_readlane(byte, run));         // 0 -> I, 1 -> M of the previous column
+                c -= run + 1;
+            }
         }
     }
     if (s0 < 0) s0 = L.state[c + 1].sB;                    // arrived in row 0 on the backbone
