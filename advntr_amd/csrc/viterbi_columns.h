@@ -701,7 +701,15 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
             w.z = (L.class_base + (unsigned)inf.tclass * (unsigned)sizeof(ColClass)) | ((unsigned)inf.flags << 16);
             w.w = (L.emis_base + (unsigned)inf.emM * (COL_EMIS_STRIDE * 8u)) |
                   ((L.emis_base + (unsigned)inf.emI * (COL_EMIS_STRIDE * 8u)) << 16);
-            if (PAIR) w.w = (unsigned)pair_of_col[ci] * 16u;            // offset inside a symbol row of the pair table
+            if (PAIR) {
+                // row-blocked Viterbi sweep: offset inside a symbol row of the pair table; the two flags the sweep tests every
+                // step sit in bytes of their own (a byte compare each): byte 2 = feeder flag | fed sink's index << 1, byte 3 =
+                // sink flag
+                w.w = (unsigned)pair_of_col[ci] * 16u;
+                w.z = (L.class_base + (unsigned)inf.tclass * (unsigned)sizeof(ColClass)) |
+                      ((inf.flags & COL_FLAG_FEED) ? (1u | (((unsigned)inf.flags >> 8) & 15u) << 1) << 16 : 0u) |
+                      ((inf.flags & COL_FLAG_SINK) ? 1u << 24 : 0u);
+            }
             pinfo[i] = w;
         }
         L.pinfo = lds_addr(pinfo);

@@ -169,14 +169,17 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
         const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
         const unsigned epo = meta.y;                 // this column's offset inside a symbol row of the emission pair table
-        const unsigned fl = meta.x >> 16;
-        const bool anysink = __ballot((fl & COL_FLAG_SINK) != 0) != 0;      // wave-uniform, rare
+        // flags of the lane's column (stage_model<1, true>): byte 3 = fan-in sink, byte 2 = feeder | fed sink's index << 1
+        const bool on_sink = (meta.x >> 24) != 0u;
+        const unsigned feedb = (meta.x >> 16) & 0xffu;
+        const bool on_feed = feedb != 0u;
+        unsigned long long sinkmask = __ballot(on_sink);                    // wave-uniform, rare
         // Fan-in (hmm.pyx order: the first maximum over the feeders, in column order): every row keeps the running
         // maximum `er`; a feeder that beats it writes its column straight into the sink's back-pointer slot of that row
         // (later winners overwrite earlier ones), so no winner register is carried.  Lanes that are not on a feeder
         // column carry weight -inf and never win.
         const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
-        const bool anyfeed = __ballot((fl & COL_FLAG_FEED) != 0) != 0;      // wave-uniform: false while the wave is in a flank
+        const bool anyfeed = __ballot(on_feed) != 0;      // wave-uniform: false while the wave is in a flank
         const unsigned *bps = bpw + (int64_t)sstep * (64 * WORDS);    // the step's back-pointer slab (scalar address)
         double *capq = rown + 3 * sstep + cap_lane;          // where this column's row-n values go (lane holding the last row)
         // emission log-probs {M, I} of the lane's rows: one 16-byte read per cell, all requested before the first cell so
@@ -226,11 +229,13 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 relax_mask2(vM, cM2, cM3, bps, 48 * k);
                 relax_mask2(vI, cI2, cI3, bps, 48 * k + 16);
                 relax_mask2(vB, cB2, cB3, bps, 48 * k + 32);
-                if (anysink) {
-                    asm volatile("; fan-in column" ::);          // keeps this a (wave-uniform) branch, not four selects per cell
-                    const bool sk = (fl & COL_FLAG_SINK) != 0;
-                    vB = sk ? er[k] : vB;
-                    er[k] = sk ? -INFINITY : er[k];
+                // a wave-uniform branch per cell, not four selects; the mask is re-tested as a scalar every time (as a bool
+                // the compiler carries the condition as a lane mask and rebuilds it with two vector instructions per cell)
+                asm volatile("" : "+s"(sinkmask));
+                if (sinkmask != 0ull) {
+                    asm volatile("; fan-in column" ::);
+                    vB = on_sink ? er[k] : vB;
+                    er[k] = on_sink ? -INFINITY : er[k];
                 }
                 I[k] = vI; M[k] = vM; B[k] = vB;
                 if (kcap == k) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
@@ -240,8 +245,8 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         }
         if (anyfeed) {                 // after the cells: the accumulators take the rows' final b values of this column
             asm volatile("; feeder column" ::);
-            const double erw = (fl & COL_FLAG_FEED) ? erw_c : -INFINITY;
-            const unsigned win = win0 + ((fl >> 8) & 15u) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
+            const double erw = on_feed ? erw_c : -INFINITY;
+            const unsigned win = win0 + (feedb >> 1) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double cand = B[k] + erw;
