@@ -817,3 +817,52 @@ def test_row_blocked_kernels_at_their_length_boundaries():
     for i in range(0, 2 * len(lens)):
         olp, opath = O.viterbi(reads[i])
         assert a[0][i] == olp and a[2][i] == opath, (i, len(reads[i]))
+
+
+@pytest.mark.parametrize("mode", ["rows", "columns"])
+def test_long_deletion_runs_in_the_traceback(mode):
+    """Reads with 9-40 consecutive bases of the locus missing (flank, inside a unit, across unit boundaries, whole units): the
+    Viterbi path crosses them in runs of delete / silent b states longer than the traceback's horizontal gather (8 cells),
+    some ending on a fan-in sink column; short reads (row-blocked kernels) and reads beyond 155 bases (tiled kernel).  Paths
+    and scores against the oracle."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(777)
+    flags = {"columns": _lib.FLAG_ANTIDIAGONAL, "rows": 0}[mode]
+    n_checked = n_long = 0
+    for trial in range(6):
+        flank = int(rng.integers(40, 90))
+        plen = int(rng.integers(8, 40))
+        copies = int(rng.integers(3, 7))
+        loc = workloads.make_locus(rng, flank, plen, copies, 0.05, n_units=int(rng.integers(1, 4)))
+        dm = loc.model.device_model()
+        assert dm.has_column_program()
+        full = loc.left + "".join(loc.units[i % len(loc.units)] for i in range(copies)) + loc.right
+        reads = []
+        for _ in range(20):
+            cut = int(rng.integers(9, 41))
+            at = int(rng.integers(5, max(6, len(full) - cut - 5)))
+            s = full[:at] + full[at + cut:]
+            lo = int(rng.integers(0, max(1, len(s) - 60)))
+            n = int(rng.integers(60, 260))
+            r = s[lo:lo + n]
+            if len(r) >= 30:
+                reads.append(r)
+        bases, off = _lib.encode_reads(reads)
+        logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags, want_paths=True)
+        a = loc.model.baked_arrays()
+        edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k]))
+                 for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+        names = [s.name for s in loc.model.states]
+        for i, r in enumerate(reads):
+            olp, opath = O.viterbi(r)
+            assert logp[i] == olp, (trial, i, len(r))
+            assert paths[i] == opath, (trial, i, len(r))
+            run = longest = 0
+            for j in opath:                      # longest run of non-emitting states on the path
+                run = run + 1 if j >= a["silent_start"] else 0
+                longest = max(longest, run)
+            n_long += longest > 8
+            n_checked += 1
+    assert n_checked >= 60 and n_long >= 10, (n_checked, n_long)      # the case this test is about did occur
