@@ -125,7 +125,7 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
 // LDS bytes of a sum-product launch whose tables take `tables` bytes: + tile slot + the linear row-0 table
 static inline size_t forward_lds_bytes(const size_t tables, const int nc_max)
 {
-    return ((tables + 15) & ~size_t(15)) + 16 + 16 * (size_t)nc_max + 16;
+    return ((tables + 15) & ~size_t(15)) + 16 + 16 * ((size_t)nc_max + 128) + 16;     // (row-blocked kernels: padded like the info table)
 }
 
 // slot: which tile list (0..3 = reads of 1..4 chunks, 4 = long reads).  The sum-product sweep works in the linear domain
