@@ -290,15 +290,16 @@ __device__ __forceinline__ void col_cell(ColRegs<K> &R, const int k, const LdsTa
         // sum-product in the LINEAR domain (forward_columns.h): the class and emission tables in LDS hold probabilities
         // (emissions times the per-row scale 16), values are probabilities times 16^row (times the tile's offset), so a
         // cell is a dozen multiply-adds instead of the fourteen exp/log calls of pair_lse folding
-        vI = ((nI * T->iI + nM * T->iM) + nB * T->iD) * eI;
-        double accM = R.pI[k] * T->mI + R.pM[k] * T->mM;
+        // (explicit fma(): the build contracts nothing by itself, -ffp-contract=off)
+        vI = fma(nB, T->iD, fma(nI, T->iI, nM * T->iM)) * eI;
+        double accM = fma(R.pI[k], T->mI, R.pM[k] * T->mM);
         if (MODE == 0 && k == 0) accM = accM + ((t == 1) ? fwd_mX : 0.0);
-        vM = (accM + R.pB[k] * T->mD) * eM;
-        vB = (R.I[k] * T->dI + R.M[k] * T->dM) + R.B[k] * T->dD;
+        vM = fma(R.pB[k], T->mD, accM) * eM;
+        vB = fma(R.B[k], T->dD, fma(R.I[k], T->dI, R.M[k] * T->dM));
         const unsigned flf = meta.x >> 16;
         if (__ballot((flf & 3u) != 0)) {
             if (flf & COL_FLAG_SINK) { vB = R.er[k]; R.er[k] = 0.0; }
-            if (flf & COL_FLAG_FEED) R.er[k] = R.er[k] + vB * T->erw;
+            if (flf & COL_FLAG_FEED) R.er[k] = fma(vB, T->erw, R.er[k]);
         }
     } else {
     // I_c(t) <- [I_c, M_c, b_c](t-1)
