@@ -19,11 +19,18 @@
 #define SC_BASE_SHIFT 8
 #define SC_BASE_VALID 0x0400
 
+// Sum over the 64 lanes, the same value returned to all of them.  DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16 lanes,
+// then row_bcast 15 / 31 across rows): the finish phase is one dependent instruction stream, and six rounds of
+// ds_bpermute + wait per sum were most of the summary's time.
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);       // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);       // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);       // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);       // row_shr:8  -> lane 15 of a row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // rev[0..len) holds the path reversed (rev[0] = model end ... rev[len-1] = model start).
