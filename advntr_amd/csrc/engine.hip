@@ -832,7 +832,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.bp_stride = (std::max(C.bp_stride, tiled_bp) + 255) & ~int64_t(255);
                 C.rown_stride = std::max<int64_t>(C.rown_stride, 2 * (3 * ((int64_t)C.nc_max + 128) + COL_MAX_TAIL));
             }
-            if (rows_groups > 1) {            // row-blocked kernels: G reads per wave, one dword per lane and step
+            if (rows_groups > 1) {            // row-blocked kernels: G reads per wave, six 64-bit lane masks per cell of a step (256 B per step at R <= 5)
                 const int64_t rows_bp = (int64_t)(C.nc_max + 33) * 64 * 4;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
                 C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * (3 * ((int64_t)C.nc_max + 64) + COL_MAX_TAIL));
