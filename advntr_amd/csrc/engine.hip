@@ -752,7 +752,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if ((rc = B->dmalloc(&B->d_path_len, (size_t)n_reads))) return rc;
     }
     const int cus = device_cus();
-    B->path_cap = B->n_max + B->m_max + 2;
+    // reversed-path scratch of a wave: the longest path any kernel accepts is the reference's own buffer, n + m entries
+    // (hmm.pyx:1953; longer paths are refused per read, col_emit_outputs); the tracebacks write up to 64 states at a time and
+    // stop 66 short of the end, hence the margin
+    B->path_cap = B->n_max + B->m_max + 2 + 66;
 
     if (B->n_col) {
         ColumnLaunch &C = B->col;

@@ -722,8 +722,11 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
 // summary record and (optionally) the path of one read, from the reversed path in `rev`
 __device__ __forceinline__ void col_emit_outputs(const ColArgs &g, const uint32_t flags, const DevModel &M, const int r,
                                                  const uint8_t *__restrict__ seq, const int n, const int32_t *__restrict__ rev,
-                                                 const int len, const int lane)
+                                                 const int len_walked, const int lane)
 {
+    // the reference's path buffer holds n + m entries (hmm.pyx:1953, written without a bound check): a longer path is
+    // refused here, the same way by every kernel
+    const int len = len_walked > n + M.m ? -2 : len_walked;
     if (g.a.out_summary && !(flags & 4u)) {
         int32_t *out = g.a.out_summary + (int64_t)r * 8;
         if (len > 0) summarize_path(rev, len, M.sclass, seq, n, out, lane);

@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(ADV_WAVE) viterbi_generic_kernel(BatchArgs a, 
                 else rev[len++] = py;
             }
             len = __shfl(len, 0, 64);
+            if (len > n + M.m) len = -2;          // beyond the reference's own path buffer (hmm.pyx:1953): refused by every kernel
         }
         __threadfence_block();
         __syncthreads();

@@ -866,3 +866,35 @@ def test_long_deletion_runs_in_the_traceback(mode):
             n_long += longest > 8
             n_checked += 1
     assert n_checked >= 60 and n_long >= 10, (n_checked, n_long)      # the case this test is about did occur
+
+
+def test_paths_near_the_reference_capacity_on_a_tiny_model():
+    """A 60-state model (flank 3, 7-bp unit) and reads of up to 400 bases: the Viterbi path loops through the unit's silent
+    states once per copy and comes within a few entries of n + m, the size of the reference's own path buffer
+    (hmm.pyx:1953).  Every kernel accepts paths of up to n + m entries and refuses longer ones the same way (length -2, no
+    summary) -- found by scripts/fuzz_kernels.py: the column kernels used to stop 66 entries early."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(1459)
+    loc = workloads.make_locus(rng, 3, 7, 1, 0.3, n_units=2)
+    dm = loc.model.device_model()
+    a = loc.model.baked_arrays()
+    m = a["m"]
+    reads = [workloads.make_reads(rng, loc, 1, int(n), locus_fraction=0.9, sub_rate=0.05)[0] for n in rng.integers(150, 400, 60)]
+    reads += [(loc.units[0] * 60)[:n] for n in (120, 155, 156, 250, 399)]          # nothing but copies of the unit
+    bases, off = _lib.encode_reads(reads)
+    which = np.zeros(len(reads), np.int32)
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k])) for l in range(m) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(m, a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    res = {name: _lib.viterbi_batch([dm], bases, off, which, flags=fl)
+           for name, fl in (("rows", 0), ("antidiagonal", _lib.FLAG_ANTIDIAGONAL), ("generic", _lib.FLAG_FORCE_GENERIC))}
+    near = 0
+    for i, r in enumerate(reads):
+        olp, opath = O.viterbi(r, path_cap=4 * (len(r) + m))
+        want_len = len(opath) if len(opath) <= len(r) + m else -2
+        near += len(opath) > len(r) + m - 66
+        for name, (logp, summ, _) in res.items():
+            assert logp[i] == olp, (name, i)
+            assert summ[i][_lib.SUM_PATH_LEN] == want_len, (name, i, len(r), len(opath), summ[i])
+        assert np.array_equal(res["rows"][1][i], res["generic"][1][i]) and np.array_equal(res["rows"][1][i], res["antidiagonal"][1][i])
+    assert near >= 3, near            # the case this test is about did occur
