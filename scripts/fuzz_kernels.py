@@ -9,6 +9,8 @@ e.build()
 from advntr_amd import _lib, workloads
 
 n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+MAX_LEN = int(os.environ.get("FUZZ_MAX_LEN", "400"))            # longest read (longer: the row-tiled kernels)
+MAX_READS = int(os.environ.get("FUZZ_MAX_READS", "400"))
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
@@ -24,8 +26,8 @@ for k in range(n_loci):
         print("locus %d has no column program" % k)
         continue
     reads = []
-    for _ in range(int(rng.integers(50, 400))):
-        n = int(rng.integers(1, 400))
+    for _ in range(int(rng.integers(min(50, MAX_READS - 1), MAX_READS))):
+        n = int(rng.integers(1, MAX_LEN))
         r = workloads.make_reads(rng, loc, 1, n, locus_fraction=0.6, sub_rate=float(rng.choice([0.0, 0.01, 0.1])))[0]
         if rng.random() < 0.3:      # homopolymer / low-complexity stretches provoke exact ties
             p = int(rng.integers(0, max(1, n - 5)))
