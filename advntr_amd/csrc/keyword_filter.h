@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define KWF_MAX_LENGTHS 4
+#define KWF_MAX_LENGTHS 8
 #define KWF_BITSET_BITS (1u << 20)          // 128 KiB of LDS: one 1024-thread workgroup per CU, two bits per keyword
 #define KWF_EMPTY 0xffffffffffffffffull
 #define KWF_SLOTS 4

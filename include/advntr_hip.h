@@ -139,7 +139,7 @@ int advntr_batch_info(const advntr_batch *batch, char *buf, int32_t capacity);
 /* ---- keyword prefilter (the stage upstream of the scoring path) ------------------------------------
  * Replaces the scan loop of the reference's adVNTR-Filtering binary (/root/reference/filtering/main.cc:
  * automaton build :56-157, per-read matching :247-283).  Keywords: concatenated base codes 0..3 with offsets
- * (any length >= 1; up to four distinct lengths of <= 29 bases, longer ones share one slot: they are found through
+ * (any length >= 1; up to eight distinct lengths of <= 29 bases, longer ones share one slot: they are found through
  * their 29-base prefix and verified on the hits), kw_vntr[w] = caller's VNTR index of keyword w (the same string may belong to several VNTRs).
  * scan(): reads as base codes 0..3, 4 = any other symbol (resets a match, main.cc:44-55); returns unordered
  * (read, vntr, count) records with count >= 1 -- a read/vntr pair may be split over several records, sum them.
