@@ -33,6 +33,10 @@ for b in range(n_batches):
     same_lp = (a[0] == g[0]) | (np.isnan(a[0]) & np.isnan(g[0]))
     assert same_lp.all(), ("logp", b, np.flatnonzero(~same_lp)[:5])
     assert np.array_equal(a[1], g[1]), ("summary", b, np.flatnonzero((a[1] != g[1]).any(1))[:5])
+    if b % 4 == 0:              # the other routes: one read per wavefront on anti-diagonals, reads packed back to back
+        for name, fl in (("anti-diagonal", _lib.FLAG_ANTIDIAGONAL), ("stream", _lib.FLAG_STREAM)):
+            o = _lib.viterbi_batch(dms, bases, off, which, flags=fl)
+            assert np.array_equal(o[0], a[0]) and np.array_equal(o[1], a[1]), (name, b)
     # both strands in one call = the forward calls followed by the calls on the reverse complements
     s2 = _lib.viterbi_batch(dms, bases, off, which, flags=_lib.FLAG_BOTH_STRANDS)
     rc = [r.translate(COMP)[::-1] for r in reads]
