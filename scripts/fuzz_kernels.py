@@ -11,12 +11,14 @@ from advntr_amd import _lib, workloads
 n_loci = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 MAX_LEN = int(os.environ.get("FUZZ_MAX_LEN", "400"))            # longest read (longer: the row-tiled kernels)
 MAX_READS = int(os.environ.get("FUZZ_MAX_READS", "400"))
+FLANK_MAX = int(os.environ.get("FUZZ_FLANK_MAX", "160"))         # wide models: column tables beyond the LDS (staging levels 1 and 0)
+FLANK_MIN = int(os.environ.get("FUZZ_FLANK_MIN", "3"))
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t0 = time.time()
 total = 0
 for k in range(n_loci):
-    flank = int(rng.integers(3, 160))
+    flank = int(rng.integers(FLANK_MIN, FLANK_MAX))
     plen = int(rng.integers(2, 80))
     copies = int(rng.integers(1, 14))
     err = float(rng.choice([0.05, 0.3, 0.1]))
