@@ -511,7 +511,15 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     }
     out.n_cols = NC;
     out.n_sinks = n_sinks;
-    if (out.lds_bytes() > 96 * 1024) return fail("column program larger than 96 KiB of LDS");
+    // What has to sit in LDS is the class / emission tables and the sweep's padded copy of the column-info table; the
+    // traceback's state table and the unpadded info table are read from the model blob when they do not fit (staging
+    // levels 1 and 0, engine.hip).  (The sum-product sweep needs 16 B per column more; advntr_forward_batch says so when a
+    // model is too wide for it.)
+    {
+        const size_t tables = out.classes.size() * sizeof(ColClass) + (out.emis.size() + out.epair.size()) * sizeof(double);
+        if (tables + (size_t)(NC + 128 * 4) * sizeof(ColInfo) > 150 * 1024)
+            return fail("column program larger than the LDS of a CU (class / emission tables + 16 B per column)");
+    }
     // the sweep addresses class and emission records through 16-bit LDS addresses (tables start 16 B into LDS)
     if (out.classes.size() * sizeof(ColClass) + (out.emis.size() + out.epair.size()) * sizeof(double) + 64 > 0x10000)
         return fail("class + emission tables larger than 64 KiB of LDS");

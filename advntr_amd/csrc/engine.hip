@@ -778,6 +778,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         C.lds_core_bytes = lds_core; C.lds_min_bytes = lds_min;
         if (wgs(lds_core) > wgs(C.lds_bytes)) { C.lds_bytes = lds_core; C.lds_level = 1; }
         if (wgs(lds_min) > wgs(C.lds_bytes)) { C.lds_bytes = lds_min; C.lds_level = 0; }
+        // (one workgroup per CU either way: still take the level that fits at all)
+        if (C.lds_bytes + 16 > 160 * 1024 && C.lds_level > 1 && lds_core + 16 <= 160 * 1024) { C.lds_bytes = lds_core; C.lds_level = 1; }
+        if (C.lds_bytes + 16 > 160 * 1024 && C.lds_level > 0) { C.lds_bytes = lds_min; C.lds_level = 0; }
         if (C.lds_bytes + 16 > 160 * 1024)
             return fail(ADVNTR_ERR_TOO_LARGE, "batch: the class / emission tables of a %d-column model take %zu B of LDS "
                         "(> 160 KiB per CU)", C.nc_max, C.lds_bytes + 16);

@@ -40,7 +40,19 @@ for k in range(n_loci):
     which = np.zeros(len(reads), np.int32)
     want_paths = (k % 5 == 0)
     a = _lib.viterbi_batch([dm], bases, off, which, want_paths=want_paths)
-    b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=want_paths)
+    arr = loc.model.baked_arrays()
+    wide = arr["m"] > 10240                     # beyond the generic kernel (its trellis rows sit in LDS): the CPU oracle on a few reads
+    if wide:
+        from oracle.oracle import OracleModel
+        edges = [(int(arr["in_src"][e2]), l, float(arr["in_logp"][e2])) for l in range(arr["m"]) for e2 in range(arr["in_ptr"][l], arr["in_ptr"][l + 1])]
+        O = OracleModel(arr["m"], arr["silent_start"], arr["start_index"], arr["end_index"], edges, arr["emis_logp"])
+        ap = _lib.viterbi_batch([dm], bases, off, which, want_paths=True)
+        for i in range(min(3, len(reads))):
+            olp, opath = O.viterbi(reads[i])
+            assert ap[0][i] == olp and ap[2][i] == opath, ("wide model vs oracle", k, i, arr["m"])
+        b = a
+    else:
+        b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=want_paths)
     c = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_STREAM)
     d = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL, want_paths=want_paths)
     assert np.array_equal(a[0], d[0]), ("rows vs anti-diagonal logp", k, flank, plen, copies, err,

@@ -898,3 +898,31 @@ def test_paths_near_the_reference_capacity_on_a_tiny_model():
             assert summ[i][_lib.SUM_PATH_LEN] == want_len, (name, i, len(r), len(opath), summ[i])
         assert np.array_equal(res["rows"][1][i], res["generic"][1][i]) and np.array_equal(res["rows"][1][i], res["antidiagonal"][1][i])
     assert near >= 3, near            # the case this test is about did occur
+
+
+def test_very_wide_model_runs_from_the_lowest_lds_staging_level():
+    """A locus with 2 000-base flanks: 4 000+ columns, 12 000+ states.  Only the class / emission tables and the sweep's
+    padded info copy fit in LDS (staging level 0: the traceback reads the state and info tables from the model blob); the
+    generic kernel cannot take the model at all (its trellis rows sit in LDS).  Scores and paths against the oracle, short
+    reads (row-blocked kernels) and long ones (row tiles), and the anti-diagonal route against the default one."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(2000)
+    loc = workloads.make_locus(rng, 2000, 25, 6, 0.05, n_units=2)
+    dm = loc.model.device_model()
+    assert dm.has_column_program()
+    a = loc.model.baked_arrays()
+    assert a["m"] > 10240
+    reads = [workloads.make_reads(rng, loc, 1, int(n), locus_fraction=1.0, sub_rate=0.03)[0] for n in (1, 40, 100, 150, 155, 156, 300, 700)]
+    bases, off = _lib.encode_reads(reads)
+    which = np.zeros(len(reads), np.int32)
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, which, want_paths=True)
+    alt = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL, want_paths=True)
+    assert np.array_equal(alt[0], logp) and np.array_equal(alt[1], summ) and alt[2] == paths
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k])) for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    for i, r in enumerate(reads):
+        olp, opath = O.viterbi(r)
+        assert logp[i] == olp and paths[i] == opath, (i, len(r))
+    with pytest.raises(_lib.EngineError):
+        _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC)
