@@ -111,20 +111,23 @@ __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
 #pragma unroll
             for (int k = 0; k < FA_K; ++k) { H[k] = nH[k]; S[k] = nS[k]; }
         }
-        // best cell of the wave: score, then read position, then flank position
-        int sc = 0, ei = -1, ej = -1, st = 0;
+        // best cell of the wave: score, then read position, then flank position -- the last best cell in row-major order.
+        // Position and column travel as ONE key ((read position + 1) << 8 | flank position: reads of up to 8 M bases): with
+        // the two as separate variables the compiler (ROCm 7.2) dropped the update of the read position in the per-lane
+        // step when the second chunk won, and a flank longer than 64 bases whose best cells tie across the chunks got the
+        // first chunk's cell (found by scripts/fuzz_flank_align.py)
+        int sc = 0, key = 0, st = 0;
 #pragma unroll
         for (int k = 0; k < FA_K; ++k) {
-            const int j = 64 * k + lane;
-            if (best[k] > sc || (best[k] == sc && best[k] > 0 && (bi[k] > ei || (bi[k] == ei && j > ej)))) {
-                sc = best[k]; ei = bi[k]; ej = j; st = bS[k];
-            }
+            const int kk = ((bi[k] + 1) << 8) | (64 * k + lane);
+            if (best[k] > sc || (best[k] == sc && best[k] > 0 && kk > key)) { sc = best[k]; key = kk; st = bS[k]; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const int osc = __shfl_xor(sc, o, 64), oei = __shfl_xor(ei, o, 64), oej = __shfl_xor(ej, o, 64), ost = __shfl_xor(st, o, 64);
-            if (osc > sc || (osc == sc && osc > 0 && (oei > ei || (oei == ei && oej > ej)))) { sc = osc; ei = oei; ej = oej; st = ost; }
+            const int osc = __shfl_xor(sc, o, 64), okey = __shfl_xor(key, o, 64), ost = __shfl_xor(st, o, 64);
+            if (osc > sc || (osc == sc && osc > 0 && okey > key)) { sc = osc; key = okey; st = ost; }
         }
+        const int ei = sc > 0 ? (key >> 8) - 1 : -1;
         if (lane == 0) {
             a.out_score[p] = sc;
             a.out_begin[p] = sc > 0 ? max(st >> 8, st & 0xff) : -1;

@@ -181,3 +181,21 @@ def test_cli_pacbio_from_whole_long_reads(tmp_path):
                           str(tmp_path / "reads.fa"), "--pacbio", "--extract-spanning"], cwd=ROOT, stdout=subprocess.PIPE,
                          check=True).stdout.decode()
     assert out == "9\n6/9\n"
+
+
+@pytest.mark.gpu
+def test_best_cells_tying_across_the_two_flank_chunks():
+    """A low-complexity flank of more than 64 bases whose best cells tie in one row of the read, some in the first 64 columns
+    and some beyond: the last one in row-major order ends the alignment (found by scripts/fuzz_flank_align.py -- the
+    per-lane step of the reduction used to keep the first chunk's cell)."""
+    from advntr_amd import _lib
+    read = "ATGTGGTTGTGTGTATTTACCCTGGGACTAAAAACCCGGCTTTCTCCAGATCAAAAGAAGGATT"
+    flank = "CTAG" * 18
+    reads = [read, read + "ACGTTGCA", "GG" + read]
+    flanks = [flank[:n] for n in (60, 64, 65, 67, 70, 71)]
+    pr = [r for r in range(len(reads)) for _ in flanks]
+    pf = [f for _ in reads for f in range(len(flanks))]
+    score, begin, end, _ = _lib.flank_align(reads, flanks, pr, pf)
+    for p in range(len(pr)):
+        assert (int(score[p]), int(begin[p]), int(end[p])) == O.flank_align(reads[pr[p]], flanks[pf[p]]), (pr[p], len(flanks[pf[p]]))
+    assert O.flank_align(read, flank[:71]) == (3, 55, 52)
