@@ -44,5 +44,11 @@ for b in range(n_batches):
     r2 = _lib.viterbi_batch(dms, rb, ro, which)
     assert np.array_equal(s2[0][:n_reads], a[0]) and np.array_equal(s2[1][:n_reads], a[1]), ("both strands, forward half", b)
     assert np.array_equal(s2[0][n_reads:], r2[0]) and np.array_equal(s2[1][n_reads:], r2[1]), ("both strands, reverse half", b)
+    if b % 10 == 0 and n_reads <= 400 and max_len <= 400:      # log_probability on the same mixed batch (the generic kernel is slow)
+        fa = _lib.forward_batch(dms, bases, off, which)
+        fg = _lib.forward_batch(dms, bases, off, which, flags=_lib.FLAG_FORCE_GENERIC)
+        okf = (np.abs(fa - fg) <= 1e-9 * np.maximum(1.0, np.abs(fg))) | (np.isinf(fa) & np.isinf(fg))
+        assert okf.all(), ("forward", b, np.flatnonzero(~okf)[:5])
+        assert np.all(fa >= a[0] - 1e-9), ("forward below viterbi", b)
     total += n_reads
 print("batch fuzz ok: %d batches, %d reads, %.1f s" % (n_batches, total, time.time() - t0))
