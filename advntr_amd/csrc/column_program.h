@@ -31,7 +31,7 @@
 #define COL_FLAG_SINK 2u      // b_c := accumulator (fan-in from earlier backbone states)
 #define COL_MAX_SINKS 4
 #define COL_MAX_READ 256      // rows handled in registers: 4 chunks of 64 lanes (one row tile)
-#define COL_MAX_LONG_READ 65536  // longer reads are row-tiled: 256 rows per tile with a seam row in HBM
+#define COL_MAX_LONG_READ (1 << 20)  // longer reads are row-tiled: 256 rows per tile with a seam row in HBM
 
 struct ColClass {             // 11 doubles = 88 B: an odd multiple of 8 B, so records that differ by less than 32
                               // classes never share an LDS bank at the same field (64 banks x 4 B for ds_read_b64)

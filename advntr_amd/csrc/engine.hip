@@ -392,7 +392,7 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
     }
 
     // the generic kernel's tables are three quarters of a read matcher's device data and are only needed when a read
-    // cannot take the column kernel (forced, or longer than 65 536 bases): models with a column program upload them on
+    // cannot take the column kernel (forced, or longer than COL_MAX_LONG_READ): models with a column program upload them on
     // first use (hmm_ensure_generic), generic-only models carry them from the start
     BlobBuilder &B = tls_blob();
     B.bytes.clear();

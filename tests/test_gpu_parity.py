@@ -926,3 +926,26 @@ def test_very_wide_model_runs_from_the_lowest_lds_staging_level():
         assert logp[i] == olp and paths[i] == opath, (i, len(r))
     with pytest.raises(_lib.EngineError):
         _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC)
+
+
+def test_reads_of_a_hundred_thousand_bases():
+    """Reads far beyond the old 65 536-base bound of the row-tiled kernel (ultra-long nanopore reads): scores and paths
+    against the oracle."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(5)
+    loc = workloads.make_locus(rng, 60, 20, 5, 0.3, n_units=2)
+    dm = loc.model.device_model()
+    a = loc.model.baked_arrays()
+    edges = [(int(a["in_src"][k]), l, float(a["in_logp"][k])) for l in range(a["m"]) for k in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+    O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+    unit = loc.units[0]
+    reads = []
+    for n in (65537, 100000):
+        body = (loc.left + unit * (n // len(unit) + 1))[:n - 60] + loc.right
+        reads.append("".join(c if rng.random() > 0.1 else "ACGT"[int(rng.integers(0, 4))] for c in body))
+    bases, off = _lib.encode_reads(reads)
+    logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), want_paths=True)
+    for i, r in enumerate(reads):
+        olp, opath = O.viterbi(r, path_cap=4 * (len(r) + a["m"]))
+        assert logp[i] == olp and paths[i] == opath, (i, len(r))
