@@ -20,6 +20,7 @@ struct ColumnLaunch {
     int64_t bp_stride = 0, rown_stride = 0, aux_stride = 0;
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
+    int rows_depth = 1;                     // reads per lane group of the deepest row-blocked tile
     std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,
                                             // [8] = row-blocked kernel for reads of more than 155 bases (row tiles)
     ColTile *d_tiles[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -69,11 +70,12 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
+    g.rows_depth = cl.rows_depth;
     const int grid = std::min(cl.grid, g.n_tiles);
-    if (cl.lds_bytes + 16 > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(cl.lds_bytes + 16));
-    hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), cl.lds_bytes + 16, stream, g, flags);
+    const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
 }
 
 // reads of more than 155 bases, one per wavefront, row tiles of 64 * ROWS_LONG_R rows (viterbi_rows.h); tile list 8

@@ -395,6 +395,15 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
             }
         }
     }
+    // Column 0 takes nothing from a previous column (no match-like state, backbone state without in-edges in rows >= 1).  The
+    // back-to-back sweeps of viterbi_rows.h rely on it: a lane that starts column 0 of its next read still holds the last
+    // column's values of the previous one, and these -inf transitions are what keeps them out.
+    {
+        const ColClass &T0 = percol[0];
+        if (T0.mI != NINF || T0.mM != NINF || T0.mX != NINF || T0.mD != NINF || T0.dI != NINF || T0.dM != NINF || T0.dD != NINF ||
+            (flags[0] & COL_FLAG_SINK))
+            return fail("column 0 has a predecessor column");
+    }
     // feeds and sinks must not interleave: between a feeder and its sink there is no other sink, and no
     // feeder of a different sink
     {

@@ -774,14 +774,14 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         // workgroups per CU are bounded by LDS (4 waves each; 1 workgroup per CU = 1 wave per SIMD): wide models (PacBio:
         // > 1000 columns) leave the traceback's state table, then the unpadded column-info table, in HBM/L2 when
         // that buys another resident workgroup
-        auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + 1024))); };
+        auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + ROWS_STASH_BYTES + 1024))); };
         C.lds_core_bytes = lds_core; C.lds_min_bytes = lds_min;
         if (wgs(lds_core) > wgs(C.lds_bytes)) { C.lds_bytes = lds_core; C.lds_level = 1; }
         if (wgs(lds_min) > wgs(C.lds_bytes)) { C.lds_bytes = lds_min; C.lds_level = 0; }
         // (one workgroup per CU either way: still take the level that fits at all)
-        if (C.lds_bytes + 16 > 160 * 1024 && C.lds_level > 1 && lds_core + 16 <= 160 * 1024) { C.lds_bytes = lds_core; C.lds_level = 1; }
-        if (C.lds_bytes + 16 > 160 * 1024 && C.lds_level > 0) { C.lds_bytes = lds_min; C.lds_level = 0; }
-        if (C.lds_bytes + 16 > 160 * 1024)
+        if (C.lds_bytes + 16 + ROWS_STASH_BYTES > 160 * 1024 && C.lds_level > 1 && lds_core + 16 + ROWS_STASH_BYTES <= 160 * 1024) { C.lds_bytes = lds_core; C.lds_level = 1; }
+        if (C.lds_bytes + 16 + ROWS_STASH_BYTES > 160 * 1024 && C.lds_level > 0) { C.lds_bytes = lds_min; C.lds_level = 0; }
+        if (C.lds_bytes + 16 + ROWS_STASH_BYTES > 160 * 1024)
             return fail(ADVNTR_ERR_TOO_LARGE, "batch: the class / emission tables of a %d-column model take %zu B of LDS "
                         "(> 160 KiB per CU)", C.nc_max, C.lds_bytes + 16);
         int per_cu = wgs(C.lds_bytes);
@@ -815,10 +815,21 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
-                if (bucket < 3) {                                  // G reads per wavefront
-                    const int G = rows_configs[bucket].G;
-                    cap = std::max<int>(COL_WAVES * G, cap * G / 2);
+                if (bucket < 3) {
+                    // G reads per wavefront side by side and up to ROWS_DEPTH one behind the other (back-to-back sweeps,
+                    // viterbi_rows.h): full-depth tiles while most of the batch is still ahead, then half depth, then
+                    // single sweeps, so that the dynamic dequeue still ends evenly across the CUs
+                    const int G = rows_configs[bucket].G, round = COL_WAVES * G;
+                    const int nc = B->models[mod]->colprog.n_cols;
+                    int depth = nc >= ROWS_STREAM_MIN_COLS ? ROWS_DEPTH : 1;
+                    if (!(flags & ADVNTR_FLAG_DEEP_TILES)) {
+                        depth = std::max(1, std::min(depth, B->n_col / std::max(1, cus * per_cu * round)));
+                        if (left <= B->n_col * ROWS_TAIL_HALF_PCT / 100) depth = std::min(depth, std::max(1, ROWS_DEPTH / 2));
+                        if (left <= B->n_col * ROWS_TAIL_SINGLE_PCT / 100) depth = 1;
+                    }
+                    cap = round * depth;
                     rows_groups = std::max(rows_groups, G);
+                    C.rows_depth = std::max(C.rows_depth, depth);
                 }
                 int j = i;
                 while (j < B->n_col && j - i < cap && kof(col_reads[j]) == bucket && read_model[col_reads[j]] == mod) ++j;
@@ -838,10 +849,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.bp_stride = (std::max(C.bp_stride, tiled_bp) + 255) & ~int64_t(255);
                 C.rown_stride = std::max<int64_t>(C.rown_stride, 2 * (3 * ((int64_t)C.nc_max + 128) + COL_MAX_TAIL));
             }
-            if (rows_groups > 1) {            // row-blocked kernels: G reads per wave, six 64-bit lane masks per cell of a step (256 B per step at R <= 5)
-                const int64_t rows_bp = (int64_t)(C.nc_max + 33) * 64 * 4;
+            if (rows_groups > 1) {            // row-blocked kernels: G reads per wave side by side, ROWS_DEPTH one behind the other; six 64-bit lane masks per cell of a step (256 B per step at R <= 5)
+                const int64_t rows_bp = ((int64_t)C.rows_depth * C.nc_max + 33) * 64 * 4;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
-                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * (3 * ((int64_t)C.nc_max + 64) + COL_MAX_TAIL));
+                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64) + COL_MAX_TAIL);
             }
         }
         size_t n_tiles = 0;
@@ -853,7 +864,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
         const int64_t bp_budget = (int64_t)(free_b / 10 * 6) + (int64_t)g_cache.cached[B->device];
         while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > bp_budget) C.grid = (C.grid + 1) / 2;
-        C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * COL_MAX_SINKS * C.sink_stride;
+        C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * (rows_groups > 1 ? C.rows_depth + 1 : 1) * COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;

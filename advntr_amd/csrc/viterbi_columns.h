@@ -65,6 +65,7 @@ struct ColArgs {
     int32_t lds_tables;      // bytes of LDS reserved for the tables
     int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
     int32_t ring;            // stream kernel: back-pointer slabs per wave (row tiles kept for the traceback)
+    int32_t rows_depth;      // row-blocked kernels: reads per lane group of the deepest tile (back-to-back sweeps, viterbi_rows.h)
     int32_t lds_level;       // which tables of the column program are staged in LDS: 2 = all; 1 = all but the traceback's
                              // column->state table; 0 = only classes and emissions (+ the padded info copy the sweep
                              // indexes).  The rest is read from the model blob in HBM/L2, which leaves room for more
@@ -496,11 +497,13 @@ __device__ __forceinline__ ColFinishTables col_finish_tables(const ColProgram *_
 }
 
 // Tail states at the last row: first maximum over the reference-order in-edge list, wave-parallel.
+// (tail values go to `tailv`; by default right behind the row)
 __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, double *__restrict__ rown,
-                                           int32_t *__restrict__ tailwin, const int NC, const int lane)
+                                           int32_t *__restrict__ tailwin, const int NC, const int lane,
+                                           double *__restrict__ tailv = nullptr)
 {
     const ColFinishTables F = col_finish_tables(cp);
-    double *tailv = rown + 3 * NC;
+    if (tailv == nullptr) tailv = rown + 3 * NC;
     double result = -INFINITY;
     const int n_tail = F.n_tail, end_tail = F.end_tail;
     int e1 = F.tptr[0];
@@ -540,7 +543,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
                                                   const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
                                                   const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
                                                   int32_t *__restrict__ rev, const int cap, const int lane,
-                                                  const int U0, const int W)
+                                                  const int U0, const int W, const int sink_col0 = 0)
 {
     const ColFinishTables F = col_finish_tables(cp);
     int len = 0;
@@ -620,7 +623,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             if (run >= COL_B_RUN) { c -= COL_B_RUN; continue; }
             const unsigned flr = (unsigned)__builtin_amdgcn_readlane((int)fl, run);
             if (flr & COL_FLAG_SINK) {
-                c = __builtin_amdgcn_readfirstlane(sinkbp[((flr >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1]);   // fan-in winner
+                c = __builtin_amdgcn_readfirstlane(sinkbp[((flr >> 4) & 15) * sink_stride + ((U0 + t - 1) % W) + 1]) - sink_col0;   // fan-in winner
             } else {
                 slot = bp_ptr_B(__builtin_amdgcn_readlane(byte, run));         // 0 -> I, 1 -> M of the previous column
                 c -= run + 1;
@@ -662,7 +665,9 @@ __device__ __forceinline__ int col_traceback(const ColProgram *__restrict__ cp, 
 // copy fits.
 // PAIR: the padded info records carry the column's emission PAIR offset (row-blocked Viterbi sweep) instead of the two
 // emission record addresses
-template <int K, bool PAIR = false>
+// WRAPCOPY: the 33 records behind the last column repeat columns 0 .. 32 instead of being dummies (back-to-back sweeps of
+// viterbi_rows.h: a lane that has done the last column of a read walks straight on into column 0 of the next one)
+template <int K, bool PAIR = false, bool WRAPCOPY = false>
 __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, uint8_t *tables, const int lds_tables,
                                             const int lds_level, LdsTables &L, const int tid)
 {
@@ -693,7 +698,8 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
         const uint16_t *pair_of_col = (const uint16_t *)((const uint8_t *)cp + cp->off_pair_of_col);
         for (int i = tid; i < ncol + 128 * K; i += COL_WAVES * 64) {
             const int c = i - 64 * K;
-            const int ci = (c >= 0 && c < ncol) ? c + 1 : 0;
+            int ci = (c >= 0 && c < ncol) ? c + 1 : 0;
+            if (WRAPCOPY && c >= ncol && c - ncol <= 32 && c - ncol < ncol) ci = c - ncol + 1;
             const ColInfo inf = L.info0[ci];
             uint4 w;
             const unsigned long long vb = (unsigned long long)__double_as_longlong(inf.v0b);

@@ -20,6 +20,7 @@
 // Reads of a tile go G at a time to a wavefront; after the sweep the wave finishes them one by one (tail states,
 // cooperative traceback, path summary) with the code of viterbi_columns.h.
 #pragma once
+#include <type_traits>
 #include "viterbi_columns.h"
 
 // Three instantiations cover the short reads of a large batch (engine.hip routes by length):
@@ -40,6 +41,24 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 #endif
 #define ROWS_MAX_READ 155           // longest read any configuration takes
 #define ROWS_MAX_GROUPS 4
+#define ROWS_STASH_BYTES (COL_WAVES * ROWS_DEPTH * ROWS_MAX_GROUPS * 16)     // LDS behind the tables (viterbi_rows_kernel)
+// Back-to-back sweeps: a wavefront's lane groups take up to ROWS_DEPTH reads each, one behind the other ALONG THE STEP AXIS.
+// When a lane has done the last column of its group's kth read it starts column 0 of read k + 1 on the next step -- the
+// neighbouring lanes follow one step later each, exactly as at the start of a sweep -- so the W - 1 steps a sweep spends
+// filling and draining its pipeline are paid once per ROWS_DEPTH reads instead of once per read (REF150, 453 columns: 6 %
+// of the steps; the 99 columns of the metric's ~300-state shape: 23 %).  A lane's rows of the queued reads wait packed in
+// one 64-bit register (3 bits per row + 3 bits for the slot of the read's last row): nothing else is carried.
+#ifndef ROWS_DEPTH
+#define ROWS_DEPTH 4
+#endif
+#define ROWS_STREAM_MIN_COLS 64      // narrower models sweep their reads one at a time (the wrap window must not lap itself)
+// tile sizes (engine.hip): full depth until this share of a batch's reads is left, then half depth, then single sweeps
+#ifndef ROWS_TAIL_HALF_PCT
+#define ROWS_TAIL_HALF_PCT 25
+#endif
+#ifndef ROWS_TAIL_SINGLE_PCT
+#define ROWS_TAIL_SINGLE_PCT 10
+#endif
 #ifndef ROWS_LONG_R
 #define ROWS_LONG_R 4                // rows per lane of the tiled kernel for longer reads: row tiles of 256 rows
 #endif
@@ -116,14 +135,19 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
 
 // TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
 // the first) is the previous tile's last row, captured at seam[3 * (c + 64) + {0, 1, 2}], and takes the place of row 0.
+// `queue`, `depth` (untiled sweeps): the lane's rows of the reads that follow the first one back to back (rows_queue_push),
+// depth = reads per lane group in this sweep.  Read k occupies steps k * NC + lane .. k * NC + lane + NC - 1 of a lane, its
+// row-n values land at rown[cap_base + 3 * (W + k * NC + c)] and its fan-in winners in the kth block of `aux`.
 template <int R, int G, bool TILED = false>
 __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, const int s_end,
                                            const uint8_t *__restrict__ seq, const int n, const int lp, const int lane,
                                            unsigned *__restrict__ bpw, double *__restrict__ rown, const unsigned cap_base,
                                            int32_t *__restrict__ aux, const unsigned sink_base, const int sink_stride,
-                                           const int row0 = 0, const double *__restrict__ seam = nullptr)
+                                           const int row0 = 0, const double *__restrict__ seam = nullptr,
+                                           unsigned long long queue = 0ull, const int depth = 1)
 {
     constexpr int W = 64 / G, WORDS = (R + 4) / 5;
+    constexpr bool STREAM = !TILED;
     double I[R], M[R], B[R], er[R];
     unsigned esym[R];                  // LDS address of the emission-pair row of the base in the lane's kth row
 #pragma unroll
@@ -135,8 +159,13 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         // of I and M already
         esym[k] = L.epair_base + (unsigned)((t <= n) ? (int)seq[t - 1] : 4) * L.epair_sym_stride;
     }
-    // the lane that holds the read's last row, and the slot it sits in
-    const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
+    // the lane that holds the read's last row, and the slot it sits in (7: not in this lane) -- kept as one LANE MASK per slot
+    // (wave-uniform: a scalar register pair that the capture branch takes as its exec mask; the masks change only when a lane
+    // group moves on to its next read, so no per-step compare is spent on them)
+    int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : 7;
+    unsigned long long capm[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) capm[k] = __builtin_amdgcn_ballot_w64(kcap == k);
     const bool first_lane = lp == 0 && (!TILED || row0 == 0);       // owner of the read's first row: entry edges
     const bool fix = G == 2 && lane == 32;
     // Row above the lane's first row (the neighbouring lane's last row at the previous step), shifted in with DPP.  A
@@ -161,8 +190,22 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     // whose shifted-in values come from the seam -- always holds the values of the column it works on
     const bool seamed = TILED && seam != nullptr;
     double wI = -INFINITY, wM = -INFINITY, wB = -INFINITY;
-    const unsigned win0 = 4u * (sink_base + (unsigned)(row0 + R * lp + 1));
-    auto step = [&](double &nI, double &nM, double &qI, double &qM) {
+    unsigned win0 = 4u * (sink_base + (unsigned)(row0 + R * lp + 1));
+    // (a register of its own: as one of eight kernel-argument words loaded together it is spilled and reloaded with them)
+    unsigned sink_bytes = 4u * (unsigned)sink_stride;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(sink_bytes));
+    // Back-to-back reads.  A lane that has done its read's last column starts column 0 of its group's next read on the next
+    // step and takes its rows of that read out of the queue -- lane 0 first, the others one step later each, exactly as at the
+    // start of a sweep: a WINDOW of W steps per read in which `uw`, the column lane 0 of a group is on next, says whose turn it
+    // is (lane uw is on its last column).  A lane just keeps walking: what follows the last column in the padded info table
+    // are copies of columns 0 .. W (stage_model<1, true, true>), so the table pointer goes on while the lanes change reads one
+    // after the other; once all of them have, the pointers step back by NC records together.  Behind the LAST read the lanes
+    // walk on as well, for the W - 1 steps at most until the sweep's last lane is done: they compute values nobody reads (no
+    // capture; fan-in "winners" go to a spare block).  The steps between the windows carry none of this: the sweep is a
+    // sequence of plain stretches (two steps per loop iteration, as ever) and windows (their own copies of the step: WIN = 1
+    // between two reads, WIN = 2 behind the last one).
+    auto step = [&](auto WIN, double &nI, double &nM, double &qI, double &qM, const int uw, const bool more) {
+        constexpr int win_kind = decltype(WIN)::value;
         pa += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
         const double v0b_next = *(LdsDouble *)(size_t)pa;
@@ -238,7 +281,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                     er[k] = on_sink ? -INFINITY : er[k];
                 }
                 I[k] = vI; M[k] = vM; B[k] = vB;
-                if (kcap == k) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
+                if (__builtin_amdgcn_inverse_ballot_w64(capm[k])) { capq[0] = vI; capq[1] = vM; capq[2] = vB; }
                 upI = vI; upM = vM; upB = vB;
                 dgI = oI; dgM = oM; dgB = oB;
             }
@@ -246,7 +289,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         if (anyfeed) {                 // after the cells: the accumulators take the rows' final b values of this column
             asm volatile("; feeder column" ::);
             const double erw = on_feed ? erw_c : -INFINITY;
-            const unsigned win = win0 + (feedb >> 1) * (4u * (unsigned)sink_stride);      // byte offset of the row's slot
+            const unsigned win = win0 + (feedb >> 1) * sink_bytes;      // byte offset of the row's slot
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double cand = B[k] + erw;
@@ -255,39 +298,99 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
                 if (won) *(int32_t *)((char *)aux + (win + 4u * k)) = sstep - lp;      // this lane's column
             }
         }
+        if (win_kind != 0) {
+            const bool mine = lp == uw;
+            // fan-in winners of the next read go to the next block of `aux`; behind the last read's block lies one nobody
+            // reads, for what the lanes "win" while they walk on past the end of the sweep
+            win0 = mine ? win0 + (unsigned)COL_MAX_SINKS * sink_bytes : win0;
+            if (more) {
+                if (mine) {
+                    const unsigned w = (unsigned)queue;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) esym[k] = L.epair_base + __umul24((w >> (3 * k)) & 7u, L.epair_sym_stride);
+                    kcap = (int)((w >> (3 * R)) & 7u);
+                    queue >>= 3 * R + 3;
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) capm[k] = __builtin_amdgcn_ballot_w64(kcap == k);
+                if (uw == W) pa -= 16u * (unsigned)NC;           // every lane of the group is on its next read now
+            } else {
+                // behind the last read: nothing is captured any more.  The rows stay what they were -- the lanes compute
+                // values nobody reads on the copied columns for the few steps until the sweep's last lane is done
+                const unsigned long long gone = __builtin_amdgcn_ballot_w64(mine);
+#pragma unroll
+                for (int k = 0; k < R; ++k) capm[k] &= ~gone;
+            }
+        }
         ++sstep;
         meta = meta_next;
         v0b = v0b_next;
     };
     // two steps per loop iteration: the rotation of the loop-carried row values (a cell's old values stay live for the
     // row below while its new ones are produced) becomes register renaming instead of ~3 moves per cell
+    using Plain = std::integral_constant<int, 0>;
+    using Window = std::integral_constant<int, 1>;
     int s = 0;
     if (TILED && seamed) {              // the seam variant shifts in place (its `old` operand is the seam window)
-        for (; s < s_end; s += 2) { step(nI, nM, nI, nM); step(nI, nM, nI, nM); }
-        if (s == s_end) step(nI, nM, nI, nM);
+        for (; s < s_end; s += 2) { step(Plain{}, nI, nM, nI, nM, 0, false); step(Plain{}, nI, nM, nI, nM, 0, false); }
+        if (s == s_end) step(Plain{}, nI, nM, nI, nM, 0, false);
+    } else if (!STREAM) {
+        for (; s < s_end; s += 2) { step(Plain{}, nI, nM, qI, qM, 0, false); step(Plain{}, qI, qM, nI, nM, 0, false); }
+        if (s == s_end) step(Plain{}, nI, nM, qI, qM, 0, false);
     } else {
-        for (; s < s_end; s += 2) { step(nI, nM, qI, qM); step(qI, qM, nI, nM); }
-        if (s == s_end) step(nI, nM, qI, qM);
+        // everything runs in pairs of steps; an odd step of a plain stretch is left to the window that follows, where it does
+        // nothing (no lane answers to uw = -1)
+        for (int k = 0; k < depth; ++k) {
+            const int first_turn = (k + 1) * NC - 1;                  // the step on which lane 0 is on its last column
+            for (const int s1 = s + ((first_turn - s) & ~1); s < s1; s += 2) {
+                step(Plain{}, nI, nM, qI, qM, 0, false);
+                step(Plain{}, qI, qM, nI, nM, 0, false);
+            }
+            const bool more = k + 1 < depth;
+            for (const int s1 = more ? first_turn + W + 1 : s_end + 1; s < s1; s += 2) {     // (a step too many does nothing either)
+                step(Window{}, nI, nM, qI, qM, s - first_turn, more);
+                step(Window{}, qI, qM, nI, nM, s + 1 - first_turn, more);
+            }
+        }
     }
 }
 
-// tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group
+// A lane's rows of one queued read, as rows_sweep unpacks them when the lane gets there: 3 bits per row (base code, 4 = row
+// past the read) and the slot of the read's last row (7 = not in this lane).
+template <int R>
+__device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ seq, const int n, const int lp)
+{
+    unsigned w = 0;
+    unsigned char b[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) b[k] = seq[max(min(R * lp + k + 1, n), 1) - 1];      // (all R loads in flight together)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int t = R * lp + k + 1;
+        w |= (unsigned)((t <= n) ? (int)b[k] : 4) << (3 * k);
+    }
+    const int kc = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : 7;
+    return w | (unsigned)kc << (3 * R);
+}
+
+// tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group; col0 = the steps
+// the read's sweep began after (k * NC for the kth read of a back-to-back sweep)
 template <int R>
 __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
                                                  const LdsTables &L, const DevModel &M, const int r,
                                                  const uint8_t *__restrict__ seq, const int n, double *final_row,
-                                                 const unsigned *__restrict__ bpw, const int lane0,
+                                                 double *tailv, const unsigned *__restrict__ bpw, const int lane0,
                                                  int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                                 int32_t *__restrict__ rev, const int lane)
+                                                 int32_t *__restrict__ rev, const int lane, const int col0)
 {
     const int NC = cp->n_cols;
-    const double logp = col_tail(cp, final_row, tailwin, NC, lane);
+    const double logp = col_tail(cp, final_row, tailwin, NC, lane, tailv);
     if (lane == 0) g.a.out_logp[r] = logp;
     int len = 0;
     if (logp != -INFINITY) {
                 auto bp_at = [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); };
         len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
-                                 1 << 30);
+                                 1 << 30, col0);
         len = __builtin_amdgcn_readfirstlane(len);
     }
     __threadfence_block();
@@ -300,12 +403,16 @@ __global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
 viterbi_rows_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int W = 64 / G;
+    constexpr int W = 64 / G, WORDS = (R + 4) / 5;
+    static_assert(3 * (3 * R + 3) <= 64 && ROWS_DEPTH <= 4, "queued reads of a lane: one 64-bit register");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
     int32_t *tile_slot = (int32_t *)lds;
     uint8_t *tables = lds + 16;
+    // behind the tables: what the reads of a wavefront's sweep are (index, length, offset of the bases), kept out of the
+    // registers while the sweep runs
+    int4 *stash = (int4 *)(lds + 16 + g.lds_tables) + wave * (ROWS_DEPTH * ROWS_MAX_GROUPS);
     unsigned *bpw = (unsigned *)(g.bp + gw * g.bp_stride);
     double *rown = g.rown + gw * g.rown_stride;
     int32_t *aux = g.aux + gw * g.aux_stride;
@@ -328,41 +435,85 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<1, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+            padded = stage_model<1, true, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
-        const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;          // per read: padded row n + tail values
-        for (int j = wave * G; j < tile.count; j += COL_WAVES * G) {
-            // this lane's read (group grp of the wave)
-            const bool have = j + grp < tile.count;
-            const int r = have ? g.a.order[tile.first + j + grp] : 0;
-            const uint8_t *seq = g.a.bases + g.a.read_off[r];
-            const int n = have ? (int)(g.a.read_off[r + 1] - g.a.read_off[r]) : 0;
-            int nmax = n;
-#pragma unroll
-            for (int o = 32; o >= W; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-            nmax = __builtin_amdgcn_readfirstlane(nmax);
-            const unsigned cap_base = (unsigned)(grp * row_doubles);
-            const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * COL_MAX_SINKS * g.sink_stride);
-            if (!padded || nmax > R * (W - (G == 2 ? 1 : 0))) {                       // the host never routes such a tile here
-                if (have && lp == 0) g.a.out_logp[r] = __longlong_as_double(0x7ff8000000000000ll);
+        // per lane group: the row-n values of its reads one behind the other (padded by W columns either side: lanes run
+        // ahead of and past their reads); the tail values of the read being finished sit behind the groups
+        const int dmax = NC >= ROWS_STREAM_MIN_COLS ? g.rows_depth : 1;       // (the deepest tile of the launch: the scratch is laid out for it)
+        const int64_t grp_doubles = 3 * ((int64_t)dmax * NC + 2 * W);
+        double *tailv = rown + G * grp_doubles;
+        // a round: every wavefront takes up to dmax reads per lane group; read (k, group) of wave w is the tile's read
+        // j0 + (k * COL_WAVES + w) * G + group
+        for (int j0 = 0; j0 < tile.count; j0 += COL_WAVES * G * dmax) {
+            const int jw = j0 + wave * G;
+            if (jw >= tile.count) break;
+            const int depth = min(dmax, (tile.count - jw + COL_WAVES * G - 1) / (COL_WAVES * G));
+            if (!padded) {                                                 // the host never routes such a tile here
+                for (int k = 0; k < depth; ++k) {
+                    const int idx = jw + k * COL_WAVES * G + grp;
+                    if (idx < tile.count && lp == 0) g.a.out_logp[g.a.order[tile.first + idx]] = __longlong_as_double(0x7ff8000000000000ll);
+                }
                 continue;
             }
-            const int s_end = NC - 1 + (nmax - 1) / R;
-            rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride);
+            // the reads of this sweep: lane k * G + q fetches what read k of lane group q is (index, length, where its bases
+            // are); the sweep's lanes take their rows from there, and so does the finish phase afterwards
+            int fr = -1, fn = 0;
+            long long fo = 0;
+            {
+                const int k = lane / G, q = lane - k * G;
+                const int idx = jw + k * COL_WAVES * G + q;
+                if (k < depth && idx < tile.count) {
+                    fr = g.a.order[tile.first + idx];
+                    fo = g.a.read_off[fr];
+                    fn = (int)(g.a.read_off[fr + 1] - fo);
+                }
+            }
+            int nbad = fn > R * (W - (G == 2 ? 1 : 0));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) nbad |= __shfl_xor(nbad, o, 64);
+            if (__builtin_amdgcn_readfirstlane(nbad)) {                    // the host never routes such a tile here
+                if (fr >= 0) g.a.out_logp[fr] = __longlong_as_double(0x7ff8000000000000ll);
+                continue;
+            }
+            // this lane's rows of its group's reads: the first one unpacked, the others queued (last one pushed first)
+            unsigned long long queue = 0ull;
+            for (int k = depth - 1; k >= 1; --k) {
+                const int src = k * G + grp;
+                const int nk = __shfl(fn, src, 64);
+                const long long ok = ((long long)__shfl((int)(fo >> 32), src, 64) << 32) | (unsigned)__shfl((int)fo, src, 64);
+                queue = (queue << (3 * R + 3)) | rows_pack_read<R>(g.a.bases + ok, nk, lp);
+            }
+            const int n = __shfl(fn, grp, 64);
+            const uint8_t *seq = g.a.bases + (((long long)__shfl((int)(fo >> 32), grp, 64) << 32) | (unsigned)__shfl((int)fo, grp, 64));
+            // steps: the last read's longest
+            int nlast = 0;
+#pragma unroll
+            for (int q = 0; q < G; ++q) nlast = max(nlast, __builtin_amdgcn_readlane(fn, (depth - 1) * G + q));
+            if (lane < ROWS_DEPTH * G) stash[lane] = make_int4(fr, fn, (int)fo, (int)(fo >> 32));
+            const unsigned cap_base = (unsigned)(grp * grp_doubles);
+            const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * (dmax + 1) * COL_MAX_SINKS * g.sink_stride);
+            const int s_end = depth * NC - 1 + (max(nlast, 1) - 1) / R;
+            rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride, 0, nullptr,
+                             queue, depth);
             rows_bp_publish();
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
+            int4 what = make_int4(0, 0, 0, 0);
+            if (lane < ROWS_DEPTH * G) what = stash[lane];
 #pragma unroll 1
-            for (int q = 0; q < G; ++q) {
-                if (j + q >= tile.count) break;
-                // the read of group q: what its lanes loaded before the sweep
-                const int rq = __builtin_amdgcn_readlane(r, q * W), nq = __builtin_amdgcn_readlane(n, q * W);
-                const unsigned long long sa = (unsigned long long)seq;
-                const uint8_t *sq = (const uint8_t *)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(sa >> 32), q * W) << 32) |
-                                                      (unsigned)__builtin_amdgcn_readlane((int)sa, q * W));
-                rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * row_doubles + 3 * W, bpw, q * W, tailwin,
-                                    aux + COL_MAX_TAIL + (int64_t)q * COL_MAX_SINKS * g.sink_stride, rev, lane);
+            for (int k = 0; k < depth; ++k) {
+#pragma unroll 1
+                for (int q = 0; q < G; ++q) {
+                    if (jw + k * COL_WAVES * G + q >= tile.count) break;
+                    const int src = k * G + q;
+                    const int rq = __builtin_amdgcn_readlane(what.x, src), nq = __builtin_amdgcn_readlane(what.y, src);
+                    const uint8_t *sq = g.a.bases + (((long long)__builtin_amdgcn_readlane(what.w, src) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readlane(what.z, src));
+                    rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv,
+                                        bpw + (int64_t)k * NC * (64 * WORDS), q * W, tailwin,
+                                        aux + COL_MAX_TAIL + (int64_t)(q * (dmax + 1) + k) * COL_MAX_SINKS * g.sink_stride, rev, lane, k * NC);
+                }
             }
         }
     }

@@ -44,6 +44,11 @@ extern "C" {
                                          against read i's model: every output array then holds 2*n_reads entries
                                          (process_unmapped_read scores both strands, vntr_finder.py:239-242) */
 
+#define ADVNTR_FLAG_DEEP_TILES   64u  /* short reads go to the row-blocked kernels in tiles of full back-to-back depth (several
+                                         reads per lane group, one behind the other) whatever the batch size and to the very
+                                         end of the batch; by default small batches and the tail of a large one get shallower
+                                         tiles so that the work spreads over the CUs.  Results are identical */
+
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8
 #define ADVNTR_SUM_RU         0   /* get_number_of_repeats_in_vpath            [155-188] */

@@ -55,6 +55,13 @@ for k in range(n_loci):
         b = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_FORCE_GENERIC, want_paths=want_paths)
     c = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_STREAM)
     d = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_ANTIDIAGONAL, want_paths=want_paths)
+    # the row-blocked kernels once more with tiles of full back-to-back depth (a batch of this size gets single sweeps by default)
+    dd = _lib.viterbi_batch([dm], bases, off, which, flags=_lib.FLAG_DEEP_TILES, want_paths=want_paths)
+    assert np.array_equal(a[0], dd[0]), ("rows vs back-to-back rows logp", k, flank, plen, copies, err,
+                                         np.flatnonzero(~((a[0] == dd[0]) | (np.isnan(a[0]) & np.isnan(dd[0]))))[:5])
+    assert np.array_equal(a[1], dd[1]), ("rows vs back-to-back rows summary", k, np.flatnonzero((a[1] != dd[1]).any(1))[:5])
+    if want_paths:
+        assert a[2] == dd[2], ("rows vs back-to-back rows paths", k)
     assert np.array_equal(a[0], d[0]), ("rows vs anti-diagonal logp", k, flank, plen, copies, err,
                                         np.flatnonzero(~((a[0] == d[0]) | (np.isnan(a[0]) & np.isnan(d[0]))))[:5])
     assert np.array_equal(a[1], d[1]), ("rows vs anti-diagonal summary", k, np.flatnonzero((a[1] != d[1]).any(1))[:5])

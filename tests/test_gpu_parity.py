@@ -115,10 +115,11 @@ def test_mirror_model_viterbi_api():
 
 
 @pytest.mark.parametrize("shape", ["s300", "ref150"])
-@pytest.mark.parametrize("force_generic", [True, False, "stream", "rows"])
+@pytest.mark.parametrize("force_generic", [True, False, "stream", "rows", "deep"])
 def test_synthetic_batch_vs_oracle(shape, force_generic):
     """Seeded C1-style batch at a size the oracle finishes in seconds.  "rows": the default routing
-    (row-blocked kernels); False: the anti-diagonal kernel, one read per wavefront."""
+    (row-blocked kernels); "deep": the same kernels with tiles of full back-to-back depth (what a large batch gets);
+    False: the anti-diagonal kernel, one read per wavefront."""
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
     locus = getattr(workloads, shape)()
@@ -130,7 +131,8 @@ def test_synthetic_batch_vs_oracle(shape, force_generic):
     dm = m.device_model()
     if force_generic is not True and not dm.has_column_program():
         pytest.skip("no column program")
-    flags = {True: _lib.FLAG_FORCE_GENERIC, False: _lib.FLAG_ANTIDIAGONAL, "stream": _lib.FLAG_STREAM, "rows": 0}[force_generic]
+    flags = {True: _lib.FLAG_FORCE_GENERIC, False: _lib.FLAG_ANTIDIAGONAL, "stream": _lib.FLAG_STREAM, "rows": 0,
+             "deep": _lib.FLAG_DEEP_TILES}[force_generic]
     bases, off = _lib.encode_reads(reads)
     logp, summ, paths = _lib.viterbi_batch([dm], bases, off, np.zeros(len(reads), np.int32), flags=flags,
                                            want_paths=True)
@@ -152,6 +154,48 @@ def test_synthetic_batch_vs_oracle(shape, force_generic):
         if len(reads[i]) > 0:
             lm, lb, rm, rb = Or.flanking_counts(inner, reads[i], locus.left, locus.right)
             assert tuple(summ[i][[_lib.SUM_LEFT_MATCH, _lib.SUM_LEFT_BP, _lib.SUM_RIGHT_MATCH, _lib.SUM_RIGHT_BP]]) == (lm, lb, rm, rb)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_back_to_back_sweeps_ragged_multi_model_vs_oracle(seed):
+    """Back-to-back sweeps (ADVNTR_FLAG_DEEP_TILES: up to four reads per lane group, one behind the other along the step
+    axis): reads of 1..155 bases -- all three row-blocked instantiations, tiles that are not full, groups without a read,
+    reads of different lengths behind each other -- of several loci incl. one too narrow for the scheme (< 64 columns),
+    against the oracle (logp ==, paths identical, summaries equal to the default routing's)."""
+    from advntr_amd import _lib, workloads
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(seed)
+    loci = [workloads.make_locus(rng, int(rng.integers(20, 150)), int(rng.integers(4, 40)), int(rng.integers(1, 6)),
+                                 float(rng.choice([0.05, 0.3])), n_units=int(rng.integers(1, 4))) for _ in range(3)]
+    loci.append(workloads.make_locus(rng, 6, 5, 2, 0.05))                 # 6 + 2 * 5 + 6 + connectors: a few dozen columns
+    reads, which = [], []
+    for k, loc in enumerate(loci):
+        for _ in range(int(rng.integers(70, 140))):
+            n = int(rng.choice([int(rng.integers(1, 156)), 150, 64, 65, 124, 125, 155, 1]))
+            r = workloads.make_reads(rng, loc, 1, n, locus_fraction=0.7, sub_rate=0.02)[0]
+            if rng.random() < 0.3 and n > 20:
+                p = int(rng.integers(0, n - 12))
+                r = (r[:p] + "T" * 12 + r[p + 12:])[:n]
+            reads.append(r)
+            which.append(k)
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    which = np.array([which[i] for i in perm], np.int32)
+    dms = [loc.model.device_model() for loc in loci]
+    assert all(dm.has_column_program() for dm in dms)
+    bases, off = _lib.encode_reads(reads)
+    deep = _lib.viterbi_batch(dms, bases, off, which, flags=_lib.FLAG_DEEP_TILES, want_paths=True)
+    plain = _lib.viterbi_batch(dms, bases, off, which, want_paths=True)
+    assert np.array_equal(deep[0], plain[0]) and np.array_equal(deep[1], plain[1]) and deep[2] == plain[2]
+    for k, loc in enumerate(loci):
+        a = loc.model.baked_arrays()
+        edges = [(int(a["in_src"][q]), l, float(a["in_logp"][q]))
+                 for l in range(a["m"]) for q in range(a["in_ptr"][l], a["in_ptr"][l + 1])]
+        O = OracleModel(a["m"], a["silent_start"], a["start_index"], a["end_index"], edges, a["emis_logp"])
+        for i in np.flatnonzero(which == k):
+            olp, opath = O.viterbi(reads[i])
+            assert deep[0][i] == olp, (seed, k, i, len(reads[i]))
+            assert deep[2][i] == opath, (seed, k, i, len(reads[i]))
 
 
 def test_multi_model_batch_and_device_resident_api():
