@@ -40,6 +40,8 @@ SYMBOLS = {
     "advntr_batch_run": (ctypes.c_int, [_vp]),
     "advntr_batch_sync": (ctypes.c_int, [_vp]),
     "advntr_batch_run_timed": (ctypes.c_int, [_vp, _i32, _vp]),
+    "advntr_batch_forward": (ctypes.c_int, [_vp]),
+    "advntr_batch_forward_timed": (ctypes.c_int, [_vp, _i32, _vp]),
     "advntr_batch_fetch": (ctypes.c_int, [_vp, _vp, _vp]),
     "advntr_batch_fetch_paths": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "advntr_batch_result_ptrs": (ctypes.c_int, [_vp, _vp, _vp]),
@@ -226,6 +228,12 @@ class DeviceModel(object):
 
     def has_column_program(self):
         return bool(load().advntr_hmm_has_column_program(self._h))
+
+    def n_columns(self):
+        """Columns of the model's column program (0: none, the model runs on the generic-CSR kernel)."""
+        nc = ctypes.c_int32(0)
+        check(load().advntr_hmm_info(self._h, None, None, None, ctypes.byref(nc)))
+        return int(nc.value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -500,6 +508,15 @@ class DeviceBatch(object):
     def run_timed(self, iters):
         ms = ctypes.c_float(0)
         check(load().advntr_batch_run_timed(self._h, iters, ctypes.byref(ms)))
+        return ms.value
+
+    def forward(self):
+        """Model.log_probability over the resident reads: results replace the batch's log-probabilities (fetch())."""
+        check(load().advntr_batch_forward(self._h))
+
+    def forward_timed(self, iters):
+        ms = ctypes.c_float(0)
+        check(load().advntr_batch_forward_timed(self._h, iters, ctypes.byref(ms)))
         return ms.value
 
     def fetch(self):

@@ -133,8 +133,18 @@ struct DeviceCaches {
 
 DeviceCaches g_cache;
 
+// The device advntr_set_device chose is the process's: HIP keeps the current device per host thread, so a thread that has not
+// chosen one itself (a host-side worker that prepares the next piece of a run) adopts it on its first call here.
+std::atomic<int> g_process_device{-1};
+thread_local bool t_device_chosen = false;
+
 int current_device()
 {
+    if (!t_device_chosen) {
+        t_device_chosen = true;
+        const int want = g_process_device.load();
+        if (want >= 0) (void)hipSetDevice(want);
+    }
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) d = 0;
     return d;
@@ -160,6 +170,8 @@ extern "C" int advntr_device_count(void)
 extern "C" int advntr_set_device(int device)
 {
     HIP_TRY(hipSetDevice(device));
+    g_process_device.store(device);
+    t_device_chosen = true;
     return ADVNTR_OK;
 }
 
@@ -1158,6 +1170,42 @@ extern "C" int advntr_viterbi_batch(advntr_hmm *const *models, int32_t n_models,
     return rc;
 }
 
+// The sum-product launches of a batch (the lists batch_build made serve both recurrences): results go to d_logp.
+static int forward_launch(advntr_batch *B)
+{
+    HIP_TRY(hipMemsetAsync(B->d_counter, 0, 12 * sizeof(int32_t), B->stream));
+    if (B->n_col) {               // reads of models with a column program: sum-product on the anti-diagonal sweep
+        BatchArgs a = make_args(B);
+        a.n_reads = B->n_col;
+        a.order = B->d_order;
+        // batch_build sized the LDS staging level for the Viterbi kernels; the sum-product kernels add a linear
+        // row-0 table (16 B per column): step the level down until the launch fits the 160 KiB of a CU
+        ColumnLaunch C = B->col;                  // (a copy: the Viterbi launches of the same batch keep their level)
+        const size_t kLds = 160 * 1024;
+        if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 1) { C.lds_bytes = C.lds_core_bytes; C.lds_level = 1; }
+        if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 0) { C.lds_bytes = C.lds_min_bytes; C.lds_level = 0; }
+        if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds)
+            return fail(ADVNTR_ERR_TOO_LARGE, "log_probability: a model of %d columns needs %zu B of LDS for the "
+                        "sum-product sweep (> 160 KiB)", C.nc_max, forward_lds_bytes(C.lds_bytes, C.nc_max));
+        if (C.stream) return fail(ADVNTR_ERR_UNSUPPORTED, "log_probability: the batch was created with ADVNTR_FLAG_STREAM");
+        HIP_TRY((column_launch_fwd<1, false>(C, a, B->stream, 0)));
+        HIP_TRY((column_launch_fwd<2, false>(C, a, B->stream, 1)));
+        HIP_TRY((column_launch_fwd<3, false>(C, a, B->stream, 2)));
+        HIP_TRY((column_launch_fwd<COL_LONG_K, true>(C, a, B->stream, 3)));      // 193-256 rows: two row tiles
+        HIP_TRY((column_launch_fwd<COL_LONG_K, true>(C, a, B->stream, 4)));
+        HIP_TRY((column_launch_fwd_rows<5, 2>(C, a, B->stream, 0)));              // the row-blocked kernels' lists
+        HIP_TRY((column_launch_fwd_rows<4, 2>(C, a, B->stream, 1)));
+        HIP_TRY((column_launch_fwd_rows<4, 4>(C, a, B->stream, 2)));
+        HIP_TRY((column_launch_fwd<COL_LONG_K, true>(C, a, B->stream, 8)));
+    }
+    if (B->n_gen) {
+        BatchArgs a = generic_args(B);
+        hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return ADVNTR_OK;
+}
+
 extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models, const uint8_t *bases,
                                     const int64_t *read_off, const int32_t *read_model, int32_t n_reads,
                                     double *out_logp, uint32_t flags)
@@ -1166,45 +1214,37 @@ extern "C" int advntr_forward_batch(advntr_hmm *const *models, int32_t n_models,
     advntr_batch *B = new advntr_batch();
     int rc = batch_build(B, models, n_models, bases, read_off, read_model, n_reads,
                          (flags | ADVNTR_FLAG_NO_SUMMARY) & ~(ADVNTR_FLAG_PATH | ADVNTR_FLAG_STREAM));
-    if (rc == ADVNTR_OK && n_reads) {
-        rc = [&]() -> int {
-            HIP_TRY(hipMemsetAsync(B->d_counter, 0, 12 * sizeof(int32_t), B->stream));
-            if (B->n_col) {               // reads of models with a column program: sum-product on the anti-diagonal sweep
-                BatchArgs a = make_args(B);
-                a.n_reads = B->n_col;
-                a.order = B->d_order;
-                // batch_build sized the LDS staging level for the Viterbi kernels; the sum-product kernels add a linear
-                // row-0 table (16 B per column): step the level down until the launch fits the 160 KiB of a CU
-                ColumnLaunch &C = B->col;
-                const size_t kLds = 160 * 1024;
-                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 1) { C.lds_bytes = C.lds_core_bytes; C.lds_level = 1; }
-                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds && C.lds_level > 0) { C.lds_bytes = C.lds_min_bytes; C.lds_level = 0; }
-                if (forward_lds_bytes(C.lds_bytes, C.nc_max) > kLds)
-                    return fail(ADVNTR_ERR_TOO_LARGE, "advntr_forward_batch: a model of %d columns needs %zu B of LDS for the "
-                                "sum-product sweep (> 160 KiB)", C.nc_max, forward_lds_bytes(C.lds_bytes, C.nc_max));
-                HIP_TRY((column_launch_fwd<1, false>(B->col, a, B->stream, 0)));
-                HIP_TRY((column_launch_fwd<2, false>(B->col, a, B->stream, 1)));
-                HIP_TRY((column_launch_fwd<3, false>(B->col, a, B->stream, 2)));
-                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 3)));      // 193-256 rows: two row tiles
-                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 4)));
-                HIP_TRY((column_launch_fwd_rows<5, 2>(B->col, a, B->stream, 0)));              // the row-blocked kernels' lists
-                HIP_TRY((column_launch_fwd_rows<4, 2>(B->col, a, B->stream, 1)));
-                HIP_TRY((column_launch_fwd_rows<4, 4>(B->col, a, B->stream, 2)));
-                HIP_TRY((column_launch_fwd<COL_LONG_K, true>(B->col, a, B->stream, 8)));
-            }
-            if (B->n_gen) {
-                BatchArgs a = generic_args(B);
-                hipLaunchKernelGGL(forward_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a);
-            }
-            HIP_TRY(hipGetLastError());
-            return ADVNTR_OK;
-        }();
-    }
+    if (rc == ADVNTR_OK && n_reads) rc = forward_launch(B);
     if (rc == ADVNTR_OK) rc = advntr_batch_fetch(B, out_logp, nullptr);
     std::string keep = g_err;
     advntr_batch_destroy(B);
     g_err = keep;
     return rc;
+}
+
+// log_probability on a device-resident batch: the reads stay where advntr_batch_create put them, the sum-product kernels
+// write d_logp (the summaries of an earlier Viterbi run are left alone)
+extern "C" int advntr_batch_forward(advntr_batch *B)
+{
+    if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_forward: null batch");
+    if (B->n_reads == 0) return ADVNTR_OK;
+    return forward_launch(B);
+}
+
+extern "C" int advntr_batch_forward_timed(advntr_batch *B, int32_t iters, float *ms_per_run)
+{
+    if (!B || iters <= 0 || !ms_per_run) return fail(ADVNTR_ERR_ARG, "advntr_batch_forward_timed: bad argument");
+    HIP_TRY(hipEventRecord(B->ev0, B->stream));
+    for (int i = 0; i < iters; ++i) {
+        int rc = advntr_batch_forward(B);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(B->ev1, B->stream));
+    HIP_TRY(hipEventSynchronize(B->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, B->ev0, B->ev1));
+    *ms_per_run = ms / (float)iters;
+    return ADVNTR_OK;
 }
 
 #include "abi_keyword_filter.h"

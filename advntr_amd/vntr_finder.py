@@ -132,24 +132,24 @@ def recruit_mask(logp, summary, read_lengths, min_scores):
     return rate_ok & (by_score | by_default) & (s[:, _lib.SUM_PATH_LEN] > 2)
 
 
-def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=True):
-    """score_reads_multi without a Python object per read, for genome-scale runs: returns a dict of arrays over all
-    kept reads (reads holding 'N' are dropped): locus, index (position in read_lists[locus]), logp, summary,
-    reversed, recruited, length -- the chosen strand per read (reverse iff logp < rev_logp, vntr_finder.py:242-246)."""
+def _empty_scores():
+    return dict(locus=np.zeros(0, np.int32), index=np.zeros(0, np.int32), logp=np.zeros(0),
+                summary=np.zeros((0, _lib.SUMMARY_INTS), np.int32), reversed=np.zeros(0, bool),
+                recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
+
+
+def _prepare_reads(read_lists):
+    """The host half of score_reads_arrays: one code buffer for every read of every locus (case folding, encoding and the
+    test for symbols outside ACGT on host threads in the library, advntr_encode_ascii).  Reads holding 'N' are dropped as
+    the reference does (vntr_finder.py:237); any other foreign symbol raises, as the reference's viterbi does
+    (hmm.pyx:72,79).  Returns None when nothing is left to score."""
     import itertools
-    n_loci = len(models)
-    scaled = [np.nan if (s is None or s == 0) else float(s) for s in (scaled_scores or [None] * n_loci)]
+    n_loci = len(read_lists)
     counts = np.fromiter((len(seqs) for seqs in read_lists), dtype=np.int64, count=n_loci)
     flat = list(itertools.chain.from_iterable(read_lists))
     n_all = len(flat)
-    empty = dict(locus=np.zeros(0, np.int32), index=np.zeros(0, np.int32), logp=np.zeros(0),
-                 summary=np.zeros((0, _lib.SUMMARY_INTS), np.int32), reversed=np.zeros(0, bool),
-                 recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
     if n_all == 0:
-        return empty
-    # one buffer for every read; case folding, encoding and the test for symbols outside ACGT run on host threads in the
-    # library (advntr_encode_ascii).  Reads holding 'N' are dropped as the reference does (vntr_finder.py:237); any other
-    # foreign symbol raises, as the reference's viterbi does (hmm.pyx:72,79).
+        return None
     codes, all_off, bad = _lib.encode_ascii(flat)
     if np.any(bad == 2):
         raise ValueError("Symbol is not defined in a distribution (read %d holds a symbol outside ACGTN)" % int(np.argmax(bad == 2)))
@@ -159,21 +159,25 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
     index_all = (np.arange(n_all, dtype=np.int64) - np.repeat(np.cumsum(counts) - counts, counts)).astype(np.int32)
     nf = int(keep.sum())
     if nf == 0:
-        return empty
+        return None
     if nf == n_all:
-        out = dict(locus=locus_all, index=index_all)
-        lens, bases, off = all_len, codes, all_off
-    else:
-        out = dict(locus=locus_all[keep], index=index_all[keep])
-        lens = all_len[keep]
-        bases = codes[np.repeat(keep, all_len)]
-        off = np.zeros(nf + 1, np.int64)
-        np.cumsum(lens, out=off[1:])
-    which = out["locus"]
-    # both strands in one engine batch: the reverse complements are made on the device (ADVNTR_FLAG_BOTH_STRANDS), call
-    # nf + i = reverse complement of read i
-    logp, summ, _ = _lib.viterbi_batch(device_models(models), bases, off, which, want_paths=False, want_summary=True,
-                                       flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
+        return dict(locus=locus_all, index=index_all, lens=all_len, bases=codes, off=all_off)
+    lens = all_len[keep]
+    off = np.zeros(nf + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    return dict(locus=locus_all[keep], index=index_all[keep], lens=lens, bases=codes[np.repeat(keep, all_len)], off=off)
+
+
+def _score_prepared(models, prep, scaled_scores=None, compute_reverse=True):
+    """The device half: both strands in one engine batch -- the reverse complements are made on the device
+    (ADVNTR_FLAG_BOTH_STRANDS), call nf + i = reverse complement of read i --, the strand choice and the recruit rule."""
+    if prep is None:
+        return _empty_scores()
+    n_loci = len(models)
+    scaled = [np.nan if (s is None or s == 0) else float(s) for s in (scaled_scores or [None] * n_loci)]
+    lens, nf = prep["lens"], len(prep["lens"])
+    logp, summ, _ = _lib.viterbi_batch(device_models(models), prep["bases"], prep["off"], prep["locus"], want_paths=False,
+                                       want_summary=True, flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
     if compute_reverse:
         rlogp, rsumm = logp[nf:], summ[nf:]
         use_rev = logp[:nf] < rlogp
@@ -181,10 +185,27 @@ def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=T
         summ = np.where(use_rev[:, None], rsumm, summ[:nf])
     else:
         use_rev = np.zeros(nf, bool)
-    min_scores = np.asarray(scaled, np.float64)[out["locus"]] * lens
-    out.update(logp=logp, summary=summ, reversed=use_rev, length=lens,
-               recruited=recruit_mask(logp, summ, lens, min_scores))
-    return out
+    min_scores = np.asarray(scaled, np.float64)[prep["locus"]] * lens
+    return dict(locus=prep["locus"], index=prep["index"], logp=logp, summary=summ, reversed=use_rev, length=lens,
+                recruited=recruit_mask(logp, summ, lens, min_scores))
+
+
+def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=True):
+    """score_reads_multi without a Python object per read, for genome-scale runs: returns a dict of arrays over all
+    kept reads (reads holding 'N' are dropped): locus, index (position in read_lists[locus]), logp, summary,
+    reversed, recruited, length -- the chosen strand per read (reverse iff logp < rev_logp, vntr_finder.py:242-246)."""
+    return _score_prepared(models, _prepare_reads(read_lists), scaled_scores, compute_reverse)
+
+
+def _genotypes_from_scores(res, n_loci, accuracy_filter, is_haploid, threads):
+    keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
+    locus = res["locus"][keep]                       # ascending already: reads are laid out locus by locus
+    summ = res["summary"][keep]
+    if len(locus) and np.any(np.diff(locus) < 0):
+        order = np.argsort(locus, kind="stable")
+        locus, summ = locus[order], summ[order]
+    bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
+    return find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
 
 
 def genotype_loci(models, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False, compute_reverse=True,
@@ -194,16 +215,75 @@ def genotype_loci(models, read_lists, scaled_scores=None, accuracy_filter=False,
     recruit rule on the summary records (:179-190), reads with more than two repeat bases selected (:251), and the
     per-locus aggregation + maximum-likelihood genotype (:807-887, :473-532) in the library's host threads
     (advntr_genotype_illumina).  Returns one GenotypeResult per locus."""
-    n_loci = len(models)
     res = score_reads_arrays(models, read_lists, scaled_scores, compute_reverse)
-    keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
-    locus = res["locus"][keep]                       # ascending already: reads are laid out locus by locus
-    summ = res["summary"][keep]
-    if len(locus) and np.any(np.diff(locus) < 0):
-        order = np.argsort(locus, kind="stable")
-        locus, summ = locus[order], summ[order]
+    return _genotypes_from_scores(res, len(models), accuracy_filter, is_haploid, threads)
+
+
+def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False,
+                            compute_reverse=True, chunks=8, threads=0, timings=None):
+    """genotype_loci from the locus DESCRIPTIONS -- loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...], what
+    the reference turns into a model per locus inside its serial loop (genome_analyzer.py:280-297 -> vntr_finder.py:117-138) --
+    with the host stages overlapped with the device's: the locus set is cut into `chunks` pieces; a preparation thread builds
+    the models of piece k + 1 (native builder, host threads), uploads them and encodes the piece's reads while the calling
+    thread has piece k scored (both strands, one engine batch) and applies the strand choice and the recruit rule.  The
+    per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results as
+    genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage."""
+    import queue
+    import threading
+    import time
+    from . import hmm_utils
+    n_loci = len(loci)
+    chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
+    cuts = [n_loci * i // chunks for i in range(chunks + 1)]
+    ready = queue.Queue(maxsize=2)               # (piece, models, prepared reads) waiting for the device
+    T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, score_recruit=0.0, aggregate_genotype=0.0)
+
+    def prepare():
+        try:
+            for k in range(chunks):
+                lo, hi = cuts[k], cuts[k + 1]
+                t = time.perf_counter()
+                models = hmm_utils.build_read_matcher_models(loci[lo:hi], threads=threads)
+                T["build_models"] += time.perf_counter() - t
+                t = time.perf_counter()
+                device_models(models)
+                T["upload_models"] += time.perf_counter() - t
+                t = time.perf_counter()
+                prep = _prepare_reads(read_lists[lo:hi])
+                T["encode_reads"] += time.perf_counter() - t
+                ready.put((k, models, prep))
+        except BaseException as e:                  # handed to the consumer: a failure must not leave it waiting
+            ready.put(e)
+
+    t0 = time.perf_counter()
+    worker = threading.Thread(target=prepare, name="advntr-prepare")
+    worker.start()
+    parts = []
+    try:
+        for _ in range(chunks):
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            k, models, prep = item
+            t = time.perf_counter()
+            res = _score_prepared(models, prep, None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]],
+                                  compute_reverse)
+            keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
+            parts.append((res["locus"][keep].astype(np.int64) + cuts[k], res["summary"][keep]))
+            T["score_recruit"] += time.perf_counter() - t
+            del models, prep, res                   # the piece's models leave the device with their last reference
+    finally:
+        worker.join()
+    t = time.perf_counter()
+    locus = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
+    summ = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, _lib.SUMMARY_INTS), np.int32)
     bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
-    return find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
+    out = find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
+    T["aggregate_genotype"] = time.perf_counter() - t
+    T["total"] = time.perf_counter() - t0
+    if timings is not None:
+        timings.update(T)
+    return out
 
 
 def get_conditional_likelihood(ck, ci, cj, r, r_e):

@@ -125,15 +125,15 @@ def _c2_locus(args):
     mapped = make_reads(rng, loc, n_mapped, read_len, locus_fraction=0.9)
     unmapped = make_reads(rng, loc, n_unmapped, read_len, locus_fraction=0.5)
     calls = mapped + unmapped + [reverse_complement(s) for s in unmapped]
-    return (loc.left, loc.right, loc.units, loc.copies, loc.error_rate), calls
+    return (loc.left, loc.right, loc.units, loc.copies, loc.error_rate), calls, (n_mapped, n_unmapped)
 
 
 def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapped_mean=40, workers=None, build=True,
-                     only=None):
+                     only=None, return_counts=False):
     """make_c2 with the synthetic read generation spread over a process pool (per-locus seeds, independent of the
     worker count); the models are then built by the native builder on host threads.  only = the locus indices this
     rank owns (multi-GPU sharding: every rank can produce exactly its share).  Returns ([Locus], reads, read_locus)
-    with read_locus indexing the returned list."""
+    with read_locus indexing the returned list (+ the (mapped, unmapped) read counts per locus with return_counts)."""
     import multiprocessing as mp
     import os
     workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
@@ -141,13 +141,16 @@ def make_c2_parallel(n_loci, seed=20240602, read_len=150, mapped_mean=80, unmapp
     jobs = [(k, seed, read_len, mapped_mean, unmapped_mean) for k in ks]
     with mp.get_context("fork").Pool(workers) as pool:
         res = pool.map(_c2_locus, jobs, chunksize=8)
-    loci, reads, which = [], [], []
-    for i, (params, calls) in enumerate(res):
+    loci, reads, which, counts = [], [], [], []
+    for i, (params, calls, nmu) in enumerate(res):
         loci.append(Locus(*params))
         reads += calls
         which += [i] * len(calls)
+        counts.append(nmu)
     if build:
         build_models(loci)
+    if return_counts:           # (mapped, unmapped) per locus: a locus's calls are mapped + unmapped + the unmapped reads' reverse complements
+        return loci, reads, np.asarray(which, dtype=np.int32), counts
     return loci, reads, np.asarray(which, dtype=np.int32)
 
 

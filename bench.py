@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--loci", type=int, default=None, help="c2/c3: default 6719; c4: default 8960")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-s300", action="store_true")
+    ap.add_argument("--no-c2", action="store_true",
+                    help="c1 at --gpus 1: leave out the `c2` and `end_to_end` sub-records (the 6719-locus target configuration)")
+    ap.add_argument("--c2-loci", type=int, default=6719, help="loci of the `c2` / `end_to_end` sub-records")
     ap.add_argument("--dry-run", action="store_true", help="plan + rendezvous only, no GPU work (host communicator)")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes every call's (global id, logp, summary), gathered from all ranks after the timed "
@@ -154,7 +157,7 @@ def load_json(*parts):
 def pmc_section(workload, n_calls, kernel):
     """Counters per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench);
     None when no committed profile describes this workload / kernel / size."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         pmc = load_json("profiles", name)
         if not pmc:
             continue
@@ -268,6 +271,13 @@ def main(argv=None):
         alg_bytes_total = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
         relax_total = float(np.sum((lens + 1) * edges_per_locus[which]))
     else:
+        c2_input = None
+        if world == 1 and not args.no_c2 and not args.no_s300:
+            # the target configuration of the north star rides on the C1 line as sub-records `c2` / `end_to_end`; its
+            # synthetic reads come out of a process pool, which must have gone before the GPU is touched (see above)
+            t_gen = time.perf_counter()
+            c2_input = workloads.make_c2_parallel(args.c2_loci, seed=20240602, build=False, workers=host_workers,
+                                                  return_counts=True) + (time.perf_counter() - t_gen,)
         locus = workloads.ref150()
         a = locus.model.baked_arrays()
         m, P, E = a["m"], a["silent_start"], len(a["in_src"])
@@ -424,7 +434,9 @@ def main(argv=None):
                                                "source": pmc.get("file"), "stale": pmc.get("stale")}
         if workload == "c1" and not args.no_s300:
             out["s300"] = s300_record(_lib, workloads, flags, args)
-            out["log_probability"] = forward_record(_lib, locus, bases, off, n_reads, args)
+            out["log_probability"] = forward_record(_lib, locus, batch, bases, off, n_reads, n, args)
+            if c2_input is not None:
+                out["end_to_end"], out["c2"] = target_configuration_records(_lib, workloads, c2_input, flags, args)
         if workload == "c1" and world == 1 and not args.no_cpu:
             cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
@@ -461,12 +473,25 @@ def main(argv=None):
     return rc
 
 
-def forward_record(_lib, locus, bases, off, n_reads, args):
-    """Model.log_probability (the sum-product twin of the scored path) on the same batch: the one-shot
-    C-ABI call from host buffers (upload, kernel, download: there is no device-resident forward batch), best of three; on the
-    bench sample the values are within 1e-9 relative of the oracle's log-domain forward."""
+F64_PEAK_TFLOPS = SIMDS * CLOCK_GHZ * 1e9 * 16 * 2 / 1e12      # 16 fp64 lanes per cycle and SIMD (a wave64 fp64 instruction
+                                                               # issues over 4 cycles, profiles/r02_f64_issue_ubench.txt), fused
+                                                               # multiply-add = 2 flop: 78.6 TFLOP/s
+FORWARD_FMA_PER_CELL = 11      # csrc/forward_rows.h: the linear-domain cell, three states
+
+
+def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
+    """Model.log_probability (the sum-product twin of the scored path) on the same batch.  `kernel_ms`:
+    the sum-product kernels on the RESIDENT reads (advntr_batch_forward_timed, HIP events on the launch stream), priced
+    against fp64 multiply-add issue: cells x fused multiply-adds per cell x 2 flop / time vs the vector fp64 peak.
+    `ms_per_call`: the one-shot C-ABI call from host buffers (upload, kernel, download), best of three.  On the bench
+    sample the values are within 1e-9 relative of the oracle's log-domain forward."""
     dm = locus.model.device_model()
     which = np.zeros(n_reads, np.int32)
+    nc = dm.n_columns() if hasattr(dm, "n_columns") else None
+    batch.forward()
+    batch.sync()
+    kernel_ms = batch.forward_timed(max(1, args.steps))
+    lp_resident, _ = batch.fetch()
     _lib.forward_batch([dm], bases[:off[64]], off[:65], which[:64])
     best = None
     for _ in range(3):
@@ -474,9 +499,19 @@ def forward_record(_lib, locus, bases, off, n_reads, args):
         lp = _lib.forward_batch([dm], bases, off, which)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    rec = {"reads": n_reads, "value": n_reads / best, "unit": "reads/s", "ms_per_call": best * 1e3,
-           "timing": "one-shot advntr_forward_batch from host buffers (PCIe inclusive), best of 3",
-           "kernel": "forward_rows_kernel<5, 2>"}
+    assert np.array_equal(lp, lp_resident), "resident and one-shot log_probability differ"
+    rec = {"reads": n_reads, "value": n_reads / (kernel_ms * 1e-3), "unit": "reads/s", "kernel_ms": kernel_ms,
+           "kernel": "forward_rows_kernel<5, 2>", "timing": "advntr_batch_forward_timed on the resident batch (HIP events)",
+           "one_shot": {"value": n_reads / best, "ms_per_call": best * 1e3,
+                        "timing": "advntr_forward_batch from host buffers (PCIe inclusive), best of 3"}}
+    if nc:
+        cells = float(n_reads) * n * nc
+        tflops = cells * FORWARD_FMA_PER_CELL * 2 / (kernel_ms * 1e-3) / 1e12
+        rec["roofline"] = {"bound": "valu_f64", "achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tflops / F64_PEAK_TFLOPS, "cells": cells, "fma_per_cell": FORWARD_FMA_PER_CELL,
+                           "columns": nc,
+                           "note": "trellis cells (read length x model columns x reads) x 11 fused multiply-adds x 2 flop over the "
+                                   "HIP-event kernel time, against the fp64 vector peak (16 lanes/cycle/SIMD x 1024 SIMDs x 2.4 GHz)"}
     if not args.no_cpu:
         O = oracle_model(locus)
         k = min(200, n_reads)
@@ -488,6 +523,120 @@ def forward_record(_lib, locus, bases, off, n_reads, args):
         rec["oracle_sample"] = k
         assert worst <= 1e-9, "GPU/oracle log_probability mismatch on the bench sample"
     return rec
+
+
+def target_configuration_records(_lib, workloads, c2_input, flags, args):
+    """The north star's target configuration on one GPU (BASELINE config 2: 6719 Illumina loci x a 30x-equivalent read
+    batch) as two sub-records of the C1 line.
+
+    `end_to_end`: candidate reads -> genotypes, what the reference's per-locus loop does (genome_analyzer.py:280-297 ->
+    vntr_finder.py:727-767, 807-887): models built by the native builder, both strands of every candidate scored, recruit
+    rule, aggregation, maximum-likelihood genotype -- the host stages of one piece of the locus set overlapped with the
+    scoring of the previous one (vntr_finder.genotype_loci_pipelined), next to the same stages run one after the other.
+    `c2`: the scoring kernel alone over the whole set's calls, resident in HBM, with its roofline object."""
+    from advntr_amd import hmm_utils, vntr_finder
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which, counts, t_gen = c2_input
+    n_loci = len(loci)
+    desc = [(l.left, l.right, l.units, l.copies) for l in loci]
+    first = np.concatenate([[0], np.cumsum([nm + 2 * nu for nm, nu in counts])])
+    candidates = [reads[first[k]:first[k] + nm + nu] for k, (nm, nu) in enumerate(counts)]      # forward strands only
+    n_cand = int(sum(len(c) for c in candidates))
+    hmm_utils.build_read_matcher_models(desc[:4])                                                   # warm-up
+    vntr_finder.score_reads_arrays(hmm_utils.build_read_matcher_models(desc[:1]), [candidates[0][:8]])
+    # the stages one after the other
+    T = {}
+    t0 = time.perf_counter()
+    models = hmm_utils.build_read_matcher_models(desc)
+    T["build_models"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dms = device_models(models)
+    T["upload_models"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    res = vntr_finder.score_reads_arrays(models, candidates, None, compute_reverse=True)
+    T["encode_score_recruit"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    plain = vntr_finder._genotypes_from_scores(res, n_loci, False, False, 0)
+    T["aggregate_genotype"] = time.perf_counter() - t1
+    T["total"] = time.perf_counter() - t0
+    recruited = int((res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)).sum())
+    # ... and overlapped
+    P = {}
+    piped = vntr_finder.genotype_loci_pipelined(desc, candidates, timings=P)
+    same = sum(a.copy_numbers == b.copy_numbers and a.recruited_reads_count == b.recruited_reads_count
+               for a, b in zip(plain, piped))
+    assert same == n_loci, "pipelined and stage-by-stage genotypes differ on %d loci" % (n_loci - same)
+    e2e = {"loci": n_loci, "candidate_reads": n_cand, "viterbi_calls": 2 * n_cand, "recruited_reads": recruited,
+           "loci_with_genotype": sum(g.copy_numbers is not None for g in piped),
+           "value": 2 * n_cand / P["total"], "unit": "calls/s", "total_s": P["total"],
+           "stage_s_overlapped": {k: v for k, v in P.items() if k != "total"},
+           "stages_one_after_the_other": dict(T),
+           "genotypes_identical_to_stage_by_stage": same == n_loci,
+           "note": "from candidate reads in Python lists to RU-count genotypes; overlapped = model build / upload / read "
+                   "encoding of locus piece k+1 on a host thread while piece k is scored (8 pieces); synthetic input "
+                   "generated in %.1f s (not timed)" % t_gen}
+    # the kernel over the whole set's calls (mapped forward + unmapped on both strands, as BASELINE config 2 counts them)
+    bases, off = _lib.encode_reads(reads)
+    batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
+    batch.run()
+    batch.sync()
+    steps = max(1, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+    batch.sync()
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms = batch.run_timed(steps)
+    logp, summ = batch.fetch()
+    kernels = batch.kernels()
+    kernel = max(kernels, key=lambda k: k[1])[0]
+    ms = np.array([d.m for d in dms])
+    lens = np.diff(off)
+    alg = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    pmc = pmc_section("c2", len(reads), kernel) or {}
+    traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
+    c2 = {"loci": n_loci, "calls": len(reads), "mean_states": float(np.mean(ms[which])), "read_len": int(round(float(lens.mean()))),
+          "value": len(reads) / dt, "unit": "calls/s", "ms_per_step": dt * 1e3, "steps": steps, "kernel_ms": kernel_ms,
+          "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t} for k, r, t in kernels],
+          "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBPS, "algorithmic_gb_per_launch": alg / 1e9,
+                       "traffic": traffic / 1e9 if traffic else None, "traffic_source": pmc.get("file"),
+                       "note": "exact sum over the calls of n + (n+1) m + (n+m) + 32 bytes (SURVEY 8d) / HIP-event kernel time"}}
+    if not args.no_cpu:
+        # per-locus sample against the oracle: log-probabilities bit for bit, repeat-unit counts as hmm_utils derives them
+        # from the oracle's path; its single-thread rate on these models prices the whole set for the reference
+        from oracle import oracle as Or
+        sample = np.linspace(0, n_loci - 1, 48).astype(int)
+        n_chk = same_ru = 0
+        t_cpu = 0.0
+        for k in sample:
+            arr = models[k].baked_arrays()
+            edges = [(int(arr["in_src"][e]), l, float(arr["in_logp"][e]))
+                     for l in range(arr["m"]) for e in range(arr["in_ptr"][l], arr["in_ptr"][l + 1])]
+            O = Or.OracleModel(arr["m"], arr["silent_start"], arr["start_index"], arr["end_index"], edges, arr["emis_logp"])
+            names = [st.name for st in models[k].states]
+            for i in range(int(first[k]), int(first[k]) + 6):
+                t1 = time.perf_counter()
+                olp, opath = O.viterbi(reads[i])
+                t_cpu += time.perf_counter() - t1
+                assert logp[i] == olp, "GPU/oracle log-prob mismatch on the C2 sample (locus %d)" % k
+                ru = Or.number_of_repeats([names[j] for j in opath][1:-1]) if opath else 0
+                same_ru += int(ru == int(summ[i][0]))
+                n_chk += 1
+        cal = load_json("profiles", "cpu_calibration.json") or {}
+        ratio = cal.get("oracle_over_pomegranate")
+        cps = n_chk / t_cpu
+        c2["ru_concordance"] = {"loci": len(sample), "calls": n_chk, "identical_ru_counts": same_ru, "logp_bit_equal": True}
+        c2["cpu_baseline"] = {"value": cps, "unit": "calls/s", "cores": 1, "kind": "port", "cpu_model": cpu_model_name(),
+                              "sample": "6 calls of each of 48 loci spread over the set, oracle/viterbi_oracle.c through its "
+                                        "per-call entry, 1 thread",
+                              "pomegranate_equivalent": cps / ratio if ratio else None}
+        if ratio:
+            c2["speedup_vs_pomegranate_equivalent_1thread"] = c2["value"] / (cps / ratio)
+            e2e["reference_scoring_alone_s_pomegranate_equivalent"] = 2 * n_cand / (cps / ratio)
+    batch.close()
+    return e2e, c2
 
 
 def s300_record(_lib, workloads, flags, args):

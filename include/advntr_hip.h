@@ -128,6 +128,10 @@ void advntr_batch_destroy(advntr_batch *batch);
 int advntr_batch_run(advntr_batch *batch);
 int advntr_batch_sync(advntr_batch *batch);
 int advntr_batch_run_timed(advntr_batch *batch, int32_t iters, float *ms_per_run);
+/* Model.log_probability over a resident batch (hmm.pyx:1258-1313): the sum-product kernels on the uploaded reads,
+ * results in the batch's logp array (fetch with advntr_batch_fetch; summaries untouched); _timed as run_timed.     */
+int advntr_batch_forward(advntr_batch *batch);
+int advntr_batch_forward_timed(advntr_batch *batch, int32_t iters, float *ms_per_run);
 int advntr_batch_fetch(advntr_batch *batch, double *out_logp, int32_t *out_summary);
 int advntr_batch_fetch_paths(advntr_batch *batch, int32_t *out_path, const int64_t *out_path_off,
                              int32_t *out_path_len);

@@ -228,3 +228,64 @@ def test_both_strands_flag_equals_explicit_reverse_complements():
     lp3, sm3 = B.fetch()
     B.close()
     assert np.array_equal(lp3, lp) and np.array_equal(sm3, sm)
+
+
+def test_pipelined_genotyping_equals_stage_by_stage():
+    """vntr_finder.genotype_loci_pipelined (model build / upload / read encoding of locus piece k+1 on a host thread while
+    piece k is scored) gives the genotypes, probabilities and read counts of the stage-by-stage route on the same loci --
+    incl. a locus without reads, reads holding N, more pieces than loci -- and its per-read scores are the oracle's."""
+    from advntr_amd import hmm_utils, vntr_finder, workloads
+    loci, reads, which, counts = workloads.make_c2_parallel(37, seed=77, build=False, workers=2, return_counts=True)
+    desc = [(l.left, l.right, l.units, l.copies) for l in loci]
+    first = np.concatenate([[0], np.cumsum([nm + 2 * nu for nm, nu in counts])])
+    cand = [reads[first[k]:first[k] + nm + nu] for k, (nm, nu) in enumerate(counts)]
+    cand[5] = []                                           # a locus nobody mapped to
+    cand[7] = cand[7][:3] + ["ACGTN" * 30] + cand[7][3:]   # dropped before scoring (vntr_finder.py:237)
+    models = hmm_utils.build_read_matcher_models(desc)
+    plain = vntr_finder.genotype_loci(models, cand)
+    for chunks in (1, 4, 64):
+        T = {}
+        piped = vntr_finder.genotype_loci_pipelined(desc, cand, chunks=chunks, timings=T)
+        assert len(piped) == len(plain) == 37
+        for a, b in zip(plain, piped):
+            assert a.copy_numbers == b.copy_numbers
+            assert a.maximum_likelihood == b.maximum_likelihood
+            assert (a.recruited_reads_count, a.spanning_reads_count, a.flanking_reads_count) == \
+                (b.recruited_reads_count, b.spanning_reads_count, b.flanking_reads_count)
+        assert T["total"] > 0 and set(T) >= {"build_models", "upload_models", "encode_reads", "score_recruit"}
+    assert plain[5].copy_numbers is None
+    assert sum(g.copy_numbers is not None for g in plain) >= 30
+    # a failure in the preparation thread reaches the caller
+    bad = list(desc)
+    bad[20] = (desc[20][0], desc[20][1], ["ACGTXX"], 3)
+    with pytest.raises(Exception):
+        vntr_finder.genotype_loci_pipelined(bad, cand, chunks=4)
+
+
+def test_resident_log_probability_equals_one_shot_and_oracle():
+    """advntr_batch_forward on a resident batch (what bench.py times) == the one-shot advntr_forward_batch, within 1e-9
+    relative of the oracle's log-domain forward; a Viterbi run on the same batch afterwards is unaffected."""
+    from advntr_amd import _lib, workloads
+    locus = workloads.s300()
+    reads = workloads.make_reads(np.random.default_rng(5), locus, 300, 150) + ["ACGT", "A" * 200]
+    bases, off = _lib.encode_reads(reads)
+    dm = locus.model.device_model()
+    which = np.zeros(len(reads), np.int32)
+    B = _lib.DeviceBatch([dm], bases, off, which)
+    B.run()
+    v_logp, v_summ = B.fetch()
+    B.forward()
+    f_logp, f_summ = B.fetch()
+    assert np.array_equal(f_summ, v_summ)                   # summaries are the Viterbi run's
+    one_shot = _lib.forward_batch([dm], bases, off, which)
+    assert np.array_equal(f_logp, one_shot)
+    assert B.forward_timed(2) > 0
+    O = _oracle(locus.model)
+    for i in range(0, len(reads), 11):
+        want = O.forward(bases[off[i]:off[i + 1]])
+        assert abs(f_logp[i] - want) <= 1e-9 * max(1.0, abs(want))
+        assert f_logp[i] >= v_logp[i] - 1e-9                # the sum over paths is at least the best path
+    B.run()
+    again, _ = B.fetch()
+    assert np.array_equal(again, v_logp)
+    B.close()
