@@ -63,6 +63,7 @@ SYMBOLS = {
     "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "advntr_comm_available": (ctypes.c_int, []),
     "advntr_comm_unique_id": (ctypes.c_int, [_vp]),
     "advntr_comm_create": (_vp, [_i32, _i32, _vp]),
     "advntr_comm_destroy": (None, [_vp]),
@@ -72,6 +73,7 @@ SYMBOLS = {
     "advntr_comm_barrier": (ctypes.c_int, [_vp]),
     "advntr_comm_gather_results_start": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
     "advntr_comm_gather_results_finish": (ctypes.c_int, [_vp, _vp, _vp]),
+    "advntr_comm_last_gather_ms": (ctypes.c_int, [_vp, _vp]),
     "advntr_comm_gather_bytes": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
 }
 

@@ -4,7 +4,7 @@ The path shards by locus (sharding.py) and has a single exchange step, the gathe
 (SURVEY.md section 8e).  That gather runs device to device over xGMI through the library's C ABI
 (`advntr_comm_*`, csrc/abi_comm.h: grouped ncclSend / ncclRecv).  What RCCL needs from the host is the 128-byte
 unique id handed from rank 0 to the others; `FileRendezvous` does that through a directory under /tmp (the ranks of
-one node share a file system), keyed by the launcher's MASTER_PORT and process id, so it works the same under
+one node share a file system), named after the launch (launcher process and its start time, MASTER_PORT, run id, restart count) and closed to other users, so it works the same under
 `python -m torch.distributed.run` (which only sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and starts the
 processes -- nothing of torch is imported here) and under bench.py's own spawner.
 
@@ -23,19 +23,47 @@ import time
 
 import numpy as np
 
+SUMMARY_INTS = 8            # int32 words of a result record's summary (include/advntr_hip.h: ADVNTR_SUMMARY_INTS)
+
+
+def _launcher_identity():
+    """What tells one launch of the ranks from another on this host: the launcher's port and run id, its restart count
+    (a torchrun agent that restarts its workers keeps port, run id and its own process), and the launcher PROCESS --
+    its pid together with its start time, so that a recycled pid is somebody else."""
+    ppid = os.getppid()
+    started = "x"
+    try:
+        with open("/proc/%d/stat" % ppid) as fh:
+            started = fh.read().rsplit(")", 1)[1].split()[19]            # field 22: starttime (clock ticks since boot)
+    except (OSError, IndexError):
+        pass
+    return "%s_%s_%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), ppid, started,
+                               os.environ.get("TORCHELASTIC_RUN_ID", "x"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+
 
 class FileRendezvous(object):
-    """Small blobs between the ranks of one node through files: put / get by name, all-gather, barrier."""
+    """Small blobs between the ranks of one node through files: put / get by name, all-gather, barrier.
+
+    The directory is this user's alone (mode 0700; a directory that exists already must be a real directory owned by
+    this user and closed to others, anything else is refused), and its name carries the launch's identity, so the ranks
+    of a restarted or later launch never meet the files a crashed one left behind."""
 
     def __init__(self, rank, world, directory=None, timeout=900.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if directory is None:
             directory = os.environ.get("ADVNTR_RDZV_DIR")
         if directory is None:
-            key = "%s_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), os.environ.get("TORCHELASTIC_RUN_ID", "x"))
-            directory = os.path.join("/tmp", "advntr_rdzv_%d_%s" % (os.getuid(), key))
+            directory = os.path.join("/tmp", "advntr_rdzv_%d_%s" % (os.getuid(), _launcher_identity()))
         self.dir = directory
-        os.makedirs(self.dir, exist_ok=True)
+        try:
+            os.makedirs(self.dir, mode=0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(self.dir)
+        import stat as stat_mod
+        if not stat_mod.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError("rendezvous directory %s is not a directory of this user alone (uid %d, mode %o): refusing "
+                                  "to exchange data through it" % (self.dir, st.st_uid, st.st_mode & 0o7777))
         self._seq = 0
 
     def put(self, name, data):
@@ -125,27 +153,66 @@ class HostComm(object):
         for p, c in zip(parts, counts):
             c = int(c)
             lps.append(np.frombuffer(p[:8 * c], np.float64))
-            sms.append(np.frombuffer(p[8 * c:], np.int32).reshape(c, -1))
+            sms.append(np.frombuffer(p[8 * c:], np.int32).reshape(c, SUMMARY_INTS))
         return np.concatenate(lps), np.concatenate(sms)
 
     def close(self):
         self.rdzv.close()
 
 
+class CommSetupError(RuntimeError):
+    """RCCL cannot be used by this job; raised on every rank alike, before any of them entered a collective."""
+
+
 class RcclComm(HostComm):
     """RCCL communicator of the library (advntr_comm_*), one rank per GPU; the current device must be set before."""
     backend = "rccl"
 
-    def __init__(self, rdzv):
+    def __init__(self, rdzv, init_timeout=None):
+        """Collective.  Every rank makes the same rendezvous calls whatever fails where, and no rank enters
+        ncclCommInitRank -- a collective that only returns when ALL ranks have called it -- before every rank has said
+        that it can: (1) each rank loads librccl (advntr_comm_available) and the ranks exchange the outcome; (2) rank 0
+        makes the unique id and broadcasts it, an empty blob if that failed; (3) the ranks create their communicators, each
+        under a watchdog that ends the PROCESS if the call has not returned after `init_timeout` seconds (default
+        ADVNTR_COMM_INIT_TIMEOUT or 180): a peer that died between (2) and (3) must not leave the job hanging.
+        Raises CommSetupError on every rank alike when any of them reported a failure in (1) or (2)."""
         from . import _lib
         HostComm.__init__(self, rdzv)
         self._lib = _lib
+        self._h = None
         L = _lib.load()
+        err = b""
+        if L.advntr_comm_available() != _lib.OK:
+            err = ("rank %d: %s" % (self.rank, _lib.last_error())).encode("utf-8", "replace")
+        failures = [x for x in rdzv.allgather(err) if x]
         uid = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _lib.check(L.advntr_comm_unique_id(ctypes.addressof(uid)))
-        blob = rdzv.broadcast(uid.raw, 0)
-        self._h = L.advntr_comm_create(self.rank, self.world, blob)
+        blob = b""
+        if self.rank == 0 and not failures:
+            if L.advntr_comm_unique_id(ctypes.addressof(uid)) == _lib.OK:
+                blob = uid.raw
+            else:
+                failures.append(("rank 0: %s" % _lib.last_error()).encode("utf-8", "replace"))
+        blob = rdzv.broadcast(blob, 0)                       # always: every rank takes this step
+        if failures or len(blob) != 128:
+            reason = failures[0].decode("utf-8", "replace") if failures else "rank 0 could not make the RCCL unique id"
+            raise CommSetupError(reason)
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("ADVNTR_COMM_INIT_TIMEOUT", "180"))
+        import sys
+        import threading
+
+        def give_up():
+            sys.stderr.write("advntr_amd.comm: rank %d: ncclCommInitRank did not return within %.0f s (a peer is gone?); "
+                             "ending this process\n" % (self.rank, init_timeout))
+            sys.stderr.flush()
+            os._exit(70)
+        watchdog = threading.Timer(init_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            self._h = L.advntr_comm_create(self.rank, self.world, blob)
+        finally:
+            watchdog.cancel()
         if not self._h:
             raise _lib.EngineError(_lib.ERR_DEVICE, _lib.last_error())
 
@@ -193,6 +260,14 @@ class RcclComm(HostComm):
             self._h, None if logp is None else logp.ctypes.data, None if summ is None else summ.ctypes.data))
         return logp, summ
 
+    def last_gather_ms(self):
+        """Milliseconds the last finished result gather took on the communicator's stream, from the moment the records of
+        its pass were staged (HIP events): about the transfer itself when it ran beside the next pass, about a whole pass
+        when it had to wait for that pass's kernels to leave the compute units."""
+        ms = ctypes.c_float(0)
+        self._lib.check(self._lib.load().advntr_comm_last_gather_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.load().advntr_comm_destroy(self._h)
@@ -227,26 +302,32 @@ def init_from_env(backend=None, set_device=True):
     rdzv = FileRendezvous(rank, world)
     if backend == "host":
         return HostComm(rdzv)
-    # RCCL, agreed on by all ranks: if the communicator cannot be created on some rank (driver / IPC configuration), every
-    # rank drops to the host communicator together instead of leaving the others waiting in a collective.  The choice is
-    # visible in `.backend` and in `.fallback_reason`; ADVNTR_COMM_FALLBACK=0 turns the fallback into an error.
+    # RCCL, agreed on by all ranks.  When it cannot be used (librccl missing, driver / IPC configuration) every rank learns
+    # so at the same point of the same sequence of rendezvous steps, and the job ENDS with an error on every rank -- a gather
+    # through host files is not the path this package is about.  ADVNTR_COMM_FALLBACK=1 (explicitly) lets the ranks drop to
+    # the host communicator together instead; the choice is then visible in `.backend` and `.fallback_reason`.
     c, err = None, b""
     try:
         c = RcclComm(rdzv)
-    except Exception as e:          # noqa: BLE001 -- whatever went wrong is reported, not swallowed
+    except CommSetupError as e:     # raised on every rank alike: nobody is inside a collective
+        err = str(e).encode("utf-8", "replace")
+    except Exception as e:          # noqa: BLE001 -- this rank's communicator failed after the others may have entered theirs
         err = ("rank %d: %s" % (rank, e)).encode("utf-8", "replace")
     failures = [x for x in rdzv.allgather(err) if x]
     if not failures:
         return c
-    if c is not None:
+    if c is not None and c._h:
         c._lib.load().advntr_comm_destroy(c._h)
         c._h = None
     reason = failures[0].decode("utf-8", "replace")
-    if os.environ.get("ADVNTR_COMM_FALLBACK", "1") == "0":
-        raise RuntimeError("RCCL communicator could not be created: " + reason)
+    if os.environ.get("ADVNTR_COMM_FALLBACK", "0") != "1":
+        rdzv.close()
+        raise RuntimeError("RCCL communicator could not be created (%s); set ADVNTR_COMM_FALLBACK=1 to gather through the "
+                           "host communicator instead" % reason)
     import sys
     if rank == 0:
-        sys.stderr.write("advntr_amd.comm: RCCL unavailable (%s); the result gather goes through the host communicator\n" % reason)
+        sys.stderr.write("advntr_amd.comm: RCCL unavailable (%s); ADVNTR_COMM_FALLBACK=1: the result gather goes through "
+                         "the host communicator\n" % reason)
     h = HostComm(rdzv)
     h.fallback_reason = reason
     return h

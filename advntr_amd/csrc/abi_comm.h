@@ -34,10 +34,18 @@ RcclApi *rccl_api()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // ADVNTR_RCCL_LIB names the library to load (an RCCL build outside the loader's path); by default the usual names
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names)
-            if ((api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!api.handle) { api.error = std::string("dlopen(librccl.so) failed: ") + dlerror(); return; }
+        const char *given = getenv("ADVNTR_RCCL_LIB");
+        if (given && *given) api.handle = dlopen(given, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char *n : names)
+                if ((api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!api.handle) {
+            const char *why = dlerror();
+            api.error = std::string("dlopen(") + (given && *given ? given : "librccl.so") + ") failed: " + (why ? why : "?");
+            return;
+        }
         auto sym = [&](const char *name) {
             void *p = dlsym(api.handle, name);
             if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + name;
@@ -71,6 +79,8 @@ struct advntr_comm {
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t staged = nullptr;            // the records of the pass to gather sit in the staging buffers
+    hipEvent_t g0 = nullptr, g1 = nullptr;  // around the gather on `stream` (timing: advntr_comm_last_gather_ms)
+    float last_gather_ms = -1.f;
     double *d_stage_logp = nullptr;         // this rank's records, copied out of the batch so that the next pass may
     int32_t *d_stage_sum = nullptr;         // overwrite the batch's arrays while the gather is still in flight
     double *d_all_logp = nullptr;           // root: every rank's records, rank after rank
@@ -97,6 +107,15 @@ struct advntr_comm {
     }
 };
 
+// Can this process use RCCL at all (library found, every entry point resolved)?  No GPU call, no collective: what the ranks
+// tell each other BEFORE any of them enters ncclCommInitRank.
+extern "C" int advntr_comm_available(void)
+{
+    RcclApi *api = rccl_api();
+    if (!api->error.empty()) return fail(ADVNTR_ERR_DEVICE, "%s", api->error.c_str());
+    return ADVNTR_OK;
+}
+
 extern "C" int advntr_comm_unique_id(uint8_t *id128)
 {
     if (!id128) return fail(ADVNTR_ERR_ARG, "advntr_comm_unique_id: null buffer");
@@ -118,6 +137,8 @@ extern "C" void advntr_comm_destroy(advntr_comm *C)
                     (void *)C->d_bytes, (void *)C->d_small})
         if (p) (void)hipFree(p);
     if (C->staged) (void)hipEventDestroy(C->staged);
+    if (C->g0) (void)hipEventDestroy(C->g0);
+    if (C->g1) (void)hipEventDestroy(C->g1);
     if (C->stream) (void)hipStreamDestroy(C->stream);
     delete C;
 }
@@ -138,6 +159,8 @@ extern "C" advntr_comm *advntr_comm_create(int32_t rank, int32_t world, const ui
         RCCL_TRY(api->CommInitRank(&C->comm, world, id, rank));
         HIP_TRY(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&C->staged, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&C->g0));
+        HIP_TRY(hipEventCreate(&C->g1));
         HIP_TRY(hipMalloc((void **)&C->d_small, ((size_t)world + 2) * sizeof(int64_t)));
         return ADVNTR_OK;
     }();
@@ -262,6 +285,11 @@ extern "C" int advntr_comm_gather_results_start(advntr_comm *C, advntr_batch *B,
     }
     HIP_TRY(hipEventRecord(C->staged, B->stream));
     HIP_TRY(hipStreamWaitEvent(C->stream, C->staged, 0));
+    HIP_TRY(hipEventRecord(C->g0, C->stream));
+    // RCCL's send / receive kernels need a few workgroup slots.  The scoring kernels are persistent -- their workgroups stay
+    // until the pass is done and fill every compute unit's registers --, so with peers the passes that follow leave a few
+    // slots unclaimed: the gather of pass i then runs beside pass i + 1 instead of behind it (1 % of the slots)
+    if (C->world > 1) B->col.reserve_workgroups = 8;
     // both arrays in one group: one RCCL launch per rank and pass
     std::vector<int64_t> bytes_l(C->world), bytes_s(C->world);
     for (int r = 0; r < C->world; ++r) {
@@ -277,6 +305,7 @@ extern "C" int advntr_comm_gather_results_start(advntr_comm *C, advntr_batch *B,
     RCCL_TRY(ge);
     if ((rc = comm_gatherv_own(C, root, C->d_stage_logp, C->d_all_logp, bytes_l.data()))) return rc;
     if ((rc = comm_gatherv_own(C, root, C->d_stage_sum, C->d_all_sum, bytes_s.data()))) return rc;
+    HIP_TRY(hipEventRecord(C->g1, C->stream));
     C->counts.assign(counts, counts + C->world);
     C->root = root;
     C->in_flight = true;
@@ -299,6 +328,17 @@ extern "C" int advntr_comm_gather_results_finish(advntr_comm *C, double *out_log
             HIP_TRY(hipMemcpyAsync(out_summary, C->d_all_sum, total * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, C->stream));
     }
     HIP_TRY(hipStreamSynchronize(C->stream));
+    if (hipEventElapsedTime(&C->last_gather_ms, C->g0, C->g1) != hipSuccess) C->last_gather_ms = -1.f;
+    return ADVNTR_OK;
+}
+
+// Milliseconds the gather finished last spent on the communicator's stream, from the moment its pass's records were
+// staged to the arrival of the last record (HIP events): the transfer alone when it ran beside the next pass's kernels,
+// about a whole pass when it had to wait for them.  -1 before the first gather.
+extern "C" int advntr_comm_last_gather_ms(const advntr_comm *C, float *ms)
+{
+    if (!C || !ms) return fail(ADVNTR_ERR_ARG, "advntr_comm_last_gather_ms: bad argument");
+    *ms = C->last_gather_ms;
     return ADVNTR_OK;
 }
 

@@ -21,6 +21,8 @@ struct ColumnLaunch {
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
     int rows_depth = 1;                     // reads per lane group of the deepest row-blocked tile
+    int reserve_workgroups = 0;             // resident workgroup slots the launches leave unclaimed (a multi-GPU run's
+                                            // result gather runs beside the next pass: abi_comm.h)
     std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,
                                             // [8] = row-blocked kernel for reads of more than 155 bases (row tiles)
     ColTile *d_tiles[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -46,7 +48,7 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     if (cl.lds_bytes + 16 > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
@@ -71,7 +73,7 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.rows_depth = cl.rows_depth;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -94,7 +96,7 @@ static inline void column_launch_rows_long(const ColumnLaunch &cl, const BatchAr
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     if (cl.lds_bytes + 16 > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_long_kernel<ROWS_LONG_R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
@@ -117,7 +119,7 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.ring = cl.ring;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_columns_stream_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -145,7 +147,7 @@ static inline hipError_t column_launch_fwd(const ColumnLaunch &cl, const BatchAr
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)forward_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -168,7 +170,7 @@ static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const Ba
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
-    const int grid = std::min(cl.grid, g.n_tiles);
+    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
     const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

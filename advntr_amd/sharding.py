@@ -5,7 +5,7 @@ ranks, no data-path collective, one gather of the per-read result records to ran
 HostComm for ranks that share a GPU, and any adapter with the same methods in tests (tests/test_sharding_gloo.py
 drives them over a gloo process group).  Nothing here imports torch.  The reference has no counterpart (it scores
 loci serially, /root/reference/advntr/genome_analyzer.py:280)."""
-import pickle
+import json
 
 import numpy as np
 
@@ -51,8 +51,9 @@ def gather_records(comm, read_ids, logp, summary, dst=0):
 
 def run_sharded(work, fn, comm=None, dst=0):
     """Locus-sharded execution of a per-locus job: every rank takes its LPT share of range(len(work)), calls
-    fn(indices) -> list of picklable results (one per index, same order) and the results come back to rank `dst` in
-    index order (None elsewhere).  One ragged gather at the end; with no communicator (single process) it just runs fn
+    fn(indices) -> list of results (one per index, same order; text rows or anything else JSON can carry) and the
+    results come back to rank `dst` in index order (None elsewhere).  The rows travel as JSON text -- a blob handed over
+    by another process is parsed, never executed.  One ragged gather at the end; with no communicator (single process) it just runs fn
     over everything.  This is how `python -m advntr_amd genotype` runs with one process per GPU."""
     n = len(work)
     if comm is None or comm.world <= 1:
@@ -61,11 +62,14 @@ def run_sharded(work, fn, comm=None, dst=0):
     results = list(fn(mine))
     if len(results) != len(mine):
         raise ValueError("run_sharded: fn returned %d results for %d indices" % (len(results), len(mine)))
-    parts = comm.gather_bytes(pickle.dumps(list(zip(mine, results)), protocol=pickle.HIGHEST_PROTOCOL), dst)
+    parts = comm.gather_bytes(json.dumps([mine, results]).encode("utf-8"), dst)
     if comm.rank != dst:
         return None
     out = [None] * n
     for blob in parts:
-        for i, r in pickle.loads(blob):
-            out[i] = r
+        idx, res = json.loads(bytes(blob).decode("utf-8"))
+        if len(idx) != len(res):
+            raise ValueError("run_sharded: a rank sent %d results for %d indices" % (len(res), len(idx)))
+        for i, r in zip(idx, res):
+            out[int(i)] = r
     return out

@@ -62,6 +62,11 @@ def parse_args(argv=None):
                     help="c1 at --gpus 1: leave out the `c2` and `end_to_end` sub-records (the 6719-locus target configuration)")
     ap.add_argument("--c2-loci", type=int, default=6719, help="loci of the `c2` / `end_to_end` sub-records")
     ap.add_argument("--dry-run", action="store_true", help="plan + rendezvous only, no GPU work (host communicator)")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0,
+                    help="--gpus N > 1 started without a launcher: seconds after which the ranks are ended and the status is non-zero")
+    ap.add_argument("--fault", default=None,
+                    help="fault injection for the launcher's tests: 'exit:R' makes rank R leave with status 3 before the "
+                         "rendezvous, 'hang:R' makes it sleep instead of joining")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes every call's (global id, logp, summary), gathered from all ranks after the timed "
                          "region, to this .npz (parity of an N-rank run with a 1-rank run: tests/test_gpu_parity.py)")
@@ -72,34 +77,54 @@ def parse_args(argv=None):
 # launcher: N ranks as child processes (only when no launcher set RANK for us)
 # ------------------------------------------------------------------------------------------------
 def spawn_ranks(args, argv):
+    """Start the N ranks as children, forward rank 0's line, exit with their status.  The children are watched together:
+    the first one to fail, or the overall deadline (--launch-timeout), ends the job -- the children this process started
+    are killed (exactly those) and the status is non-zero; a rank left waiting in a collective for a peer that is gone
+    must not keep the launcher alive."""
+    import shutil
     import socket
     import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    rdzv = tempfile.mkdtemp(prefix="advntr_rdzv_")
+    rdzv = tempfile.mkdtemp(prefix="advntr_rdzv_")             # mode 0700, this launch's alone
+    fd, out_path = tempfile.mkstemp(prefix="advntr_rank0_")    # (not inside rdzv: rank 0 removes that directory when it leaves)
+    os.close(fd)
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ADVNTR_RDZV_DIR=rdzv)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                                       # the exact child we started
+    with open(out_path, "wb") as out0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), ADVNTR_RDZV_DIR=rdzv)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + args.launch_timeout
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = bad[0][1], "rank %d exited with status %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc, why = 124, "the ranks did not finish within %.0f s (--launch-timeout)" % args.launch_timeout
+            break
+        time.sleep(0.05)
+    if why is not None:
+        sys.stderr.write("bench.py: %s; ending the other ranks\n" % why)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                       # the exact children started above
+        for p in procs:
             p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+    with open(out_path, "rb") as fh:
+        sys.stdout.write(fh.read().decode())
     sys.stdout.flush()
-    import shutil
+    os.unlink(out_path)
     shutil.rmtree(rdzv, ignore_errors=True)
-    return rc
+    return rc or 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -190,6 +215,13 @@ def main(argv=None):
 
     from advntr_amd import comm as comm_mod
     rank, local_rank, world = comm_mod.env_world()
+    if args.fault:
+        kind, _, who = args.fault.partition(":")
+        if int(who or -1) == rank:
+            if kind == "exit":
+                return 3
+            if kind == "hang":
+                time.sleep(10 ** 6)
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; using %d\n" % (args.gpus, world, world))
     workload = args.workload or ("c1" if world == 1 else "c3")
@@ -306,6 +338,7 @@ def main(argv=None):
         if use_gather:
             if state["pending"]:                            # the previous gather has had a whole pass to finish
                 comm.gather_results_finish(fetch=False)
+                state["gather_ms"] = comm.last_gather_ms()
             comm.gather_results_start(batch, counts, root=0)      # queued behind this pass; the next pass overlaps it
             state["pending"] = True
         elif host_gather:
@@ -316,6 +349,7 @@ def main(argv=None):
         if state["pending"]:
             out = comm.gather_results_finish(fetch=fetch)
             state["pending"] = False
+            state["gather_ms"] = comm.last_gather_ms()
         return out
 
     for _ in range(args.warmup):
@@ -350,7 +384,10 @@ def main(argv=None):
     per_rank = None
     if comm:
         rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
-                          "kernel_ms": kernel_ms, "model_build_s": t_build}).encode()
+                          "kernel_ms": kernel_ms, "model_build_s": t_build,
+                          # the last gather of the timed region on the communicator's stream (HIP events): the transfer alone
+                          # when it ran beside the next pass, about a pass when it had to wait for that pass's kernels
+                          "gather_ms": state.get("gather_ms")}).encode()
         parts_json = comm.gather_bytes(rec, 0)
         if rank == 0:
             per_rank = [json.loads(p) for p in parts_json]
@@ -421,6 +458,10 @@ def main(argv=None):
                                  "roof that actually binds this max-plus recurrence is fp64 VALU issue -> bound_actual"},
         }
         if comm:
+            # what carried the gather, at the top level of the line: "rccl", or "host" when ADVNTR_COMM_FALLBACK=1 let the
+            # ranks drop to the file rendezvous (without that variable a job whose RCCL cannot be set up ends with an error)
+            out["comm"] = comm.backend
+            out["rccl"] = comm.backend == "rccl"
             out["config"]["comm"] = comm.backend if comm.fallback_reason is None else "host (RCCL unavailable: %s)" % comm.fallback_reason
             out["config"]["world_size_seen_by_comm"] = comm.world
             out["config"]["per_rank"] = per_rank

@@ -266,6 +266,10 @@ int advntr_genotype_illumina(const int32_t *summaries, const int64_t *locus_off,
  * socket: advntr_amd/comm.py); every rank then calls advntr_comm_create on its own device.  librccl.so is loaded on
  * first use.  counts[] arrays have one entry per rank and must be the same on every rank.                        */
 typedef struct advntr_comm advntr_comm;
+/* ADVNTR_OK if librccl (ADVNTR_RCCL_LIB, or the loader's librccl.so) loads with every entry point this file needs; no GPU
+ * call, no collective.  ncclCommInitRank only returns when EVERY rank has called it, so the ranks exchange this answer
+ * first (advntr_amd/comm.py) and nobody enters the collective when somebody cannot.                               */
+int advntr_comm_available(void);
 int advntr_comm_unique_id(uint8_t *id128);
 advntr_comm *advntr_comm_create(int32_t rank, int32_t world, const uint8_t *id128);   /* NULL on error */
 void advntr_comm_destroy(advntr_comm *comm);
@@ -279,6 +283,10 @@ int advntr_comm_barrier(advntr_comm *comm);
  * (host, sum(counts) records in rank order, either may be NULL) receive everything.                              */
 int advntr_comm_gather_results_start(advntr_comm *comm, advntr_batch *batch, int32_t root, const int64_t *counts);
 int advntr_comm_gather_results_finish(advntr_comm *comm, double *out_logp, int32_t *out_summary);
+/* milliseconds the gather finished last took on the communicator's stream, from the staging of its pass's records to
+ * the last record's arrival (HIP events): the transfer alone if it ran beside the next pass's kernels, about a pass if it
+ * had to wait for them (with peers the batch's later launches leave 8 workgroup slots unclaimed for RCCL's kernels) */
+int advntr_comm_last_gather_ms(const advntr_comm *comm, float *ms);
 /* ragged gather of host byte strings through the devices (the genotype driver's per-locus result rows):
  * counts[r] = bytes of rank r; dst (root only) receives them rank after rank.                                   */
 int advntr_comm_gather_bytes(advntr_comm *comm, int32_t root, const void *src, const int64_t *counts, void *dst);

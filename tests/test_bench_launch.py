@@ -41,3 +41,24 @@ def test_single_process_default_is_c1():
                          check=True, timeout=300).stdout
     d = _line(out)
     assert d["n_gpus"] == 1 and d["config"]["workload"] == "c1" and d["scaling"] == "weak"
+
+
+def test_a_rank_that_exits_early_ends_the_job_with_an_error():
+    """One rank leaves before the rendezvous, the other waits for it: the launcher sees the failure, ends the waiting
+    rank (a child it started) and exits non-zero, long before any rendezvous timeout."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--loci", "24",
+                        "--fault", "exit:1"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-400:])
+    assert b"rank 1 exited with status 3" in p.stderr
+    assert time.time() - t0 < 120
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith("{")]       # no line that looks like a result
+
+
+def test_a_hanging_rank_is_ended_at_the_launch_deadline():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--loci", "24",
+                        "--fault", "hang:0", "--launch-timeout", "8"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 124, (p.returncode, p.stderr[-400:])
+    assert b"--launch-timeout" in p.stderr

@@ -166,6 +166,7 @@ def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
     d2 = _bench(common + ["--gpus", "2", "--dump-records", two], env=dict(os.environ, ADVNTR_DIST_BACKEND="host"))
     assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["scaling"] == "strong"
     assert d2["config"]["comm"] == "host" and len(d2["config"]["per_rank"]) == 2
+    assert d2["comm"] == "host" and d2["rccl"] is False
     assert sum(d2["config"]["calls_per_rank"]) == d1["config"]["calls_this_rank"]
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a["ids"], np.arange(len(a["ids"]))) and np.array_equal(b["ids"], a["ids"])
@@ -182,6 +183,8 @@ def test_c3_rccl_communicator_world_size_1(tmp_path):
                ADVNTR_RDZV_DIR=str(tmp_path / "rdzv"))
     d = _bench(common + ["--dump-records", rec], env=env)
     assert d["config"]["comm"] == "rccl" and d["config"]["world_size_seen_by_comm"] == 1
+    assert d["comm"] == "rccl" and d["rccl"] is True                      # at the top level of the line
+    assert d["config"]["per_rank"][0]["gather_ms"] is not None and d["config"]["per_rank"][0]["gather_ms"] >= 0.0
     _bench(common + ["--dump-records", ref])
     a, b = np.load(rec), np.load(ref)
     assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])

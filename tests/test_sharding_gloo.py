@@ -10,6 +10,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 
 
 class GlooComm(object):
@@ -212,3 +213,92 @@ def test_product_imports_no_torch():
         if re.search(r"^\s*(import|from)\s+torch\b", open(path).read(), re.M):
             offenders.append(path)
     assert offenders == []
+
+
+def _rccl_missing_worker(rank, world, directory, fallback, q):
+    """init_from_env with an RCCL library that cannot be loaded: no GPU is touched before the ranks have agreed."""
+    import time
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT="29999", ADVNTR_RDZV_DIR=directory, ADVNTR_RCCL_LIB="/nonexistent/librccl.so")
+    if fallback:
+        os.environ["ADVNTR_COMM_FALLBACK"] = "1"
+    else:
+        os.environ.pop("ADVNTR_COMM_FALLBACK", None)
+    from advntr_amd import comm
+    t0 = time.time()
+    try:
+        c = comm.init_from_env(set_device=False)
+    except RuntimeError as e:
+        q.put((rank, "error", "librccl" in str(e) or "dlopen" in str(e), time.time() - t0))
+        return
+    ok = c.backend == "host" and c.fallback_reason is not None and c.allgather_i64(rank) == list(range(world))
+    c.close()
+    q.put((rank, "host", bool(ok), time.time() - t0))
+
+
+@pytest.mark.parametrize("fallback", [False, True])
+def test_missing_rccl_is_agreed_on_by_all_ranks_without_waiting(tmp_path, fallback):
+    """rank 0 used to raise before its broadcast and leave the others in a 900 s wait.  Every rank now makes
+    the same rendezvous calls; without ADVNTR_COMM_FALLBACK=1 all of them end with an error (in seconds), with it they drop
+    to the host communicator together."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    d = str(tmp_path / "rdzv")
+    procs = [ctx.Process(target=_rccl_missing_worker, args=(r, 2, d, fallback, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert [g[0] for g in got] == [0, 1]
+    assert all(g[1] == ("host" if fallback else "error") and g[2] for g in got), got
+    assert all(g[3] < 60 for g in got), got
+
+
+def test_rendezvous_directory_must_be_this_users_alone(tmp_path):
+    from advntr_amd import comm
+    d = tmp_path / "open_to_all"
+    d.mkdir(mode=0o755)
+    os.chmod(str(d), 0o755)
+    with pytest.raises(PermissionError):
+        comm.FileRendezvous(0, 1, str(d))
+    f = tmp_path / "not_a_directory"
+    f.write_text("x")
+    with pytest.raises((PermissionError, FileExistsError, NotADirectoryError)):
+        comm.FileRendezvous(0, 1, str(f))
+    fresh = comm.FileRendezvous(0, 1, str(tmp_path / "fresh"))
+    assert (os.stat(fresh.dir).st_mode & 0o777) == 0o700
+    # the default name tells one launch from the next: launcher pid AND its start time, port, run id, restart count
+    os.environ["TORCHELASTIC_RESTART_COUNT"] = "0"
+    a = comm._launcher_identity()
+    os.environ["TORCHELASTIC_RESTART_COUNT"] = "1"
+    b = comm._launcher_identity()
+    os.environ.pop("TORCHELASTIC_RESTART_COUNT")
+    assert a != b and str(os.getppid()) in a
+    fresh.close()
+
+
+def test_host_gather_results_with_a_rank_that_holds_no_reads(tmp_path):
+    """reshape(0, -1) of an empty summary block raised on the root."""
+    from advntr_amd import comm
+
+    class FakeBatch(object):
+        def __init__(self, n):
+            self.n = n
+
+        def fetch(self):
+            return np.arange(self.n, dtype=np.float64), np.arange(8 * self.n, dtype=np.int32).reshape(self.n, 8)
+
+    c = comm.HostComm(comm.FileRendezvous(0, 1, str(tmp_path / "r")))
+    logp, summ = c.gather_results(FakeBatch(0), [0])
+    assert logp.shape == (0,) and summ.shape == (0, 8)
+    logp, summ = c.gather_results(FakeBatch(3), [3])
+    assert logp.tolist() == [0.0, 1.0, 2.0] and summ.shape == (3, 8)
+    c.close()
+
+
+def test_run_sharded_carries_rows_as_json_not_pickle():
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "advntr_amd", "sharding.py")).read()
+    assert "pickle" not in src
