@@ -280,14 +280,26 @@ def _numpy_exp_loop():
         return _NUMPY_EXP_LOOP
     _NUMPY_EXP_LOOP = None
     try:
+        import sys
+        import sysconfig
         u = np.exp
         base, ptr_size = id(u), ctypes.sizeof(ctypes.c_void_p)
-        if ptr_size != 8 or not isinstance(u, np.ufunc):
+        # the struct offsets below are those of a release build of CPython (no Py_DEBUG object header, no free-threaded
+        # header) with NumPy 1.x / 2.x on a 64-bit platform; anything else takes the callback
+        if (ptr_size != 8 or not isinstance(u, np.ufunc) or sys.implementation.name != "cpython"
+                or sysconfig.get_config_var("Py_DEBUG") or sysconfig.get_config_var("Py_GIL_DISABLED")
+                or hasattr(sys, "gettotalrefcount") or int(np.__version__.split(".")[0]) not in (1, 2)
+                or os.environ.get("ADVNTR_NUMPY_EXP_LOOP", "1") == "0"):
             return None
         nin, nout, nargs, _identity = (ctypes.c_int * 4).from_address(base + 16)
         ntypes = ctypes.c_int.from_address(base + 48).value
-        name = ctypes.c_char_p.from_address(base + 56).value
-        if (nin, nout, nargs, ntypes, name) != (1, 1, 2, u.ntypes, b"exp"):
+        if (nin, nout, nargs, ntypes) != (1, 1, 2, u.ntypes):        # the integers first: no pointer is followed before they fit
+            return None
+        name_ptr = ctypes.c_void_p.from_address(base + 56).value
+        if not name_ptr:
+            return None
+        name = ctypes.string_at(name_ptr, 3)
+        if name != b"exp":
             return None
         codes = {"e": 23, "f": 11, "d": 12, "g": 13, "F": 14, "D": 15, "G": 16, "O": 17}
         want = [(codes.get(t[0], -1), codes.get(t[-1], -1)) for t in u.types]

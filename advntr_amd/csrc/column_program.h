@@ -31,7 +31,10 @@
 #define COL_FLAG_SINK 2u      // b_c := accumulator (fan-in from earlier backbone states)
 #define COL_MAX_SINKS 4
 #define COL_MAX_READ 256      // rows handled in registers: 4 chunks of 64 lanes (one row tile)
-#define COL_MAX_LONG_READ (1 << 20)  // longer reads are row-tiled: 256 rows per tile with a seam row in HBM
+#define COL_MAX_LONG_READ (1 << 17)  // longer reads are row-tiled: 256 rows per tile with a seam row in HBM.  The bound is a
+                                     // constant, not a structure: 131 072 bases is ten times what the reference can hand
+                                     // over (reads are trimmed to the VNTR + 100-base flanks, VNTRs are capped at 10 kb:
+                                     // vntr_finder.py:362,415, models.py:164,174) and what the GPU suite covers (100 000)
 
 struct ColClass {             // 11 doubles = 88 B: an odd multiple of 8 B, so records that differ by less than 32
                               // classes never share an LDS bank at the same field (64 banks x 4 B for ds_read_b64)

@@ -850,7 +850,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             }
             const int kmax = std::min(4, (n_max_col + 63) / 64);
             const int TL = 64 * COL_LONG_K;
-            const int64_t row_tiles = n_max_col > COL_MAX_READ ? (n_max_col + TL - 1) / TL : 0;
+            // (the anti-diagonal kernel's row-tiled slabs only when some read really goes there: by default longer reads take
+            // the tiled row-blocked kernel, whose slabs are sized below)
+            const int64_t row_tiles = (n_max_col > COL_MAX_READ && !C.tiles[4].empty()) ? (n_max_col + TL - 1) / TL : 0;
             const int64_t short_bp = (int64_t)(64 * kmax + C.nc_max) * (64 * kmax), long_bp = row_tiles * (int64_t)(TL + C.nc_max) * TL;
             C.bp_stride = (std::max(short_bp, long_bp) + 255) & ~int64_t(255);
             C.rown_stride = 2 * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
@@ -876,6 +878,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
         const int64_t bp_budget = (int64_t)(free_b / 10 * 6) + (int64_t)g_cache.cached[B->device];
         while (C.grid > 1 && (int64_t)C.grid * COL_WAVES * C.bp_stride > bp_budget) C.grid = (C.grid + 1) / 2;
+        if ((int64_t)COL_WAVES * C.bp_stride > bp_budget)
+            return fail(ADVNTR_ERR_TOO_LARGE, "batch: the back-pointers of its longest read (%d bases on a %d-column model) take "
+                        "%lld B per wavefront, %lld B for one workgroup; %lld B of device memory can be had", n_max_col, C.nc_max,
+                        (long long)C.bp_stride, (long long)COL_WAVES * C.bp_stride, (long long)bp_budget);
         C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * (rows_groups > 1 ? C.rows_depth + 1 : 1) * COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
