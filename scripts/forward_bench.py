@@ -1,15 +1,30 @@
-import sys, time, numpy as np
+"""Model.log_probability on the bench batch (100 000 REF150 reads of 150 bases), resident in HBM: advntr_batch_forward_timed
+(HIP events on the launch stream), the one-shot call from host buffers, and the agreement of the two.  Run under
+`rocprofv3 --kernel-trace --stats` this is the kernel-trace summary of forward_rows_kernel<5, 2> alone.
+    python scripts/forward_bench.py [n_reads]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.')
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import __graft_entry__ as e; e.build()
+import __graft_entry__ as e
+e.build()
 from advntr_amd import _lib, workloads
-loc = workloads.ref150()
-reads = workloads.make_reads(np.random.default_rng(1), loc, 100000, 150)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+locus = workloads.ref150()
+reads = workloads.make_reads(np.random.default_rng(20240601), locus, n, 150)
 bases, off = _lib.encode_reads(reads)
-dm = loc.model.device_model()
-_lib.forward_batch([dm], bases[:off[100]], off[:101], np.zeros(100, np.int32))
-t = time.perf_counter(); lp = _lib.forward_batch([dm], bases, off, np.zeros(len(reads), np.int32)); dt = time.perf_counter() - t
-print("forward, column program (one-shot call incl. PCIe/alloc): %d reads in %.1f ms -> %.0f reads/s" % (len(reads), dt * 1e3, len(reads) / dt))
-sub = 20000
-t = time.perf_counter(); lg = _lib.forward_batch([dm], bases[:off[sub]], off[:sub + 1], np.zeros(sub, np.int32), flags=_lib.FLAG_FORCE_GENERIC); dt = time.perf_counter() - t
-print("forward, generic kernel: %d reads in %.1f ms -> %.0f reads/s; max rel diff vs column %.2e" % (sub, dt * 1e3, sub / dt, float(np.max(np.abs(lg - lp[:sub]) / np.abs(lg)))))
+dm = locus.model.device_model()
+which = np.zeros(n, np.int32)
+B = _lib.DeviceBatch([dm], bases, off, which, flags=_lib.FLAG_NO_SUMMARY)
+B.forward(); B.sync()
+ms = B.forward_timed(10)
+lp, _ = B.fetch()
+t0 = time.perf_counter()
+one = _lib.forward_batch([dm], bases, off, which)
+dt = time.perf_counter() - t0
+assert np.array_equal(lp, one)
+cells = float(n) * 150 * dm.n_columns()
+print("forward_rows kernel %.3f ms per %d reads = %.2f M reads/s; %.1f TFLOP/s at 11 FMA per cell; one-shot call %.2f ms"
+      % (ms, n, n / ms / 1e3, cells * 22 / (ms * 1e-3) / 1e12, dt * 1e3))
+B.close()

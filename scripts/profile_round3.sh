@@ -1,0 +1,53 @@
+#!/bin/bash
+# Run on the GPU box: everything profiles/r03_* is made of.  scripts/profile_round3.sh gpurun_out/r03_prof
+# (every profiler pass under its own timeout: a pass that hangs must not eat the call)
+out=$1; root=$(pwd); mkdir -p $root/$out
+python3 bench.py > $out/c1_bench.json 2> $out/c1_bench.err
+python3 bench.py --workload c2 --no-cpu > $out/c2_bench.json 2> $out/c2_bench.err
+python3 bench.py --workload c4 --no-cpu > $out/c4_bench.json 2> $out/c4_bench.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 python3 bench.py --workload c3 --no-cpu > $out/c3_1gpu_rccl_bench.json 2> $out/c3_bench.err
+cd /tmp && export TMPDIR=/tmp
+# the sum-product kernel alone (resident batch, advntr_batch_forward): its own kernel-trace summary
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd.log 2>&1 < /dev/null
+for w in c1 c2 c4; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_$w -- python3 $root/bench.py --workload $w --no-cpu --no-s300 > $root/$out/trace_$w.log 2>&1 < /dev/null
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_${w}_$c -- python3 $root/bench.py --workload $w --no-cpu --no-s300 --steps 1 --warmup 0 > $root/$out/pmc_${w}_$c.log 2>&1 < /dev/null
+  done
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU_ADD_F64 --output-format csv -d $root/$out/pmc_${w}_sq -- python3 $root/bench.py --workload $w --no-cpu --no-s300 --steps 1 --warmup 0 > $root/$out/pmc_${w}_sq.log 2>&1 < /dev/null
+done
+cd $root
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+sections = []
+for w in ("c1", "c2", "c4"):
+    bench = json.load(open("%s/%s_bench.json" % (out, w)))
+    kernel = bench["config"]["kernel"]
+    tot = collections.defaultdict(float); n = collections.defaultdict(int)
+    for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row.get("Kernel_Name", "")
+            if not name.startswith("void " + kernel.split("<")[0]) or kernel not in name: continue
+            tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
+    c = {k: tot[k] / n[k] for k in tot}
+    # one bench run under the profiler launches the dominant kernel (1 step + kernel-only timing runs) several times
+    # on the same batch: per-launch averages
+    sec = {"workload": w, "calls": bench["config"]["calls_this_rank"], "kernel": kernel, "counters_per_launch": c,
+           "launches_averaged": dict(n)}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB here; FETCH_SIZE counts half of the bytes of wide reads on
+        # gfx950 (MI355X_MICROARCH.md, HBM section): x2
+        sec["hbm_bytes_per_launch_fetch_x2"] = (c["WRITE_SIZE"] + 2 * c["FETCH_SIZE"]) * 1024
+    if "SQ_INSTS_VALU" in c:
+        sec["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+    sections.append(sec)
+    for f in glob.glob("%s/trace_%s/**/*kernel_stats.csv" % (out, w), recursive=True):
+        open("%s/%s_kernel_stats.csv" % (out, w), "w").write(open(f).read())
+for f in glob.glob("%s/trace_fwd/**/*kernel_stats.csv" % out, recursive=True):
+    open("%s/forward_rows_kernel_stats.csv" % out, "w").write(open(f).read())
+json.dump({"note": "per-launch counters of the dominant kernel of `python bench.py --workload W` (rocprofv3 --pmc, separate "
+                   "passes); FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (WRITE + 2 x FETCH) x 1024",
+           "sections": sections}, open(out + "/pmc_summary.json", "w"), indent=1)
+print(json.dumps(sections, indent=1)[:3000])
+PY

@@ -199,3 +199,37 @@ def test_best_cells_tying_across_the_two_flank_chunks():
     for p in range(len(pr)):
         assert (int(score[p]), int(begin[p]), int(end[p])) == O.flank_align(reads[pr[p]], flanks[pf[p]]), (pr[p], len(flanks[pf[p]]))
     assert O.flank_align(read, flank[:71]) == (3, 55, 52)
+
+
+@pytest.mark.gpu
+def test_kernel_equals_restatement_at_baseline_config_4_read_lengths():
+    """BASELINE config 4 names reads of 5-15 kb: PacBio-like reads of 5 000-15 000 bases (and one of 20 000) with noisy
+    copies of the 100-base flanks planted once or several times, either strand, against the restatement
+    (oracle/flank_align_oracle.c: score, begin, end equal).  Parity with biopython's pairwise2 stays unpinned (it is not in
+    the image); this covers the kernel's long-read path -- windows of the read past 64 K steps never occur, 15 k rows do."""
+    from advntr_amd import _lib, vntr_finder, workloads
+    rng = np.random.default_rng(415)
+    flanks = [workloads.rand_seq(rng, 100) for _ in range(6)] + [workloads.rand_seq(rng, 37), "ACGT" * 25]
+    reads = []
+    for n in [5000, 6111, 7500, 9000, 10240, 12345, 14999, 15000, 20000]:
+        body = workloads.rand_seq(rng, n)
+        for _ in range(int(rng.integers(2, 6))):
+            f = flanks[int(rng.integers(0, len(flanks)))]
+            c = _noisy(rng, f, float(rng.choice([0.0, 0.1, 0.2, 0.3])))
+            if rng.random() < 0.3:
+                c = vntr_finder.reverse_complement(c)
+            at = int(rng.integers(0, n - len(c)))
+            body = body[:at] + c + body[at + len(c):]
+        # a flank cut off by either end of the read
+        body = flanks[0][40:] + body[60:n - 50] + flanks[1][:50]
+        reads.append(body)
+    pr, pf = [], []
+    for r in range(len(reads)):
+        for f in range(len(flanks)):
+            pr.append(r)
+            pf.append(f)
+    score, begin, end, _ = _lib.flank_align(reads, flanks, pr, pf)
+    for p in range(len(pr)):
+        want = O.flank_align(reads[pr[p]], flanks[pf[p]])
+        assert (int(score[p]), int(begin[p]), int(end[p])) == want, (p, len(reads[pr[p]]), pf[p])
+    assert (score >= 70).sum() >= len(reads)            # the planted copies are found
