@@ -81,6 +81,12 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     std::vector<uint16_t> fps(n_buckets * 8, 0);
     std::vector<int32_t> ids;                                  // short keys: owners
     std::vector<KwfLongRec> long_recs;                         // long-prefix keys: their records, contiguous per key
+    // one keyword length of at most 16 bases: keyword_filter_short_kernel with its own filters and exact table (below)
+    bool short_ok = lengths.size() == 1 && lengths[0].second != KWF_LONG_TAG && lengths[0].first <= 16;
+    for (auto &kv : groups)
+        if (kv.second.size() > 127) short_ok = false;                 // (the short table's count field)
+    std::vector<uint2> short_table;
+    if (short_ok) short_table.assign(slots, make_uint2(0u, KWF_SHORT_EMPTY));
     for (auto &kv : groups) {
         const bool is_long = (kv.first >> 58) == KWF_LONG_TAG;
         if (kv.second.size() > 255) {
@@ -111,7 +117,34 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
             for (int32_t i : kv.second) long_recs.push_back(long_recs_h[i]);
         } else {
             vals[s] = (uint32_t)ids.size() | ((uint32_t)kv.second.size() << 24);
+            if (short_ok) {
+                const uint32_t k32 = (uint32_t)(kv.first & 0xffffffffull);
+                if (kv.second.size() == 1 && (kv.second[0] < 0 || kv.second[0] > 0xffffff)) {
+                    fail(ADVNTR_ERR_TOO_LARGE, "advntr_kwfilter_create: VNTR index %d", kv.second[0]);
+                    return nullptr;
+                }
+                size_t t = kwf_short_slot(kwf_h24b(kwf_h24(k32))) & (uint32_t)(slots - 1);
+                while (short_table[t].y != KWF_SHORT_EMPTY) t = (t + 1) & (slots - 1);
+                short_table[t] = make_uint2(k32, kv.second.size() == 1 ? (KWF_SHORT_ONE | (uint32_t)kv.second[0]) : vals[s]);
+            }
             ids.insert(ids.end(), kv.second.begin(), kv.second.end());
+        }
+    }
+    // one keyword length of at most 16 bases: the two blocked Bloom filters of keyword_filter_short_kernel (LDS: 1 Mbit, two
+    // bits per keyword; L2: a power of two of >= 16 bits per keyword, three bits per keyword)
+    std::vector<uint32_t> bloom, bloom2;
+    if (short_ok) {
+        size_t words2 = KWF_BLOOM_WORDS;
+        while (words2 * 32 < groups.size() * 16 && words2 < ((size_t)1 << 27)) words2 <<= 1;
+        int word_bits = 0;
+        while (((size_t)1 << word_bits) < words2) ++word_bits;
+        bloom.assign(KWF_BLOOM_WORDS, 0u);
+        bloom2.assign(words2, 0u);
+        for (auto &kv : groups) {
+            const uint32_t y = kwf_h24((uint32_t)(kv.first & 0xffffffffull));
+            bloom[y & (KWF_BLOOM_WORDS - 1)] |= kwf_bloom_mask1(y);
+            const uint32_t z = kwf_h24b(y);
+            bloom2[z & (uint32_t)(words2 - 1)] |= kwf_bloom_mask2(z, word_bits);
         }
     }
     advntr_kwfilter *F = new advntr_kwfilter();
@@ -127,7 +160,9 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     void *di = up(ids.data(), ids.size() * 4), *db = up(bitset.data(), bitset.size() * 4);
     void *df = up(fps.data(), fps.size() * 2);
     void *dl = up(long_recs.data(), long_recs.size() * sizeof(KwfLongRec)), *dlb = up(long_bases.data(), long_bases.size());
-    if (!dk || !dv || !di || !db || !df || !dl || !dlb) {
+    void *dbl = up(bloom.data(), bloom.size() * 4), *dbl2 = up(bloom2.data(), bloom2.size() * 4);
+    void *dst = up(short_table.data(), short_table.size() * sizeof(uint2));
+    if (!dk || !dv || !di || !db || !df || !dl || !dlb || !dbl || !dbl2 || !dst) {
         fail(ADVNTR_ERR_DEVICE, "advntr_kwfilter_create: device upload failed");
         advntr_kwfilter_destroy(F);
         return nullptr;
@@ -143,6 +178,9 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     D.table_mask = slots - 1;
     D.keys = (const uint64_t *)dk; D.vals = (const uint32_t *)dv; D.ids = (const int32_t *)di; D.bitset = (const uint32_t *)db;
     D.fp_buckets = (const uint4 *)df; D.bucket_mask = (uint32_t)(n_buckets - 1);
+    D.short_ok = short_ok ? 1 : 0; D.short_bloom = (const uint32_t *)dbl; D.short_l2 = (const uint32_t *)dbl2;
+    D.short_l2_mask = short_ok ? (uint32_t)(bloom2.size() - 1) : 0u;
+    D.short_table = (const uint2 *)dst; D.short_table_mask = short_ok ? (uint32_t)(slots - 1) : 0u;
     return F;
 }
 
@@ -198,10 +236,15 @@ static int kwfilter_scan_spans(advntr_kwfilter *F, const uint8_t *bytes, int64_t
         a.out_read = d_r; a.out_vntr = d_v; a.out_count = d_c; a.n_out = d_n; a.capacity = capacity;
         const int grid = std::max(1, std::min((n_reads + KWF_BLOCK - 1) / KWF_BLOCK, device_cus()));
         const void *kernel = ascii ? (const void *)keyword_filter_kernel<true> : (const void *)keyword_filter_kernel<false>;
+        if (F->dev.short_ok) {        // one keyword length of at most 16 bases
+            const bool wide = F->dev.length[0] >= 15;
+            kernel = ascii ? (wide ? (const void *)keyword_filter_short_kernel<true, true> : (const void *)keyword_filter_short_kernel<true, false>)
+                           : (wide ? (const void *)keyword_filter_short_kernel<false, true> : (const void *)keyword_filter_short_kernel<false, false>);
+        }
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        if (ascii) hipLaunchKernelGGL(keyword_filter_kernel<true>, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
-        else hipLaunchKernelGGL(keyword_filter_kernel<false>, dim3(grid), dim3(KWF_BLOCK), KWF_BITSET_BITS / 8, nullptr, a);
+        void *kargs[] = {(void *)&a};
+        HIP_TRY(hipLaunchKernel(kernel, dim3(grid), dim3(KWF_BLOCK), kargs, KWF_BITSET_BITS / 8, nullptr));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));

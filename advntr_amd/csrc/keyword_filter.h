@@ -44,6 +44,18 @@ struct KwfDevice {
     uint32_t bucket_mask;                    // load per tested position, no probe chain; 2 MiB (L2-resident) at ~320 k keywords
     const KwfLongRec *long_recs;             // keywords longer than 29 bases (the reference's long-read mode cuts two
     const uint8_t *long_bases;               // 80-base flanks per VNTR, vntr_finder.py:151-152), chained off their prefix
+    // keyword sets of ONE length of at most 16 bases (adVNTR's 15-mers): the filters of keyword_filter_short_kernel -- a
+    // blocked Bloom filter of KWF_BITSET_BITS bits for the LDS (two bits of one 32-bit word per keyword) and a second one of
+    // ~16 bits per keyword in L2 (three bits of one word); 0 words: not applicable (several lengths, or longer keywords)
+    const uint32_t *short_bloom;
+    const uint32_t *short_l2;
+    uint32_t short_l2_mask;                  // words - 1
+    int32_t short_ok;
+    // ... and their exact table: {32 bits of packed bases, value} in ONE 8-byte entry, open addressing from a slot the filters'
+    // hash gives; value = KWF_SHORT_ONE | VNTR index for a keyword of one VNTR (no second look-up), first index into ids[] |
+    // count << 24 for a shared one, KWF_SHORT_EMPTY for a free slot
+    const uint2 *short_table;
+    uint32_t short_table_mask;
 };
 
 struct KwfArgs {
@@ -66,6 +78,36 @@ __host__ __device__ __forceinline__ uint64_t kwf_hash(uint64_t k)
     uint32_t y = (x ^ hi) * 0xC2B2AE35u;
     y ^= y >> 16;
     return ((uint64_t)y << 40) | x;
+}
+
+// Hashes of a keyword of at most 16 bases (32 bits of packed bases) for the blocked Bloom filters of
+// keyword_filter_short_kernel: 24-bit multiplies only (full rate on the vector ALU; a 32-bit multiply is a quarter-rate
+// instruction), as selective as murmur's finaliser on the 317 k-keyword set.  First level (LDS, 32 768 words): word = low 15
+// bits, two bits inside the word from the next 2 x 5 bits.  Second level (L2): a second hash of the first, two bits in a word.
+// (The multiplies take the low 24 bits of their operands: bits of a window register above the keyword's 2 L never matter.)
+__host__ __device__ __forceinline__ uint32_t kwf_h24(uint32_t k)
+{
+    // (one round is as selective as two, and as murmur's finaliser, on the 317 k-keyword set: 21.5 % of random 15-mers and of
+    // keywords with one base changed pass the first level either way)
+    const uint32_t a = k & 0xffffffu, b = (k >> 6) & 0xffffffu;
+    uint32_t x = a * 0x9E3779u + b * 0x85EBCBu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t kwf_h24b(uint32_t y)
+{
+    uint32_t z = (y & 0xffffffu) * 0x85EBCBu + (y >> 9);
+    z ^= z >> 15;
+    return z;
+}
+#define KWF_SHORT_EMPTY 0xffffffffu
+#define KWF_SHORT_ONE 0x80000000u
+__host__ __device__ __forceinline__ uint32_t kwf_short_slot(uint32_t z) { return (z & 0xffffffu) * 0x9E3779u + (z >> 8); }
+#define KWF_BLOOM_WORDS (KWF_BITSET_BITS / 32)         // 32 768 words of 32 bits
+__host__ __device__ __forceinline__ uint32_t kwf_bloom_mask1(uint32_t y) { return (1u << ((y >> 15) & 31u)) | (1u << ((y >> 20) & 31u)); }
+__host__ __device__ __forceinline__ uint32_t kwf_bloom_mask2(uint32_t z, int word_bits)
+{
+    return (1u << ((z >> word_bits) & 31u)) | (1u << ((z >> (word_bits + 5 > 27 ? 27 : word_bits + 5)) & 31u));
 }
 
 // fingerprint of a key (odd, never 0 and never the overflow marker) and its bucket in the fingerprint table
@@ -274,6 +316,199 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
         }
         // wave-aggregated output: one atomic per wavefront and slot instead of one per record (a single device-wide
         // counter saturates at ~88 atomics/us, MI355X_MICROARCH "dequeue" row)
+#pragma unroll
+        for (int s = 0; s < KWF_SLOTS; ++s) {
+            const bool need = svid[s] >= 0;
+            const unsigned long long m = __ballot(need);
+            if (m == 0ull) continue;
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(a.n_out, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (need) {
+                const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if ((int64_t)pos < a.capacity) {
+                    a.out_read[pos] = r;
+                    a.out_vntr[pos] = svid[s];
+                    a.out_count[pos] = scnt[s];
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Keyword sets of one length of at most 16 bases (adVNTR's 15-mers: the prefilter of every Illumina run).
+// The general kernel above spends ~105 vector and ~50 scalar instructions per read position (profiles/r02_filter_pmc.json):
+// a 64-bit window kept base by base through per-base branches, a 64-bit hash with three quarter-rate multiplies, two LDS
+// reads, a 16-byte fingerprint bucket compared in registers.  For keywords that fit 32 bits all of it gets cheaper:
+//   * a 64-byte sector of the read becomes four words of 16 two-bit bases and a 64-bit "good base" mask with word-parallel
+//     arithmetic; the window ending at a base is ONE funnel shift (v_alignbit) of two neighbouring words and a mask, and which
+//     windows exist at all (no symbol outside ACGT inside, none before the read's start or past its end) is a handful of
+//     shift-and-and steps per 16 bases -- no per-base branch, no run counter;
+//   * the first-level filter is a BLOCKED Bloom filter (both bits of a keyword in one 32-bit LDS word: one read) on a hash
+//     made of 24-bit multiplies; 21 % of the windows pass it with 317 k keywords in 1 Mbit (a 5 % filter would need two
+//     compute units' LDS: splitting the keywords over groups of workgroups was built and measured -- every group still has to
+//     walk every read, the wavefront-level work doubles and the kernel got slower, 2.8 against 1.5 ms);
+//   * the second level is the same test on a 16-bits-per-keyword filter in L2, four windows' loads in flight together: one
+//     4-byte gather and a mask compare instead of a 16-byte bucket and eight fingerprint compares; 0.2 % of all windows go on
+//     to the exact table.
+// Everything behind that (exact table, tallies, wave-aggregated output) is the general kernel's.
+// WIDE: keywords of 15 or 16 bases -- the window needs no mask before it is hashed.
+template <bool ASCII, bool WIDE>
+__global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t bits[];
+    {
+        const uint4 *src = (const uint4 *)a.f.short_bloom;
+        uint4 *dst = (uint4 *)bits;
+        for (int i = threadIdx.x; i < (int)(KWF_BLOOM_WORDS / 4); i += KWF_BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int L0 = a.f.length[0];
+    const uint32_t mask0 = L0 >= 16 ? 0xffffffffu : ((1u << (2 * L0)) - 1u);
+    const uint64_t tag0 = (uint64_t)a.f.tag[0] << 58;
+    const uint32_t l2_mask = a.f.short_l2_mask;
+    const int l2_bits = 32 - __builtin_clz(l2_mask);                 // bits of the word index (l2_mask = words - 1 >= 32767)
+    for (int r = blockIdx.x * KWF_BLOCK + threadIdx.x; r < a.n_reads; r += gridDim.x * KWF_BLOCK) {
+        const uint8_t *seq = a.bases + a.span_start[r];
+        const int n = (int)(a.span_end[r] - a.span_start[r]);
+        int svid[KWF_SLOTS], scnt[KWF_SLOTS];
+#pragma unroll
+        for (int s = 0; s < KWF_SLOTS; ++s) { svid[s] = -1; scnt[s] = 0; }
+        uint32_t prevP = 0, prevG = 0;           // the 16 bases before the current word, and which of them were good
+        for (int pb = 0; pb < n; pb += 64) {     // one 64-byte sector of the read per outer step
+            uint32_t d[16];
+            if (pb + 64 <= n) {
+                __builtin_memcpy(d, seq + pb, 64);
+            } else {
+#pragma unroll
+                for (int w = 0; w < 16; ++w) {
+                    d[w] = 0;
+                    if (pb + 4 * w + 4 <= n) __builtin_memcpy(&d[w], seq + pb + 4 * w, 4);
+                    else for (int q = 0; pb + 4 * w + q < n; ++q) d[w] |= (uint32_t)seq[pb + 4 * w + q] << (8 * q);
+                }
+            }
+            const int left = n - pb;                                  // bases of the read in this sector and beyond
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (16 * j >= left) break;
+                // 16 bases -> P (two bits per base, first base in the top bits) and G (one bit per base: a base A, C, G, T)
+                uint32_t P = 0, G = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t w = d[4 * j + i];
+                    uint32_t code, wrong;                             // per byte: the base code; non-zero where the byte is no base
+                    if (ASCII) {
+                        const uint32_t x = (w >> 1) & 0x03030303u;
+                        code = x ^ ((x >> 1) & 0x01010101u);          // A 0, C 1, G 2, T 3 (kwf_code_of_ascii)
+                        const uint32_t lo = code & 0x01010101u, hi = (code >> 1) & 0x01010101u, hl = hi & lo;
+                        // the upper-case letter that has this code: 'A' + {0, 2, 6, 19}; anything else in the text is no base
+                        const uint32_t want = 0x41414141u + (lo << 1) + (hi << 2) + (hi << 1) + (hl << 3) + (hl << 1) + hl;
+                        wrong = w ^ want;
+                    } else {
+                        code = w & 0x03030303u;
+                        wrong = w & 0xfcfcfcfcu;
+                    }
+                    // 0x80 in every byte of `wrong` that is zero (exact per byte)
+                    const uint32_t good = ~(((wrong & 0x7f7f7f7fu) + 0x7f7f7f7fu) | wrong | 0x7f7f7f7fu);
+                    const uint32_t p8 = ((code << 6) | (code >> 4) | (code >> 14) | (code >> 24)) & 0xffu;
+                    const uint32_t g4 = ((good >> 4) | (good >> 13) | (good >> 22) | (good >> 31)) & 0xfu;
+                    P = (P << 8) | p8;
+                    G = (G << 4) | g4;
+                }
+                const int here = left - 16 * j;                       // bases of the read from this word on
+                if (here < 16) G &= 0xffffu << (16 - here);           // past the read's end: no base
+                // windows: bit b of `ok` <-> the window that ends at base 15 - b exists (L0 good bases, in the read)
+                const uint32_t c0 = (prevG << 16) | (G & 0xffffu);
+                const uint32_t c1 = c0 & (c0 >> 1), c2 = c1 & (c1 >> 2), c3 = c2 & (c2 >> 4);
+                uint32_t ok = 0xffffu;
+                int done = 0;
+                if (L0 & 16) { ok &= c3 & (c3 >> 8); done = 16; }
+                if (L0 & 8) { ok &= c3 >> done; done += 8; }
+                if (L0 & 4) { ok &= c2 >> done; done += 4; }
+                if (L0 & 2) { ok &= c1 >> done; done += 2; }
+                if (L0 & 1) ok &= c0 >> done;
+                ok &= 0xffffu;
+                if (ok != 0u) {
+                    // first level, the 16 windows of the word, no branch: bit e of `live` <-> the window that ends at base e
+                    // passed the LDS filter
+                    uint32_t live = 0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        // (no mask: the hash takes bits 0 .. 29 of the window, and a keyword of 16 bases is hashed without its
+                        // first base on the host as well)
+                        const uint32_t win = __builtin_amdgcn_alignbit(prevP, P, 2 * (15 - e));
+                        const uint32_t y = kwf_h24(WIDE ? win : (win & mask0));
+                        const uint32_t m = kwf_bloom_mask1(y);
+                        live |= (uint32_t)((bits[y & (KWF_BLOOM_WORDS - 1)] & m) == m) << e;
+                    }
+                    live &= __builtin_bitreverse32(ok) >> 16;
+                    // second level: up to four survivors of a lane per round, their words of the L2 filter loaded together
+                    uint32_t cand = 0;
+                    while (live != 0u) {
+                        int ee[4];
+                        uint32_t zz[4], w2[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            ee[i] = live ? __builtin_ctz(live) : -1;
+                            live &= live - 1u;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ee[i] >= 0) {
+                                zz[i] = kwf_h24b(kwf_h24(__builtin_amdgcn_alignbit(prevP, P, 2 * (15 - ee[i])) & mask0));
+                                w2[i] = a.f.short_l2[zz[i] & l2_mask];
+                            }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (ee[i] >= 0) {
+                                const uint32_t m2 = kwf_bloom_mask2(zz[i], l2_bits);
+                                if ((w2[i] & m2) == m2) cand |= 1u << ee[i];
+                            }
+                    }
+                    // the exact table for what is left (0.2 % of all windows, and the true hits -- two dozen per read that
+                    // comes from a locus, while the wavefront's other lanes wait): two entries of a lane in flight per round,
+                    // one 8-byte entry per look-up, the VNTR in the entry itself when the keyword has one owner
+                    while (cand != 0u) {
+                        int ee[2];
+                        uint32_t kk[2], sl[2];
+                        uint2 ent[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            ee[i] = cand ? __builtin_ctz(cand) : -1;
+                            cand &= cand - 1u;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (ee[i] >= 0) {
+                                kk[i] = __builtin_amdgcn_alignbit(prevP, P, 2 * (15 - ee[i])) & mask0;
+                                sl[i] = kwf_short_slot(kwf_h24b(kwf_h24(kk[i]))) & a.f.short_table_mask;
+                                ent[i] = a.f.short_table[sl[i]];
+                            }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (ee[i] >= 0) {
+                                uint2 en = ent[i];
+                                uint32_t at = sl[i];
+                                for (uint32_t probes = 0; probes <= a.f.short_table_mask && en.y != KWF_SHORT_EMPTY; ++probes) {
+                                    if (en.x == kk[i]) {
+                                        if (en.y & KWF_SHORT_ONE) kwf_tally_one(a, (int)(en.y & 0xffffffu), r, svid, scnt);
+                                        else kwf_tally(a, en.y, r, svid, scnt);
+                                        break;
+                                    }
+                                    at = (at + 1u) & a.f.short_table_mask;
+                                    en = a.f.short_table[at];
+                                }
+                            }
+                    }
+                }
+                prevP = P;
+                prevG = G & 0xffffu;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < KWF_SLOTS; ++s) {
             const bool need = svid[s] >= 0;

@@ -33,11 +33,13 @@ for case in range(n_cases):
     loci, lines = [], []
     pool = []
     lens1 = rng.choice([5, 9, 15, 21, 29, 30, 31, 40, 64], int(rng.integers(2, 9)), replace=False)      # the filter takes up to 8 distinct lengths
+    # one length of at most 16 bases runs on keyword_filter_short_kernel (both its instantiations: 15 / 16 bases and shorter)
+    short_len = int(rng.choice([15, 15, 15, 16, 14, 12, 9, 5, 3, 1]))
     for v in range(n_loci):
         full = seq(int(rng.integers(120, 400)))
         kws = set()
         for _ in range(int(rng.integers(1, 12))):
-            if mode == 0: L = 15
+            if mode == 0: L = short_len
             elif mode == 1: L = int(rng.choice(lens1))
             else: L = int(rng.choice([80, 100, 33]))
             if L > len(full): continue
@@ -45,7 +47,7 @@ for case in range(n_cases):
             kws.add(full[p:p + L])
         if pool and rng.random() < 0.2:               # a string owned by two VNTRs
             kws.add(pool[int(rng.integers(0, len(pool)))])
-        if not kws: kws.add(full[:int(lens1[0]) if mode == 1 else (15 if mode == 0 else 33)])
+        if not kws: kws.add(full[:int(lens1[0]) if mode == 1 else (short_len if mode == 0 else 33)])
         pool.extend(kws)
         loci.append(full)
         lines.append("%d %s" % (1000 + v * 3, " ".join(sorted(kws))))
@@ -70,6 +72,12 @@ for case in range(n_cases):
     got = filtering.run(fasta, keywords, min_matches=5 if mm is None else mm)
     want = F.run_filter(fasta, keywords, min_matches=5 if mm is None else mm)
     assert got == want, ("vs restatement", case, mode, mm)
+    if case % 3 == 0:             # the same through the encoded-reads entry (advntr_kwfilter_scan instead of _scan_text)
+        f = filtering.KeywordFilter.from_text(keywords)
+        recs = [l for l in fasta.split("\n") if l]
+        via_codes = f.select([l[1:] for l in recs[0::2]], recs[1::2], min_matches=5 if mm is None else mm)
+        f.close()
+        assert via_codes == want, ("encoded reads vs restatement", case, mode, mm)
     if have_ref:
         assert got == run_ref(fasta, keywords, mm), ("vs reference binary", case, mode, mm)
         n_ref += 1
