@@ -588,8 +588,9 @@ def genotype_illumina(summaries, locus_off, accuracy_filter=False, is_haploid=Fa
 
 
 def flank_align(reads, flanks, pair_read, pair_flank):
-    """advntr_flank_align: local alignment (1, -1, -1, -1) of flanks[pair_flank[p]] to reads[pair_read[p]].  Returns
-    (score, begin, end) int32 arrays and the kernel time in ms.  Symbols outside ACGT match nothing."""
+    """advntr_flank_align: local alignment (1, -1, -1, -1) of flanks[pair_flank[p]] to reads[pair_read[p]]; a pair_read of
+    len(reads) + r stands for the reverse complement of read r (made on the device).  Returns (score, begin, end) int32
+    arrays and the kernel time in ms.  Symbols outside ACGT match nothing."""
     L = load()
     require_gpu()
     # reads: case folding + encoding on host threads (N -> 254, other symbols -> 255; the library clamps them to "matches

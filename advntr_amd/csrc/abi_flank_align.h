@@ -19,7 +19,7 @@ extern "C" int advntr_flank_align(const uint8_t *bases, const int64_t *read_off,
             return fail(ADVNTR_ERR_TOO_LARGE, "advntr_flank_align: flank %d has %d bases (limit %d)", f,
                         flank_off[f + 1] - flank_off[f], 64 * FA_K);
     for (int p = 0; p < n_pairs; ++p)
-        if (pair_read[p] < 0 || pair_read[p] >= n_reads || pair_flank[p] < 0 || pair_flank[p] >= n_flanks)
+        if (pair_read[p] < 0 || pair_read[p] >= 2 * (int64_t)n_reads || pair_flank[p] < 0 || pair_flank[p] >= n_flanks)
             return fail(ADVNTR_ERR_ARG, "advntr_flank_align: pair %d out of range", p);
     const int64_t total = read_off[n_reads];
     const int32_t ftotal = flank_off[n_flanks];
@@ -43,27 +43,33 @@ extern "C" int advntr_flank_align(const uint8_t *bases, const int64_t *read_off,
         d_bases = take((size_t)total + 16); d_off = take(((size_t)n_reads + 1) * 8);
         d_fb = take((size_t)ftotal + 16); d_fo = take(((size_t)n_flanks + 1) * 4);
         d_pr = take((size_t)n_pairs * 4); d_pf = take((size_t)n_pairs * 4); d_out = take((size_t)n_pairs * 12);
-        if (!d_bases || !d_off || !d_fb || !d_fo || !d_pr || !d_pf || !d_out)
+        void *d_order = take((size_t)n_pairs * 4), *d_next = take(4);
+        if (!d_bases || !d_off || !d_fb || !d_fo || !d_pr || !d_pf || !d_out || !d_order || !d_next)
             return fail(ADVNTR_ERR_DEVICE, "advntr_flank_align: device allocation failed");
         if (total) HIP_TRY(hipMemcpy(d_bases, bases, (size_t)total, hipMemcpyHostToDevice));
-        // any read code above 3 (N = 4 from this repo's hosts, 254 / 255 from advntr_encode_ascii) becomes 4: the kernel's
-        // equality test then never matches it against a flank symbol (flank N is 5 there)
-        if (total) {
-            hipLaunchKernelGGL(fa_clamp_codes_kernel, dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 65535)), dim3(256), 0,
-                               nullptr, (uint8_t *)d_bases, total);
-            HIP_TRY(hipGetLastError());
-        }
         HIP_TRY(hipMemcpy(d_off, read_off, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
         if (ftotal) HIP_TRY(hipMemcpy(d_fb, flank_bases, (size_t)ftotal, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_fo, flank_off, ((size_t)n_flanks + 1) * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_pr, pair_read, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_pf, pair_flank, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+        {   // longest reads first (a counting sort would do; pair counts are modest), taken from a counter on the device
+            std::vector<int32_t> order((size_t)n_pairs);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                const int32_t rx = pair_read[x] % n_reads, ry = pair_read[y] % n_reads;
+                return read_off[rx + 1] - read_off[rx] > read_off[ry + 1] - read_off[ry];
+            });
+            HIP_TRY(hipMemcpy(d_order, order.data(), (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemset(d_next, 0, 4));
+        }
         FaArgs a{};
         a.bases = (const uint8_t *)d_bases; a.read_off = (const int64_t *)d_off;
         a.flank_bases = (const uint8_t *)d_fb; a.flank_off = (const int32_t *)d_fo;
-        a.pair_read = (const int32_t *)d_pr; a.pair_flank = (const int32_t *)d_pf; a.n_pairs = n_pairs;
+        a.pair_read = (const int32_t *)d_pr; a.pair_flank = (const int32_t *)d_pf; a.n_pairs = n_pairs; a.n_reads = n_reads;
         a.out_score = (int32_t *)d_out; a.out_begin = a.out_score + n_pairs; a.out_end = a.out_begin + n_pairs;
-        const int grid = std::max(1, std::min((n_pairs + FA_WAVES - 1) / FA_WAVES, device_cus() * 4));
+        a.order = (const int32_t *)d_order; a.next = (int32_t *)d_next;
+        // eight wavefronts per SIMD (the sweep holds 43 registers): issue-bound work wants them all
+        const int grid = std::max(1, std::min((n_pairs + FA_WAVES - 1) / FA_WAVES, device_cus() * 8));
         HIP_TRY(hipEventRecord(e0, nullptr));
         hipLaunchKernelGGL(flank_align_kernel, dim3(grid), dim3(FA_WAVES * 64), 0, nullptr, a);
         HIP_TRY(hipGetLastError());

@@ -369,7 +369,6 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
     __syncthreads();
     const int L0 = a.f.length[0];
     const uint32_t mask0 = L0 >= 16 ? 0xffffffffu : ((1u << (2 * L0)) - 1u);
-    const uint64_t tag0 = (uint64_t)a.f.tag[0] << 58;
     const uint32_t l2_mask = a.f.short_l2_mask;
     const int l2_bits = 32 - __builtin_clz(l2_mask);                 // bits of the word index (l2_mask = words - 1 >= 32767)
     for (int r = blockIdx.x * KWF_BLOCK + threadIdx.x; r < a.n_reads; r += gridDim.x * KWF_BLOCK) {

@@ -685,26 +685,22 @@ def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, f
     from . import settings
     left = left_flanking_region[-flanking_region_size:]
     right = right_flanking_region[:flanking_region_size]
-    strands = []
-    for s in reads:
-        up = str(s).upper()
-        strands.append(up)
-        strands.append(up.translate(_COMP_STR)[::-1])
-    if not strands:
+    fwd = [str(s).upper() for s in reads]
+    if not fwd:
         return [], []
-    n = len(strands)
-    pair_read = np.repeat(np.arange(n, dtype=np.int32), 2)
-    pair_flank = np.tile(np.array([0, 1], np.int32), n)
-    score, begin, _, _ = _lib.flank_align(strands, [left, right], pair_read, pair_flank)
+    n = len(fwd)
+    # strand k of the reference's loop = read k // 2, reverse strand for odd k; the reverse complements are made on the device
+    # (pair_read = n + read), in Python only for the reads that turn out to span
+    strand_read = np.arange(2 * n, dtype=np.int32) // 2 + (np.arange(2 * n, dtype=np.int32) & 1) * n
+    pair_read = np.repeat(strand_read, 2)
+    pair_flank = np.tile(np.array([0, 1], np.int32), 2 * n)
+    score, begin, _, _ = _lib.flank_align(fwd, [left, right], pair_read, pair_flank)
+    ok = ((score[0::2] > 0) & (score[0::2] >= len(left) * (1 - settings.MAX_ERROR_RATE)) &
+          (score[1::2] > 0) & (score[1::2] >= len(right) * (1 - settings.MAX_ERROR_RATE)) & (begin[1::2] >= begin[0::2]))
     spanning, lengths = [], []
-    for k, seq in enumerate(strands):
-        ls, lb, rs, rb = int(score[2 * k]), int(begin[2 * k]), int(score[2 * k + 1]), int(begin[2 * k + 1])
-        if ls <= 0 or ls < len(left) * (1 - settings.MAX_ERROR_RATE):
-            continue
-        if rs <= 0 or rs < len(right) * (1 - settings.MAX_ERROR_RATE):
-            continue
-        if rb < lb:
-            continue
+    for k in np.flatnonzero(ok).tolist():
+        lb, rb = int(begin[2 * k]), int(begin[2 * k + 1])
+        seq = fwd[k // 2] if not (k & 1) else fwd[k // 2].translate(_COMP_STR)[::-1]
         spanning.append((seq[lb:rb + flanking_region_size], k // 2, bool(k & 1)))
         lengths.append(rb - (lb + flanking_region_size))
     return spanning, lengths

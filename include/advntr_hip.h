@@ -215,7 +215,9 @@ void advntr_built_destroy(advntr_built *built);
  * VNTRFinder.check_if_flanking_regions_align_to_str (/root/reference/advntr/vntr_finder.py:324-365): local alignment
  * (match +1, mismatch -1, gap -1 per base) of flank pair_flank[p] (<= 128 bases) against read pair_read[p], n_pairs at
  * once, one per wavefront.  Reads / flanks as base codes 0..3 (anything else matches nothing), concatenated with
- * offsets.  out_score[p] = best local score (0 = no positive-scoring alignment), out_begin[p] = the `begin` of the
+ * offsets.  pair_read[p] in [n_reads, 2 n_reads) stands for the REVERSE COMPLEMENT of read pair_read[p] - n_reads, made on
+ * the device from the uploaded read (check_if_pacbio_read_spans_vntr tests both strands, :367-371); coordinates are then
+ * positions in the reverse-complemented read.  out_score[p] = best local score (0 = no positive-scoring alignment), out_begin[p] = the `begin` of the
  * first alignment pairwise2 would return (max of the two start indices; -1 if none), out_end[p] = read index of its
  * last aligned base.  PARITY UNPINNED with respect to biopython (absent from the image), see csrc/flank_align.h.     */
 int advntr_flank_align(const uint8_t *bases, const int64_t *read_off, int32_t n_reads, const uint8_t *flank_bases,

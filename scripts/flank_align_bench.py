@@ -23,14 +23,18 @@ for k in range(n_reads):
         at = int(rng.integers(0, n - len(core)))
         s = s[:at] + core + s[at + len(core):]
     reads.append(s)
+# both strands of every read: strand 2 r + 1 = the reverse complement of read r, which the device makes from the uploaded read
+# (pair_read = n_reads + r); the strings below are only what the CPU restatement is given
 strands = []
 for s in reads:
     strands += [s, vntr_finder.reverse_complement(s)]
+strand_read = np.arange(2 * n_reads, dtype=np.int32) // 2 + (np.arange(2 * n_reads, dtype=np.int32) & 1) * n_reads
+pr_dev = np.repeat(strand_read, 2)
 pr = np.repeat(np.arange(len(strands), dtype=np.int32), 2)
 pf = np.tile(np.array([0, 1], np.int32), len(strands))
-_lib.flank_align(strands[:8], [left, right], pr[:16], pf[:16])                      # warm-up
+_lib.flank_align(reads[:8], [left, right], np.arange(16, dtype=np.int32), pf[:16])          # warm-up
 t0 = time.perf_counter()
-score, begin, end, ms = _lib.flank_align(strands, [left, right], pr, pf)
+score, begin, end, ms = _lib.flank_align(reads, [left, right], pr_dev, pf)
 wall = time.perf_counter() - t0
 cells = float(sum(len(strands[r]) for r in pr)) * 100
 bytes_alg = float(sum(len(strands[r]) for r in pr))
@@ -50,10 +54,12 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                                "note": "tier rule (HBM) only: the binding roof is int32 VALU issue, see bound_actual",
                                "bound_actual": {"bound": "valu_int32", "unit": "DP cells/s",
                                                 "achieved": cells / (ms * 1e-3),
-                                                # 37 wave64 VALU instructions per 64-cell chunk-step at
-                                                # the nominal 2 cycles each on 1024 SIMDs at 2.4 GHz
-                                                "peak": 64.0 / (37 * 2) * 1024 * 2.4e9,
-                                                "frac": cells / (ms * 1e-3) / (64.0 / (37 * 2) * 1024 * 2.4e9)}},
+                                                # 28 wave64 VALU instructions per 64-cell chunk-step (round 2: 37; DESIGN.md
+                                                # section 10) at the nominal 2 cycles each on 1024 SIMDs at 2.4 GHz
+                                                "valu_per_chunk_step": 28,
+                                                "peak": 64.0 / (28 * 2) * 1024 * 2.4e9,
+                                                "frac": cells / (ms * 1e-3) / (64.0 / (28 * 2) * 1024 * 2.4e9),
+                                                "frac_at_round2_instruction_count_37": cells / (ms * 1e-3) / (64.0 / (37 * 2) * 1024 * 2.4e9)}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
                                              "unpinned); results equal to the GPU's" % n_cpu}}))
