@@ -544,12 +544,17 @@ class DeviceBatch(object):
 
     def kernels(self):
         """[(kernel name as rocprofv3 shows it, reads, tiles)] in launch order (advntr_batch_info)."""
+        return [k[:3] for k in self.kernel_info()]
+
+    def kernel_info(self):
+        """[(kernel name, reads, tiles, useful share of the sweeps' lane-steps or None)] in launch order: trellis cells of the
+        reads over the cell slots the row-blocked sweeps' lane-steps offer (pipeline fill / drain, padding rows and lanes)."""
         buf = ctypes.create_string_buffer(4096)
         check(load().advntr_batch_info(self._h, ctypes.addressof(buf), 4096))
         out = []
         for line in buf.value.decode().splitlines():
-            name, reads, tiles = line.rsplit(" ", 2)
-            out.append((name, int(reads), int(tiles)))
+            name, reads, tiles, useful = line.rsplit(" ", 3)
+            out.append((name, int(reads), int(tiles), None if int(useful) < 0 else int(useful) / 1000.0))
         return out
 
     def result_ptrs(self):

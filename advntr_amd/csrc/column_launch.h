@@ -21,6 +21,8 @@ struct ColumnLaunch {
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
     int rows_depth = 1;                     // reads per lane group of the deepest row-blocked tile
+    double useful_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per tile list (row-blocked kernels only): trellis cells of the reads,
+    double swept_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // and cell slots the sweeps' lane-steps offer (advntr_batch_info)
     int reserve_workgroups = 0;             // resident workgroup slots the launches leave unclaimed (a multi-GPU run's
                                             // result gather runs beside the next pass: abi_comm.h)
     std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,

@@ -869,6 +869,36 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64) + COL_MAX_TAIL);
             }
         }
+        // useful share of the row-blocked sweeps' lane-steps: a sweep of `depth` reads per lane group costs depth * NC + (rows of
+        // the last read - 1) / R steps of 64 lanes x R cells (viterbi_rows_kernel), a row tile of a long read NC + (rows - 1) / R
+        // (viterbi_rows_long_kernel); what the reads need is length x NC cells each
+        if (!C.stream) {
+            for (int k = 5; k <= 8; ++k)
+                for (const ColTile &t : C.tiles[k]) {
+                    const int nc = B->models[t.model]->colprog.n_cols;
+                    auto len_at = [&](int idx) { const int r = col_reads[(size_t)t.first + idx]; return (int)(read_off[r + 1] - read_off[r]); };
+                    for (int idx = 0; idx < t.count; ++idx) C.useful_cells[k] += (double)len_at(idx) * nc;
+                    if (k == 8) {
+                        const int R = ROWS_LONG_R, RT = 64 * R;
+                        for (int idx = 0; idx < t.count; ++idx)
+                            for (int n = len_at(idx), row0 = 0; row0 < n; row0 += RT)
+                                C.swept_cells[k] += (double)(nc + (std::min(RT, n - row0) - 1) / R) * 64 * R;
+                        continue;
+                    }
+                    const int R = rows_configs[k - 5].R, G = rows_configs[k - 5].G, round = COL_WAVES * G;
+                    const int dmax = nc >= ROWS_STREAM_MIN_COLS ? C.rows_depth : 1;
+                    for (int j0 = 0; j0 < t.count; j0 += round * dmax)
+                        for (int w = 0; w < COL_WAVES; ++w) {
+                            const int jw = j0 + w * G;
+                            if (jw >= t.count) break;
+                            const int depth = std::min(dmax, (t.count - jw + round - 1) / round);
+                            int nlast = 1;
+                            for (int g = 0; g < G; ++g)
+                                if (jw + (depth - 1) * round + g < t.count) nlast = std::max(nlast, len_at(jw + (depth - 1) * round + g));
+                            C.swept_cells[k] += (double)(depth * nc + (nlast - 1) / R) * 64 * R;
+                        }
+                }
+        }
         size_t n_tiles = 0;
         for (int k = 0; k < 9; ++k) n_tiles = std::max(n_tiles, C.tiles[k].size());
         C.grid = (int)std::max<size_t>(1, std::min<size_t>(n_tiles, (size_t)cus * per_cu));
@@ -975,13 +1005,15 @@ extern "C" int advntr_batch_info(const advntr_batch *B, char *buf, int32_t capac
             if (tiles.empty()) continue;
             int64_t reads = 0;
             for (const ColTile &t : tiles) reads += t.count;
-            snprintf(line, sizeof line, "%s %lld %zu\n", B->col.stream ? "viterbi_columns_stream_kernel<3>" : names[k],
-                     (long long)reads, tiles.size());
+            // (fourth field: useful share of the sweeps' lane-steps in per mille, -1 where it is not accounted)
+            const int useful = B->col.swept_cells[k] > 0 ? (int)(1000.0 * B->col.useful_cells[k] / B->col.swept_cells[k] + 0.5) : -1;
+            snprintf(line, sizeof line, "%s %lld %zu %d\n", B->col.stream ? "viterbi_columns_stream_kernel<3>" : names[k],
+                     (long long)reads, tiles.size(), useful);
             out += line;
         }
     }
     if (B->n_gen) {
-        snprintf(line, sizeof line, "viterbi_generic_kernel %d %d\n", B->n_gen, B->grid_gen);
+        snprintf(line, sizeof line, "viterbi_generic_kernel %d %d -1\n", B->n_gen, B->grid_gen);
         out += line;
     }
     if ((int64_t)out.size() + 1 > capacity) return fail(ADVNTR_ERR_TOO_LARGE, "advntr_batch_info: need %zu bytes", out.size() + 1);

@@ -321,7 +321,8 @@ def main(argv=None):
         batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(n_reads, np.int32), flags=flags)
         alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
         relax_total = float(n_reads) * (n + 1) * E
-    kernels = batch.kernels()                   # what the engine launches for this batch (advntr_batch_info)
+    kinfo = batch.kernel_info()                 # what the engine launches for this batch (advntr_batch_info)
+    kernels = [k[:3] for k in kinfo]
     kernel = max(kernels, key=lambda k: k[1])[0] if kernels else "none"
 
     # ---------------------------------------------------------------- timed region
@@ -445,7 +446,7 @@ def main(argv=None):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": dict({"workload": wl, "states": int(m), "emitting": int(P), "edges": int(E),
                             "calls_this_rank": int(n_reads), "read_len": n, "kernel": kernel,
-                            "kernels": [{"name": k, "reads": r, "tiles": t} for k, r, t in kernels],
+                            "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
                             "outputs": "logp + RU count + 6 path summaries per read",
                             "relaxations_per_s": value * relax_total / max(n_reads, 1)}, **plan_info),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -629,7 +630,8 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     dt = (time.perf_counter() - t0) / steps
     kernel_ms = batch.run_timed(steps)
     logp, summ = batch.fetch()
-    kernels = batch.kernels()
+    kinfo = batch.kernel_info()
+    kernels = [k[:3] for k in kinfo]
     kernel = max(kernels, key=lambda k: k[1])[0]
     ms = np.array([d.m for d in dms])
     lens = np.diff(off)
@@ -639,7 +641,7 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
     c2 = {"loci": n_loci, "calls": len(reads), "mean_states": float(np.mean(ms[which])), "read_len": int(round(float(lens.mean()))),
           "value": len(reads) / dt, "unit": "calls/s", "ms_per_step": dt * 1e3, "steps": steps, "kernel_ms": kernel_ms,
-          "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t} for k, r, t in kernels],
+          "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBPS, "algorithmic_gb_per_launch": alg / 1e9,
                        "traffic": traffic / 1e9 if traffic else None, "traffic_source": pmc.get("file"),
@@ -698,11 +700,13 @@ def s300_record(_lib, workloads, flags, args):
     batch.sync()
     dt = (time.perf_counter() - t0) / args.steps
     kernel_ms = batch.run_timed(max(1, args.steps))
-    kernels = batch.kernels()
+    kinfo = batch.kernel_info()
+    kernels = [k[:3] for k in kinfo]
     B = algorithmic_bytes(n, m)
     rec = {"states": int(m), "emitting": int(P), "edges": int(E), "reads": n_reads, "read_len": n,
            "value": n_reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "kernel_ms": kernel_ms,
            "kernel": max(kernels, key=lambda k: k[1])[0], "bytes_per_read": B,
+           "useful_lane_steps": max(kinfo, key=lambda k: k[1])[3],
            "achieved_gbps": B * n_reads / (kernel_ms * 1e-3) / 1e9, "frac": B * n_reads / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
            "relaxations_per_s": n_reads / dt * (n + 1) * E}
     if not args.no_cpu:

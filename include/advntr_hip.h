@@ -140,8 +140,9 @@ int advntr_batch_fetch_paths(advntr_batch *batch, int32_t *out_path, const int64
 int advntr_batch_result_ptrs(advntr_batch *batch, void **d_logp, void **d_summary);
 /* scratch / trellis bytes this batch holds in HBM (for DESIGN.md's layout accounting) */
 int64_t advntr_batch_device_bytes(const advntr_batch *batch);
-/* which kernels advntr_batch_run launches for this batch: NUL-terminated text, one line "kernel_name reads tiles"
- * per launch, in launch order (what `rocprofv3 --kernel-trace` will show).  The routing depends only on read lengths,
+/* which kernels advntr_batch_run launches for this batch: NUL-terminated text, one line "kernel_name reads tiles useful"
+ * per launch, in launch order (what `rocprofv3 --kernel-trace` will show); useful = share of the launch's lane-steps that
+ * work on a cell of a read's trellis, in per mille (the rest is pipeline fill / drain and padding rows; -1: not accounted).  The routing depends only on read lengths,
  * the models' tables and the flags given at creation -- never on the environment.                             */
 int advntr_batch_info(const advntr_batch *batch, char *buf, int32_t capacity);
 
