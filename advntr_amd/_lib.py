@@ -60,6 +60,7 @@ SYMBOLS = {
     "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
     "advntr_built_destroy": (None, [_vp]),
     "advntr_encode_ascii": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "advntr_encode_texts": (ctypes.c_int, [_vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -165,10 +166,45 @@ def encode_ascii(seqs, threads=0):
     off = np.zeros(n + 1, dtype=np.int64)
     if n:
         np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n), out=off[1:])
+    if n and off[n] >= LONG_TEXT_MEAN * n:
+        return _encode_texts(seqs, off, threads)
     raw = "".join(seqs).encode("latin-1", "replace")
     codes = np.empty(len(raw), np.uint8)
     bad = np.zeros(n, np.uint8)
     check(load().advntr_encode_ascii(raw, ptr(off), n, int(threads), ptr(codes), ptr(bad)))
+    return codes, off, bad
+
+
+LONG_TEXT_MEAN = 2048          # mean read length from which the reads are encoded out of their own buffers
+
+
+def _encode_texts(seqs, off, threads=0):
+    """advntr_encode_texts: long reads (PacBio) are encoded straight out of the strings' own buffers -- joining and
+    re-encoding 40 MB of text in Python costs more than the alignment kernel that follows.  A str whose UTF-8 form is
+    not one byte per character (so: not ASCII) goes through latin-1 'replace' like the joined path's text does."""
+    n = len(seqs)
+    as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
+    as_utf8.restype = ctypes.c_void_p
+    as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+    ptrs = np.zeros(n, np.uint64)
+    keep = []                                   # bytes objects made here: alive until the call returns
+    size = ctypes.c_ssize_t(0)
+    for r, s in enumerate(seqs):
+        if isinstance(s, str):
+            p = as_utf8(s, ctypes.byref(size))
+            if p is None or size.value != len(s):
+                b = s.encode("latin-1", "replace")
+                keep.append(b)
+                p = ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value
+        else:
+            b = bytes(s)
+            keep.append(b)
+            p = ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value
+        ptrs[r] = p or 0
+    codes = np.empty(int(off[n]), np.uint8)
+    bad = np.zeros(n, np.uint8)
+    check(load().advntr_encode_texts(ptr(ptrs), n, 0, int(threads), ptr(off), ptr(codes), ptr(bad)))
+    del keep
     return codes, off, bad
 
 

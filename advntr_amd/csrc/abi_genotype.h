@@ -98,15 +98,12 @@ extern "C" int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_th
     return ADVNTR_OK;
 }
 
-extern "C" int advntr_encode_spans(const char *ascii, const int64_t *span_start, const int64_t *span_end, int32_t n_reads,
-                                   uint32_t flags, int32_t n_threads, const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad)
+// ASCII -> base codes; source of read r given by `src_of(r)`, n bytes into out_codes[out_off[r] ..); work items sized by bytes
+// (a batch may be a million 150-base reads or a few thousand 15 kb ones)
+template <class Src>
+static int encode_reads_host(const char *who, Src &&src_of, int32_t n_reads, uint32_t flags, int32_t n_threads,
+                             const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad)
 {
-    if (n_reads < 0 || (n_reads && (!span_start || !span_end || !out_off)))
-        return fail(ADVNTR_ERR_ARG, "advntr_encode_spans: bad argument");
-    if (n_reads == 0) return ADVNTR_OK;
-    if (!ascii || !out_codes) {
-        if (out_off[n_reads] > out_off[0]) return fail(ADVNTR_ERR_ARG, "advntr_encode_spans: null buffer");
-    }
     struct Table {
         uint8_t code[256];
         explicit Table(bool fold)
@@ -118,7 +115,9 @@ extern "C" int advntr_encode_spans(const char *ascii, const int64_t *span_start,
     };
     static const Table folded(true), exact(false);
     const Table &table = (flags & ADVNTR_ENCODE_CASE_SENSITIVE) ? exact : folded;
-    const int chunk = 4096;
+    const int64_t total = out_off[n_reads] - out_off[0];
+    const int64_t mean = std::max<int64_t>(1, total / std::max(n_reads, 1));
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)512 << 10) / mean));
     const int T = host_text_threads(n_threads, n_reads, chunk);
     std::atomic<int> next(0), bad_span(-1);
     host_parallel(T, [&](int) {
@@ -127,9 +126,9 @@ extern "C" int advntr_encode_spans(const char *ascii, const int64_t *span_start,
             if (r0 >= n_reads) return;
             const int r1 = std::min(n_reads, r0 + chunk);
             for (int r = r0; r < r1; ++r) {
-                const int64_t n = span_end[r] - span_start[r];
-                if (n < 0 || out_off[r + 1] - out_off[r] != n) { bad_span = r; continue; }
-                const uint8_t *src = (const uint8_t *)ascii + span_start[r];
+                int64_t n = 0;
+                const uint8_t *src = src_of(r, n);
+                if (n < 0 || out_off[r + 1] - out_off[r] != n || (n && !src)) { bad_span = r; continue; }
                 uint8_t *dst = out_codes + out_off[r];
                 uint8_t any = 0, other = 0;
                 for (int64_t i = 0; i < n; ++i) {
@@ -142,8 +141,37 @@ extern "C" int advntr_encode_spans(const char *ascii, const int64_t *span_start,
             }
         }
     });
-    if (bad_span >= 0) return fail(ADVNTR_ERR_ARG, "advntr_encode_spans: span %d does not match its output slot", (int)bad_span);
+    if (bad_span >= 0) return fail(ADVNTR_ERR_ARG, "%s: read %d does not match its output slot", who, (int)bad_span);
     return ADVNTR_OK;
+}
+
+extern "C" int advntr_encode_spans(const char *ascii, const int64_t *span_start, const int64_t *span_end, int32_t n_reads,
+                                   uint32_t flags, int32_t n_threads, const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad)
+{
+    if (n_reads < 0 || (n_reads && (!span_start || !span_end || !out_off)))
+        return fail(ADVNTR_ERR_ARG, "advntr_encode_spans: bad argument");
+    if (n_reads == 0) return ADVNTR_OK;
+    if (!ascii || !out_codes) {
+        if (out_off[n_reads] > out_off[0]) return fail(ADVNTR_ERR_ARG, "advntr_encode_spans: null buffer");
+    }
+    return encode_reads_host("advntr_encode_spans", [&](int r, int64_t &n) {
+        n = span_end[r] - span_start[r];
+        return (const uint8_t *)ascii + span_start[r];
+    }, n_reads, flags, n_threads, out_off, out_codes, out_bad);
+}
+
+extern "C" int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flags, int32_t n_threads,
+                                   const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad)
+{
+    if (n_reads < 0 || (n_reads && (!texts || !out_off))) return fail(ADVNTR_ERR_ARG, "advntr_encode_texts: bad argument");
+    if (n_reads == 0) return ADVNTR_OK;
+    for (int r = 0; r < n_reads; ++r)
+        if (out_off[r + 1] < out_off[r]) return fail(ADVNTR_ERR_ARG, "advntr_encode_texts: out_off not monotone at %d", r);
+    if (!out_codes && out_off[n_reads] > out_off[0]) return fail(ADVNTR_ERR_ARG, "advntr_encode_texts: null buffer");
+    return encode_reads_host("advntr_encode_texts", [&](int r, int64_t &n) {
+        n = out_off[r + 1] - out_off[r];
+        return (const uint8_t *)texts[r];
+    }, n_reads, flags, n_threads, out_off, out_codes, out_bad);
 }
 
 extern "C" int advntr_encode_ascii(const char *ascii, const int64_t *read_off, int32_t n_reads, int32_t n_threads,

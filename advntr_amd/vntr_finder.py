@@ -272,6 +272,14 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
             parts.append((res["locus"][keep].astype(np.int64) + cuts[k], res["summary"][keep]))
             T["score_recruit"] += time.perf_counter() - t
             del models, prep, res                   # the piece's models leave the device with their last reference
+    except BaseException:
+        # the preparation thread would block on the full queue once nobody takes from it: drain until it is through
+        while worker.is_alive():
+            try:
+                ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        raise
     finally:
         worker.join()
     t = time.perf_counter()

@@ -242,6 +242,10 @@ int advntr_encode_spans(const char *ascii, const int64_t *span_start, const int6
                         uint32_t flags, int32_t n_threads, const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
 int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_threads, int64_t *line_start, int64_t capacity,
                       int64_t *n_lines);
+/* The same for reads held as separate texts (one pointer per read, e.g. the buffers of the host language's strings: long
+ * reads are not joined into one text first): read r = texts[r][0 .. out_off[r+1] - out_off[r]).                    */
+int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flags, int32_t n_threads,
+                        const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
 
 /* ---- genotype caller on the summary records (the step downstream of scoring; host threads, no GPU) -----------
  * Replaces, for many loci at once, the Illumina aggregation of VNTRFinder.find_repeat_count_from_alignment_file after

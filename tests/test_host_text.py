@@ -45,6 +45,30 @@ def test_encode_ascii_and_spans():
         _lib.check(_lib.load().advntr_encode_ascii(b"ACGT", np.array([0, 3, 2], np.int64).ctypes.data, 2, 1, None, None))
 
 
+def test_long_reads_are_encoded_out_of_their_own_buffers():
+    """advntr_encode_texts (one pointer per read: the strings' own buffers) == advntr_encode_ascii over the joined text; a str
+    that is not ASCII and a bytes object take the same route; encode_ascii picks the route by mean read length."""
+    rng = np.random.default_rng(8)
+    alphabet = np.array(list("ACGTacgtNn-"))
+    seqs = ["".join(rng.choice(alphabet[:11 if k % 7 == 0 else (10 if k % 3 == 0 else 8)], int(rng.integers(0, 9000)))) for k in range(120)]
+    seqs[5] = "ACGT\u00e9" * 900
+    as_text = list(seqs)
+    seqs[7] = seqs[7].encode()
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
+    c, o, b = _lib._encode_texts(seqs, off)
+    limit, _lib.LONG_TEXT_MEAN = _lib.LONG_TEXT_MEAN, 1 << 60
+    try:
+        c2, o2, b2 = _lib.encode_ascii(as_text)
+    finally:
+        _lib.LONG_TEXT_MEAN = limit
+    assert np.array_equal(c, c2) and np.array_equal(o, o2) and np.array_equal(b, b2)
+    assert b[5] == 2 and set(b.tolist()) == {0, 1, 2}
+    c3, _, b3 = _lib.encode_ascii(as_text)                         # mean length above LONG_TEXT_MEAN: the pointer route
+    assert off[-1] >= _lib.LONG_TEXT_MEAN * len(seqs) and np.array_equal(c3, c2) and np.array_equal(b3, b2)
+    with pytest.raises(_lib.EngineError):
+        _lib.check(_lib.load().advntr_encode_texts(None, 2, 0, 1, off.ctypes.data, c.ctypes.data, None))
+
+
 def test_builder_exp_routes_agree():
     """numpy.exp's inner loop located in the ufunc object and called by the worker threads == the ctypes callback around
     numpy.exp (bit for bit); libm's exp differs in the last bit of some parameters (why the reference's route matters)."""
