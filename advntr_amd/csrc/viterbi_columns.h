@@ -496,8 +496,44 @@ __device__ __forceinline__ ColFinishTables col_finish_tables(const ColProgram *_
     return F;
 }
 
-// Tail states at the last row: first maximum over the reference-order in-edge list, wave-parallel.
-// (tail values go to `tailv`; by default right behind the row)
+// Reductions over the 64 lanes with DPP moves (no LDS round trips): butterflies inside the rows of 16 lanes, then the row
+// results passed on to the next row's lanes (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3): lane 63 holds the
+// result, returned wave-uniform.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double wave_dpp_f64(const double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, ROWS, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), CTRL, ROWS, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    v = fmax(v, wave_dpp_f64<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = fmax(v, wave_dpp_f64<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = fmax(v, wave_dpp_f64<0x141>(v));           // row_half_mirror
+    v = fmax(v, wave_dpp_f64<0x140>(v));           // row_mirror
+    v = fmax(v, wave_dpp_f64<0x142, 0xA>(v));      // row_bcast15
+    v = fmax(v, wave_dpp_f64<0x143, 0xC>(v));      // row_bcast31
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)b, 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Tail states at the last row: first maximum over the reference-order in-edge list, wave-parallel: a lane takes the edges
+// e0 + lane, e0 + lane + 64, ... in order (four at a time: the loads of the edge records, then those of the values they point
+// at, are in flight together), the maximum over the lanes is found first and then the lowest edge number among the lanes that
+// hold it.  (tail values go to `tailv`; by default right behind the row)
 __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, double *__restrict__ rown,
                                            int32_t *__restrict__ tailwin, const int NC, const int lane,
                                            double *__restrict__ tailv = nullptr)
@@ -512,22 +548,26 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
         int rank = 0x7fffffff;
         const int e0 = e1;
         e1 = F.tptr[i + 1];
-        for (int e = e0 + lane; e < e1; e += 64) {
-            const TailEdge ed = F.edges[e];
-            const double v = ed.loc >= 0 ? rown[(ed.loc >> 2) * 3 + (ed.loc & 3)] : tailv[-ed.loc - 1];
-            const double cand = v + ed.logp;
-            if (cand > best) { best = cand; rank = e; }
-        }
+        for (int eb = e0; eb < e1; eb += 256) {
+            TailEdge ed[4];
+            double v[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(best, o, 64);
-            const int orank = __shfl_xor(rank, o, 64);
-            if (ov > best || (ov == best && orank < rank)) { best = ov; rank = orank; }
+            for (int u = 0; u < 4; ++u) ed[u] = F.edges[min(eb + 64 * u + lane, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ed[u].loc >= 0 ? rown[(ed[u].loc >> 2) * 3 + (ed[u].loc & 3)] : tailv[-ed[u].loc - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = eb + 64 * u + lane;
+                const double cand = v[u] + ed[u].logp;
+                if (e < e1 && cand > best) { best = cand; rank = e; }
+            }
         }
-        if (lane == 0) { tailv[i] = best; tailwin[i] = rank; }
+        const double top = wave_max_f64(best);
+        const int first = wave_min_i32(best == top ? rank : 0x7fffffff);
+        if (lane == 0) { tailv[i] = top; tailwin[i] = first; }
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
-        if (i == end_tail) result = best;
+        if (i == end_tail) result = top;
     }
     return result;
 }
