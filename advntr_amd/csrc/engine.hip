@@ -871,7 +871,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         }
         // useful share of the row-blocked sweeps' lane-steps: a sweep of `depth` reads per lane group costs depth * NC + (rows of
         // the last read - 1) / R steps of 64 lanes x R cells (viterbi_rows_kernel), a row tile of a long read NC + (rows - 1) / R
-        // (viterbi_rows_long_kernel); what the reads need is length x NC cells each
+        // (viterbi_rows_long_kernel; R = ceil(rows / 64) in a read's last tile); what the reads need is length x NC cells each
         if (!C.stream) {
             for (int k = 5; k <= 8; ++k)
                 for (const ColTile &t : C.tiles[k]) {
@@ -881,8 +881,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                     if (k == 8) {
                         const int R = ROWS_LONG_R, RT = 64 * R;
                         for (int idx = 0; idx < t.count; ++idx)
-                            for (int n = len_at(idx), row0 = 0; row0 < n; row0 += RT)
-                                C.swept_cells[k] += (double)(nc + (std::min(RT, n - row0) - 1) / R) * 64 * R;
+                            for (int n = len_at(idx), row0 = 0; row0 < n; row0 += RT) {
+                                // (a read's last tile runs with as few rows per lane as cover it)
+                                const int rows = std::min(RT, n - row0), rl = row0 + RT < n ? R : (rows + 63) / 64;
+                                C.swept_cells[k] += (double)(nc + (rows - 1) / rl) * 64 * rl;
+                            }
                         continue;
                     }
                     const int R = rows_configs[k - 5].R, G = rows_configs[k - 5].G, round = COL_WAVES * G;
@@ -988,14 +991,16 @@ extern "C" int64_t advntr_batch_device_bytes(const advntr_batch *B) { return B ?
 
 // Which kernels advntr_batch_run launches for this batch: one line "kernel reads tiles" per non-empty launch, in launch
 // order (the routing is decided in batch_build from read lengths, model tables and flags only).
+#define ADV_STR_(x) #x
+#define ADV_STR(x) ADV_STR_(x)
 extern "C" int advntr_batch_info(const advntr_batch *B, char *buf, int32_t capacity)
 {
     if (!B || !buf || capacity <= 0) return fail(ADVNTR_ERR_ARG, "advntr_batch_info: bad argument");
     static const char *const names[9] = {
         "viterbi_columns_kernel<1, false>", "viterbi_columns_kernel<2, false>", "viterbi_columns_kernel<3, false>",
         "viterbi_columns_kernel<4, false>", "viterbi_columns_kernel<3, true>", "viterbi_rows_kernel<5, 2>",
-        "viterbi_rows_kernel<4, 2>", "viterbi_rows_kernel<4, 4>", "viterbi_rows_long_kernel<4>"};
-    static_assert(COL_LONG_K == 3 && ROWS_LONG_R == 4, "kernel names above");
+        "viterbi_rows_kernel<4, 2>", "viterbi_rows_kernel<4, 4>", "viterbi_rows_long_kernel<" ADV_STR(ROWS_LONG_R) ">"};
+    static_assert(COL_LONG_K == 3, "kernel names above");
     std::string out;
     char line[160];
     if (B->n_col) {

@@ -60,7 +60,8 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 #define ROWS_TAIL_SINGLE_PCT 10
 #endif
 #ifndef ROWS_LONG_R
-#define ROWS_LONG_R 4                // rows per lane of the tiled kernel for longer reads: row tiles of 256 rows
+#define ROWS_LONG_R 5                // rows per lane of the tiled kernel for longer reads: row tiles of 320 rows (a read's last
+                                     // tile runs with as few rows per lane as cover it: viterbi_rows_long_kernel)
 #endif
 
 template <int G>
@@ -117,12 +118,12 @@ __device__ __forceinline__ void rows_bp_publish()
 }
 // back-pointer bits of state st (0 = I, 1 = M, 2 = b) of cell (t, c), in the byte layout bp_ptr_* decode: R rows per lane,
 // lane lane0 + (t - 1) / R works on column c at step c + (t - 1) / R; the two masks of a state are 16 bytes of one line
-template <int R>
-__device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc, const int st)
+// (ln: the lane that worked on the row, k: the row's slot in it; lp: its position in its lane group)
+template <int WORDS = 1>
+__device__ __forceinline__ int rows_bp_at_split(const unsigned *__restrict__ bpw, const int ln, const int k, const int cc, const int st,
+                                                const int lp_in = -1)
 {
-    constexpr int WORDS = (R + 4) / 5;
-    const int lp = (tt - 1) / R, k = (tt - 1) - lp * R;
-    const int ln = lane0 + lp;
+    const int lp = lp_in < 0 ? ln : lp_in;
     // masks of a cell in relaxation order: aM bM | aI bI | aB bB (a: the 2nd candidate won, b: the last one did)
     const int grp = st == 1 ? 0 : (st == 0 ? 1 : 2);
     const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + grp * 4 + (ln >> 5);
@@ -131,6 +132,13 @@ __device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, cons
     const unsigned a = (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
     const unsigned b = (__hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
     return (int)((a << 1 | b) << (st == 1 ? 2 : (st == 0 ? 4 : 0)));
+}
+
+template <int R>
+__device__ __forceinline__ int rows_bp_at(const unsigned *__restrict__ bpw, const int lane0, const int tt, const int cc, const int st)
+{
+    const int lp = (tt - 1) / R, k = (tt - 1) - lp * R;
+    return rows_bp_at_split<(R + 4) / 5>(bpw, lane0 + lp, k, cc, st, lp);
 }
 
 // TILED (G = 1, reads longer than 64 R rows): the sweep covers rows row0+1 .. row0+n of a longer read; `seam` (tiles after
@@ -355,6 +363,20 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
     }
 }
 
+// The last row tile of a long read with rl <= RMAX rows per lane (rl is wave-uniform: one of RMAX copies of the sweep runs)
+template <int RMAX>
+__device__ __forceinline__ void rows_sweep_last(const int rl, const LdsTables &L, const int NC, const uint8_t *__restrict__ seq,
+                                                const int nt, const int lane, unsigned *__restrict__ bpw,
+                                                double *__restrict__ rown, const unsigned cap_base, int32_t *__restrict__ aux,
+                                                const int sink_stride, const int row0, const double *__restrict__ seam)
+{
+    if constexpr (RMAX > 1) {
+        if (rl < RMAX) { rows_sweep_last<RMAX - 1>(rl, L, NC, seq, nt, lane, bpw, rown, cap_base, aux, sink_stride, row0, seam); return; }
+    }
+    rows_sweep<RMAX, 1, true>(L, NC, NC - 1 + (nt - 1) / RMAX, seq, nt, lane, lane, bpw, rown, cap_base, aux, (unsigned)COL_MAX_TAIL,
+                              sink_stride, row0, seam);
+}
+
 // A lane's rows of one queued read, as rows_sweep unpacks them when the lane gets there: 3 bits per row (base code, 4 = row
 // past the read) and the slot of the read's last row (7 = not in this lane).
 template <int R>
@@ -568,11 +590,20 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
                 continue;
             }
             const int n_tiles = (n + RT - 1) / RT;
+            // The last tile of a read holds n - (n_tiles - 1) RT rows, anything from 1 to RT: it is swept with as few rows per
+            // lane as cover it (rl = ceil(rows / 64): the step costs what its rows cost, and a tile costs NC + 63 steps whatever it
+            // holds -- with R rows per lane throughout, a read paid for ceil(n / RT) full tiles).  The back-pointers of that tile
+            // are laid out for rl rows per lane; the traceback is told.
+            const int rl = __builtin_amdgcn_readfirstlane((max(n - (n_tiles - 1) * RT, 1) + 63) >> 6);
             for (int i = 0; i < n_tiles; ++i) {
                 const int row0 = i * RT, nt = min(RT, n - row0);
-                rows_sweep<R, 1, true>(L, NC, NC - 1 + (nt - 1) / R, seq + row0, nt, lane, lane, bpw + i * slab, rown,
-                                       (unsigned)(((i + 1) & 1) * row_doubles), aux, (unsigned)COL_MAX_TAIL, g.sink_stride, row0,
-                                       i > 0 ? rown + (i & 1) * row_doubles : nullptr);
+                const unsigned cap = (unsigned)(((i + 1) & 1) * row_doubles);
+                const double *seam = i > 0 ? rown + (i & 1) * row_doubles : nullptr;
+                if (i + 1 < n_tiles || rl == R)
+                    rows_sweep<R, 1, true>(L, NC, NC - 1 + (nt - 1) / R, seq + row0, nt, lane, lane, bpw + i * slab, rown, cap, aux,
+                                           (unsigned)COL_MAX_TAIL, g.sink_stride, row0, seam);
+                else
+                    rows_sweep_last<R - 1>(rl, L, NC, seq + row0, nt, lane, bpw + i * slab, rown, cap, aux, g.sink_stride, row0, seam);
                 __threadfence_block();
                 __builtin_amdgcn_wave_barrier();
             }
@@ -582,9 +613,13 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
             if (lane == 0) g.a.out_logp[r] = logp;
             int len = 0;
             if (logp != -INFINITY) {
+                // x / rl for x < 400 as a multiply and a shift (rl = 1 .. 5)
+                const unsigned rl_magic = rl == 1 ? 65536u : (rl == 2 ? 32768u : (rl == 3 ? 21846u : (rl == 4 ? 16384u : 13108u)));
                 auto bp_at = [&](int tt, int cc, int st) -> int {
                     const int tl = (tt - 1) / RT;
-                    return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc, st);
+                    if (tl + 1 < n_tiles) return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc, st);
+                    const int x = tt - tl * RT - 1, lp = (int)(((unsigned)x * rl_magic) >> 16);
+                    return rows_bp_at_split(bpw + tl * slab, lp, x - lp * rl, cc, st);
                 };
                 len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, aux + COL_MAX_TAIL, rev,
                                          g.a.path_cap, lane, 0, 1 << 30);

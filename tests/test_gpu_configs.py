@@ -146,7 +146,7 @@ def test_c4_full_size_properties():
     assert len(reads) == 8960 * 20
     dms = device_models([l.model for l in loci])
     logp, summ, kernels = _properties(dms, reads, which, _lib.FLAG_ANTIDIAGONAL, 70001)
-    assert any(k[0] == "viterbi_rows_long_kernel<4>" for k in kernels)
+    assert any(k[0] == "viterbi_rows_long_kernel<5>" for k in kernels)
 
 
 def _bench(args, env=None, timeout=900):

@@ -835,7 +835,8 @@ def test_models_loaded_from_json_score_like_the_reference():
 @pytest.mark.gpu
 def test_row_blocked_kernels_at_their_length_boundaries():
     """A large mixed batch under the default routing: every row-blocked configuration at the edges
-    of its length range (<4,4> 1-64, <4,2> 65-124, <5,2> 125-155, tiled 156+ incl. exact tile multiples) against the
+    of its length range (<4,4> 1-64, <4,2> 65-124, <5,2> 125-155, tiled 156+ incl. exact tile multiples and every number of
+    rows per lane in the last tile) against the
     generic-CSR kernel and, on a sample, the oracle; log-probs, summaries and paths identical."""
     from advntr_amd import _lib, workloads
     from oracle.oracle import OracleModel
@@ -843,7 +844,9 @@ def test_row_blocked_kernels_at_their_length_boundaries():
     loc = workloads.make_locus(rng, 60, 9, 9, 0.05, n_units=3)
     dm = loc.model.device_model()
     assert dm.has_column_program()
-    lens = [1, 2, 4, 5, 63, 64, 65, 80, 123, 124, 125, 128, 129, 150, 154, 155, 156, 160, 255, 256, 257, 300, 511, 512, 513]
+    # (a long read's last row tile of up to 320 rows runs with 1 .. 5 rows per lane: 64-row steps of its fill on either side of each boundary)
+    lens = [1, 2, 4, 5, 63, 64, 65, 80, 123, 124, 125, 128, 129, 150, 154, 155, 156, 160, 192, 193, 255, 256, 257, 300, 320, 321,
+            384, 385, 448, 449, 511, 512, 513, 576, 577, 640, 641, 705, 960, 961]
     reads = []
     for i in range(7000):
         n = lens[i % len(lens)]
