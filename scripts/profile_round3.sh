@@ -2,10 +2,9 @@
 # Run on the GPU box: everything profiles/r03_* is made of.  scripts/profile_round3.sh gpurun_out/r03_prof
 # (every profiler pass under its own timeout: a pass that hangs must not eat the call)
 out=$1; root=$(pwd); mkdir -p $root/$out
-python3 bench.py > $out/c1_bench.json 2> $out/c1_bench.err
-python3 bench.py --workload c2 --no-cpu > $out/c2_bench.json 2> $out/c2_bench.err
-python3 bench.py --workload c4 --no-cpu > $out/c4_bench.json 2> $out/c4_bench.err
-RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 python3 bench.py --workload c3 --no-cpu > $out/c3_1gpu_rccl_bench.json 2> $out/c3_bench.err
+# (a first quick line per workload names the dominant kernel and the call count the counter sections are keyed by; the lines
+# that are kept are written at the end, when profiles/r03_pmc_summary.json describes THIS build's kernels)
+for w in c1 c2 c4; do python3 bench.py --workload $w --no-cpu --no-s300 --no-c2 --steps 2 > $out/${w}_quick.json 2> $out/${w}_quick.err; done
 cd /tmp && export TMPDIR=/tmp
 # the sum-product kernel alone (resident batch, advntr_batch_forward): its own kernel-trace summary
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd.log 2>&1 < /dev/null
@@ -22,7 +21,7 @@ import csv, glob, sys, collections, json
 out = sys.argv[1]
 sections = []
 for w in ("c1", "c2", "c4"):
-    bench = json.load(open("%s/%s_bench.json" % (out, w)))
+    bench = json.load(open("%s/%s_quick.json" % (out, w)))
     kernel = bench["config"]["kernel"]
     tot = collections.defaultdict(float); n = collections.defaultdict(int)
     for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
@@ -51,3 +50,8 @@ json.dump({"note": "per-launch counters of the dominant kernel of `python bench.
            "sections": sections}, open(out + "/pmc_summary.json", "w"), indent=1)
 print(json.dumps(sections, indent=1)[:3000])
 PY
+cp $out/pmc_summary.json profiles/r03_pmc_summary.json
+python3 bench.py > $out/c1_bench.json 2> $out/c1_bench.err
+python3 bench.py --workload c2 --no-cpu > $out/c2_bench.json 2> $out/c2_bench.err
+python3 bench.py --workload c4 --no-cpu > $out/c4_bench.json 2> $out/c4_bench.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 python3 bench.py --workload c3 --no-cpu > $out/c3_1gpu_rccl_bench.json 2> $out/c3_bench.err
