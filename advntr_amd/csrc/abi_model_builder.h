@@ -120,6 +120,35 @@ extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
 // serialization); a thread appends its blobs to 16 MiB segments of its own, so no model allocates a buffer of its own and
 // nothing is staged twice; the segments then go to ONE device allocation with one copy each.  The models keep reading the
 // builder's CSR arrays in place (shared ownership), so the only per-model host memory is the small handle.
+// Page-locked staging segments for bulk uploads, kept across calls: a copy out of pageable memory goes through the runtime's
+// own bounce buffers at a third of the link's rate, and fresh pages cost a fault each (a run that uploads its models piece by
+// piece next to the scoring of the previous piece spent a quarter of its host time there).
+struct PinnedSegments {
+    static constexpr size_t kBytes = (size_t)8 << 20;
+    static constexpr size_t kKeep = 48;                  // at most 384 MiB stay pinned
+    std::mutex mu;
+    std::vector<void *> free_list;
+    void *get()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_list.empty()) { void *q = free_list.back(); free_list.pop_back(); return q; }
+        }
+        void *q = nullptr;
+        if (hipHostMalloc(&q, kBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return q;
+    }
+    void put(void *q)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_list.size() < kKeep) { free_list.push_back(q); return; }
+        }
+        (void)hipHostFree(q);
+    }
+};
+static PinnedSegments g_pinned_segments;
+
 extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_t n, int32_t n_threads, advntr_hmm **out)
 {
     if (n < 0 || (n && (!built || !out))) return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: bad argument");
@@ -127,8 +156,14 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     if (n == 0) return ADVNTR_OK;
     if (n_threads <= 0) n_threads = default_host_threads();
     n_threads = std::max(1, std::min(n_threads, n));
-    constexpr size_t kSegment = (size_t)16 << 20;
-    struct Segment { std::unique_ptr<uint8_t[]> mem; size_t cap = 0, used = 0, device_off = 0; };
+    constexpr size_t kSegment = PinnedSegments::kBytes;
+    // (a segment is a pinned one from the pool; a blob larger than that, or a pool that cannot grow, takes pageable memory)
+    struct Segment {
+        uint8_t *mem = nullptr;
+        bool pinned = false;
+        size_t cap = 0, used = 0, device_off = 0;
+    };
+    const int dev = current_device();
     struct Placed { int thread = -1, segment = -1; size_t off = 0; };
     std::vector<std::vector<Segment>> segments(n_threads);
     std::vector<Placed> placed(n);
@@ -136,7 +171,16 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     int first_bad = -1;
     std::string msg;
     std::atomic<int> next(0);
+    auto release = [&]() {
+        for (auto &list : segments)
+            for (Segment &sgm : list) {
+                if (sgm.pinned) g_pinned_segments.put(sgm.mem);
+                else delete[] sgm.mem;
+                sgm.mem = nullptr;
+            }
+    };
     auto work = [&](int t) {
+        (void)hipSetDevice(dev);                               // (host threads start on device 0)
         std::vector<Segment> &mine = segments[t];
         for (;;) {
             const int i = next.fetch_add(1);
@@ -157,12 +201,13 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
             if (mine.empty() || mine.back().used + need > mine.back().cap) {
                 Segment sgm;
                 sgm.cap = std::max(kSegment, need);
-                sgm.mem.reset(new uint8_t[sgm.cap]);                            // uninitialised: pages are touched as they fill
-                mine.push_back(std::move(sgm));
+                if (sgm.cap == kSegment && (sgm.mem = (uint8_t *)g_pinned_segments.get())) sgm.pinned = true;
+                else sgm.mem = new uint8_t[sgm.cap];                            // uninitialised: pages are touched as they fill
+                mine.push_back(sgm);
             }
             Segment &sgm = mine.back();
-            memcpy(sgm.mem.get() + sgm.used, tls_blob().bytes.data(), H->blob_bytes);
-            memset(sgm.mem.get() + sgm.used + H->blob_bytes, 0, need - H->blob_bytes);
+            memcpy(sgm.mem + sgm.used, tls_blob().bytes.data(), H->blob_bytes);
+            memset(sgm.mem + sgm.used + H->blob_bytes, 0, need - H->blob_bytes);
             placed[i].thread = t; placed[i].segment = (int)mine.size() - 1; placed[i].off = sgm.used;
             sgm.used += need;
             out[i] = H;
@@ -179,6 +224,7 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     };
     if (first_bad >= 0) {
         drop_all();
+        release();
         return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
     }
     size_t total = 0;
@@ -186,9 +232,17 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
         for (Segment &sgm : list) { sgm.device_off = total; total += sgm.used; }
     ModelSlab *slab = new ModelSlab;
     bool ok = hipMalloc(&slab->d, total) == hipSuccess;
+    // all copies queued on a stream of their own (nothing here waits for, or holds up, kernels of other batches), one wait
+    hipStream_t copy_stream = g_cache.get_stream(dev);
+    ok = ok && copy_stream != nullptr;
     for (auto &list : segments)
         for (Segment &sgm : list)
-            ok = ok && hipMemcpy((uint8_t *)slab->d + sgm.device_off, sgm.mem.get(), sgm.used, hipMemcpyHostToDevice) == hipSuccess;
+            ok = ok && hipMemcpyAsync((uint8_t *)slab->d + sgm.device_off, sgm.mem, sgm.used, hipMemcpyHostToDevice, copy_stream) == hipSuccess;
+    if (copy_stream) {
+        ok = (hipStreamSynchronize(copy_stream) == hipSuccess) && ok;
+        g_cache.put_stream(dev, copy_stream);
+    }
+    release();
     if (!ok) {
         if (slab->d) (void)hipFree(slab->d);
         delete slab;
@@ -196,7 +250,6 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
         return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
     }
     slab->refs = n;
-    const int dev = current_device();
     for (int i = 0; i < n; ++i) {
         out[i]->slab = slab;
         out[i]->device = dev;
