@@ -848,6 +848,17 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.tiles[bucket <= 3 ? 5 + bucket : bucket - 4].push_back(ColTile{mod, i, j - i, 0});
                 i = j;
             }
+            // long reads, one per wavefront: the tiles of a launch differ by an order of magnitude in work (columns x rows of
+            // their longest read, which is the first one) -- heaviest first, so that what the dynamic dequeue hands out last is
+            // small (in model order the launch ended on whatever came last: 4 ms of 200 on BASELINE config 4)
+            for (int k : {4, 8})
+                std::stable_sort(C.tiles[k].begin(), C.tiles[k].end(), [&](const ColTile &x, const ColTile &y) {
+                    auto work = [&](const ColTile &t) {
+                        const int r = col_reads[(size_t)t.first];
+                        return (int64_t)B->models[t.model]->colprog.n_cols * (read_off[r + 1] - read_off[r]);
+                    };
+                    return work(x) > work(y);
+                });
             const int kmax = std::min(4, (n_max_col + 63) / 64);
             const int TL = 64 * COL_LONG_K;
             // (the anti-diagonal kernel's row-tiled slabs only when some read really goes there: by default longer reads take
