@@ -117,35 +117,32 @@ extern "C" advntr_hmm *advntr_built_upload(const advntr_built *B)
 }
 
 // Bulk upload.  Host threads turn every model into its device blob (validation, column-program compilation,
-// serialization); a thread appends its blobs to 16 MiB segments of its own, so no model allocates a buffer of its own and
-// nothing is staged twice; the segments then go to ONE device allocation with one copy each.  The models keep reading the
-// builder's CSR arrays in place (shared ownership), so the only per-model host memory is the small handle.
-// Page-locked staging segments for bulk uploads, kept across calls: a copy out of pageable memory goes through the runtime's
-// own bounce buffers at a third of the link's rate, and fresh pages cost a fault each (a run that uploads its models piece by
-// piece next to the scoring of the previous piece spent a quarter of its host time there).
+// serialization) and append it to staging segments shared by all threads (space is reserved under a lock, the copy happens
+// outside it), so no model allocates a buffer of its own and nothing is staged twice; the segments then go to ONE device
+// allocation with one copy each.  The models keep reading the builder's CSR arrays in place (shared ownership), so the only
+// per-model host memory is the small handle.
+// The segments are page-locked and kept across calls: a copy out of pageable memory goes through the runtime's own bounce
+// buffers at a third of the link's rate, and fresh pages cost a fault each.  The pool only ever grows to kMax segments and
+// nothing is unpinned while the process runs -- hipHostFree waits for the device, i.e. for whatever kernel another thread's
+// batch is running (a pool that gave segments back made the uploads of a pipelined run five times slower); what does not fit
+// the pool is staged in pageable memory as before.
 struct PinnedSegments {
     static constexpr size_t kBytes = (size_t)8 << 20;
-    static constexpr size_t kKeep = 48;                  // at most 384 MiB stay pinned
+    static constexpr size_t kMax = 48;                   // 384 MiB
     std::mutex mu;
     std::vector<void *> free_list;
+    size_t allocated = 0;
     void *get()
     {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!free_list.empty()) { void *q = free_list.back(); free_list.pop_back(); return q; }
-        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (!free_list.empty()) { void *q = free_list.back(); free_list.pop_back(); return q; }
+        if (allocated >= kMax) return nullptr;
         void *q = nullptr;
-        if (hipHostMalloc(&q, kBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&q, kBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); allocated = kMax; return nullptr; }
+        ++allocated;
         return q;
     }
-    void put(void *q)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (free_list.size() < kKeep) { free_list.push_back(q); return; }
-        }
-        (void)hipHostFree(q);
-    }
+    void put(void *q) { std::lock_guard<std::mutex> lk(mu); free_list.push_back(q); }
 };
 static PinnedSegments g_pinned_segments;
 
@@ -157,31 +154,46 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     if (n_threads <= 0) n_threads = default_host_threads();
     n_threads = std::max(1, std::min(n_threads, n));
     constexpr size_t kSegment = PinnedSegments::kBytes;
-    // (a segment is a pinned one from the pool; a blob larger than that, or a pool that cannot grow, takes pageable memory)
     struct Segment {
         uint8_t *mem = nullptr;
         bool pinned = false;
         size_t cap = 0, used = 0, device_off = 0;
     };
     const int dev = current_device();
-    struct Placed { int thread = -1, segment = -1; size_t off = 0; };
-    std::vector<std::vector<Segment>> segments(n_threads);
+    struct Placed { int segment = -1; size_t off = 0; };
+    std::vector<Segment> segments;
+    std::mutex seg_mu;
     std::vector<Placed> placed(n);
     std::mutex err_mu;
     int first_bad = -1;
     std::string msg;
     std::atomic<int> next(0);
     auto release = [&]() {
-        for (auto &list : segments)
-            for (Segment &sgm : list) {
-                if (sgm.pinned) g_pinned_segments.put(sgm.mem);
-                else delete[] sgm.mem;
-                sgm.mem = nullptr;
-            }
+        for (Segment &sgm : segments) {
+            if (sgm.pinned) g_pinned_segments.put(sgm.mem);
+            else delete[] sgm.mem;
+            sgm.mem = nullptr;
+        }
     };
-    auto work = [&](int t) {
+    // room for `need` bytes in the last segment, or in a new one (pinned while the pool has any; a blob larger than a
+    // segment gets pageable memory of its own size)
+    auto reserve = [&](size_t need, Placed &where) -> uint8_t * {
+        std::lock_guard<std::mutex> lk(seg_mu);
+        if (segments.empty() || segments.back().used + need > segments.back().cap) {
+            Segment sgm;
+            sgm.cap = std::max(kSegment, need);
+            if (sgm.cap == kSegment && (sgm.mem = (uint8_t *)g_pinned_segments.get())) sgm.pinned = true;
+            else sgm.mem = new uint8_t[sgm.cap];                                // uninitialised: pages are touched as they fill
+            segments.push_back(sgm);
+        }
+        Segment &sgm = segments.back();
+        where.segment = (int)segments.size() - 1;
+        where.off = sgm.used;
+        sgm.used += need;
+        return sgm.mem + where.off;
+    };
+    auto work = [&](int) {
         (void)hipSetDevice(dev);                               // (host threads start on device 0)
-        std::vector<Segment> &mine = segments[t];
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
@@ -198,18 +210,9 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
                 continue;
             }
             const size_t need = (H->blob_bytes + 255) & ~size_t(255);           // 256-B aligned sub-blobs
-            if (mine.empty() || mine.back().used + need > mine.back().cap) {
-                Segment sgm;
-                sgm.cap = std::max(kSegment, need);
-                if (sgm.cap == kSegment && (sgm.mem = (uint8_t *)g_pinned_segments.get())) sgm.pinned = true;
-                else sgm.mem = new uint8_t[sgm.cap];                            // uninitialised: pages are touched as they fill
-                mine.push_back(sgm);
-            }
-            Segment &sgm = mine.back();
-            memcpy(sgm.mem + sgm.used, tls_blob().bytes.data(), H->blob_bytes);
-            memset(sgm.mem + sgm.used + H->blob_bytes, 0, need - H->blob_bytes);
-            placed[i].thread = t; placed[i].segment = (int)mine.size() - 1; placed[i].off = sgm.used;
-            sgm.used += need;
+            uint8_t *dst = reserve(need, placed[i]);
+            memcpy(dst, tls_blob().bytes.data(), H->blob_bytes);
+            memset(dst + H->blob_bytes, 0, need - H->blob_bytes);
             out[i] = H;
         }
     };
@@ -228,23 +231,23 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
         return fail(ADVNTR_ERR_ARG, "advntr_built_upload_many: model %d: %s", first_bad, msg.c_str());
     }
     size_t total = 0;
-    for (auto &list : segments)
-        for (Segment &sgm : list) { sgm.device_off = total; total += sgm.used; }
+    for (Segment &sgm : segments) { sgm.device_off = total; total += sgm.used; }
     ModelSlab *slab = new ModelSlab;
-    bool ok = hipMalloc(&slab->d, total) == hipSuccess;
+    slab->device = dev;
+    slab->d = g_cache.get(dev, total, &slab->bytes);
+    bool ok = slab->d != nullptr;
     // all copies queued on a stream of their own (nothing here waits for, or holds up, kernels of other batches), one wait
     hipStream_t copy_stream = g_cache.get_stream(dev);
     ok = ok && copy_stream != nullptr;
-    for (auto &list : segments)
-        for (Segment &sgm : list)
-            ok = ok && hipMemcpyAsync((uint8_t *)slab->d + sgm.device_off, sgm.mem, sgm.used, hipMemcpyHostToDevice, copy_stream) == hipSuccess;
+    for (Segment &sgm : segments)
+        ok = ok && hipMemcpyAsync((uint8_t *)slab->d + sgm.device_off, sgm.mem, sgm.used, hipMemcpyHostToDevice, copy_stream) == hipSuccess;
     if (copy_stream) {
         ok = (hipStreamSynchronize(copy_stream) == hipSuccess) && ok;
         g_cache.put_stream(dev, copy_stream);
     }
     release();
     if (!ok) {
-        if (slab->d) (void)hipFree(slab->d);
+        if (slab->d) g_cache.put(dev, slab->d, slab->bytes);
         delete slab;
         drop_all();
         return fail(ADVNTR_ERR_DEVICE, "advntr_built_upload_many: device upload failed (%zu B)", total);
@@ -253,7 +256,7 @@ extern "C" int advntr_built_upload_many(const advntr_built *const *built, int32_
     for (int i = 0; i < n; ++i) {
         out[i]->slab = slab;
         out[i]->device = dev;
-        hmm_bind(out[i], (const uint8_t *)slab->d + segments[placed[i].thread][placed[i].segment].device_off + placed[i].off);
+        hmm_bind(out[i], (const uint8_t *)slab->d + segments[placed[i].segment].device_off + placed[i].off);
     }
     return ADVNTR_OK;
 }

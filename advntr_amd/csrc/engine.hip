@@ -226,8 +226,13 @@ struct advntr_hmm {
 };
 
 // One device allocation shared by the models of a bulk upload (advntr_built_upload_many); freed with its last model.
+// (a block of the per-device cache, like a batch's buffers: it goes back there, not to hipFree, which would wait for whatever
+// kernels other threads' batches are running; the batches that used these models have synchronised their streams before their
+// models may be destroyed -- the C-ABI contract, and what the Python wrappers enforce by holding references)
 struct ModelSlab {
     void *d = nullptr;
+    size_t bytes = 0;
+    int device = 0;
     std::atomic<int> refs{0};
 };
 
@@ -502,7 +507,7 @@ extern "C" void advntr_hmm_destroy(advntr_hmm *H)
     if (H->d_blob) (void)hipFree(H->d_blob);
     if (H->d_gen) (void)hipFree(H->d_gen);
     if (H->slab && H->slab->refs.fetch_sub(1) == 1) {
-        (void)hipFree(H->slab->d);
+        g_cache.put(H->slab->device, H->slab->d, H->slab->bytes);
         delete H->slab;
     }
     delete H;

@@ -93,7 +93,9 @@ void advntr_trim(void);                      /* release the cached device buffer
 advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index,
                               int32_t n_edges, const int32_t *in_ptr, const int32_t *in_src,
                               const double *in_logp, const double *emis_logp, const uint16_t *state_class);
-void advntr_hmm_destroy(advntr_hmm *model);  /* replaces free_bake_buffers, hmm.pyx:332-346             */
+void advntr_hmm_destroy(advntr_hmm *model);  /* replaces free_bake_buffers, hmm.pyx:332-346.  A model must outlive the
+                                              * batches made from it (their results fetched or their stream synchronised:
+                                              * its device memory is reused by later uploads)                                */
 /* 1 if the model was recognised as a flank-repeats-flank read matcher (hmm_utils.py:553-595) and has
  * a column program for the anti-diagonal kernel; 0 if it runs on the generic-CSR kernel.              */
 int advntr_hmm_has_column_program(const advntr_hmm *model);
