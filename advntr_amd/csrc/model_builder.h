@@ -78,6 +78,7 @@ struct Net {
     {
         v.push_back(Vertex{nm, emission});
         out.emplace_back();
+        out.back().reserve(4);                       // (a state of these models has three or four successors: one allocation)
         return (int)v.size() - 1;
     }
     int add_emission(const std::array<double, 4> &prob)
@@ -171,6 +172,7 @@ struct Net {
         size_t k = 0;
         for (int i = 0; i < n; ++i) {
             auto &r = rows[i];
+            r.reserve(out[order[i]].size() + 1);
             for (const Arc &e : out[order[i]]) r.emplace_back(pos[e.to], p[k++]);
             std::sort(r.begin(), r.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
         }
