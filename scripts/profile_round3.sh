@@ -8,8 +8,9 @@ for w in c1 c2 c4; do python3 bench.py --workload $w --no-cpu --no-s300 --no-c2 
 cd /tmp && export TMPDIR=/tmp
 # the sum-product kernel alone (resident batch, advntr_batch_forward): its own kernel-trace summary
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd.log 2>&1 < /dev/null
+declare -A passes=([c1]="--steps 20 --warmup 5" [c2]="--steps 10 --warmup 3" [c4]="--steps 5 --warmup 2")
 for w in c1 c2 c4; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_$w -- python3 $root/bench.py --workload $w --no-cpu --no-s300 > $root/$out/trace_$w.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_$w -- python3 $root/bench.py --workload $w --no-cpu --no-s300 ${passes[$w]} > $root/$out/trace_$w.log 2>&1 < /dev/null
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_${w}_$c -- python3 $root/bench.py --workload $w --no-cpu --no-s300 --steps 1 --warmup 0 > $root/$out/pmc_${w}_$c.log 2>&1 < /dev/null
   done
@@ -51,7 +52,8 @@ json.dump({"note": "per-launch counters of the dominant kernel of `python bench.
 print(json.dumps(sections, indent=1)[:3000])
 PY
 cp $out/pmc_summary.json profiles/r03_pmc_summary.json
-python3 bench.py > $out/c1_bench.json 2> $out/c1_bench.err
-python3 bench.py --workload c2 --no-cpu > $out/c2_bench.json 2> $out/c2_bench.err
-python3 bench.py --workload c4 --no-cpu > $out/c4_bench.json 2> $out/c4_bench.err
-RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 python3 bench.py --workload c3 --no-cpu > $out/c3_1gpu_rccl_bench.json 2> $out/c3_bench.err
+# (the driver's flags: five warm-up passes -- the first launches after the device has been idle run 40 %, 9 %, 3 %, 1 % slow)
+python3 bench.py --steps 20 --warmup 5 > $out/c1_bench.json 2> $out/c1_bench.err
+python3 bench.py --workload c2 --no-cpu --steps 10 --warmup 3 > $out/c2_bench.json 2> $out/c2_bench.err
+python3 bench.py --workload c4 --no-cpu --steps 5 --warmup 2 > $out/c4_bench.json 2> $out/c4_bench.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 python3 bench.py --workload c3 --no-cpu --steps 10 --warmup 3 > $out/c3_1gpu_rccl_bench.json 2> $out/c3_bench.err
