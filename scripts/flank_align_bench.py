@@ -64,10 +64,9 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                                                 # issue rates scripts/ubench measured on this device at 8 wavefronts per SIMD
                                                 # (profiles/r01_valu_ubench.txt, r02_f64_issue_ubench.txt: 2.6 cycles for a
                                                 # two-operand 32-bit instruction, 4.5 for DPP moves, v_cndmask with a scalar mask
-                                                # and three-operand forms: 10 x 2.6 + 18 x 4.5).  The difference is not
-                                                # accounted for: every condition of a step goes through VCC, one after the other
-                                                # (a build that kept them in scalar pairs did not terminate on the device and was
-                                                # dropped unexamined)
+                                                # and three-operand forms: 10 x 2.6 + 18 x 4.5).  The difference is not accounted
+                                                # for (builds with the conditions in scalar pairs instead of VCC are no faster:
+                                                # DESIGN.md section 10)
                                                 "cycles_per_chunk_step_measured": ms * 1e-3 * 2.4e9 * 1024 / (cells / 64.0),
                                                 "cycles_per_chunk_step_at_measured_issue_rates": 10 * 2.6 + 18 * 4.5}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
