@@ -38,6 +38,8 @@ score, begin, end, ms = _lib.flank_align(reads, [left, right], pr_dev, pf)
 wall = time.perf_counter() - t0
 cells = float(sum(len(strands[r]) for r in pr)) * 100
 bytes_alg = float(sum(len(strands[r]) for r in pr))
+# steps of the sweep: read length + flank length - 1 anti-diagonals, two 64-column chunks each (a 100-base flank fills 100 of 128)
+chunk_steps = float(sum(len(strands[r]) + 99 for r in pr)) * 2
 n_cpu = 24
 t0 = time.perf_counter()
 for p in range(n_cpu):
@@ -64,10 +66,9 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                                                 # issue rates scripts/ubench measured on this device at 8 wavefronts per SIMD
                                                 # (profiles/r01_valu_ubench.txt, r02_f64_issue_ubench.txt: 2.6 cycles for a
                                                 # two-operand 32-bit instruction, 4.5 for DPP moves, v_cndmask with a scalar mask
-                                                # and three-operand forms: 10 x 2.6 + 18 x 4.5).  The difference is not accounted
-                                                # for (builds with the conditions in scalar pairs instead of VCC are no faster:
-                                                # DESIGN.md section 10)
-                                                "cycles_per_chunk_step_measured": ms * 1e-3 * 2.4e9 * 1024 / (cells / 64.0),
+                                                # and three-operand forms: 10 x 2.6 + 18 x 4.5); SQ_INSTS_VALU of the launch: 27.3
+                                                # per chunk-step, 4.3 cycles each
+                                                "cycles_per_chunk_step_measured": ms * 1e-3 * 2.4e9 * 1024 / chunk_steps,
                                                 "cycles_per_chunk_step_at_measured_issue_rates": 10 * 2.6 + 18 * 4.5}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
