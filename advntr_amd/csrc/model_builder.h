@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <limits>
 #include <mutex>
 #include <stdexcept>
@@ -43,9 +44,19 @@ namespace mb {
 
 typedef void (*ExpFn)(const double *in, double *out, int64_t n, void *user);
 
+// log(x) as libm gives it, remembered per argument: a model's eighteen thousand logarithms are taken of a few hundred distinct
+// probabilities (the transition classes of the flanks, the profile columns repeated in every copy), and the value libm returns
+// for an argument is the value it returns the next time.  Direct-mapped, per thread.
 static inline double log_or_ninf(double x)            // utils.pyx:64-70
 {
-    return x > 0 ? std::log(x) : -std::numeric_limits<double>::infinity();
+    if (!(x > 0)) return -std::numeric_limits<double>::infinity();
+    struct Entry { uint64_t key; double val; };
+    static thread_local Entry memo[1024] = {};        // (key 0 = the bits of +0.0, which never gets here)
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    Entry &e = memo[(bits ^ (bits >> 17) ^ (bits >> 41)) & 1023u];
+    if (e.key != bits) { e.key = bits; e.val = std::log(x); }
+    return e.val;
 }
 
 static inline int base_code(char c)
@@ -126,8 +137,9 @@ struct Net {
         std::vector<int> emitting, silent;
         for (int i = 0; i < n; ++i) (v[i].emission >= 0 ? emitting : silent).push_back(i);
         auto by_name = [&](int a, int b) { return v[a].name < v[b].name; };
-        std::stable_sort(emitting.begin(), emitting.end(), by_name);
-        std::stable_sort(silent.begin(), silent.end(), by_name);
+        // (a net rebuilt from rows lists its emitting states in the previous bake's order: sorted already)
+        if (!std::is_sorted(emitting.begin(), emitting.end(), by_name)) std::stable_sort(emitting.begin(), emitting.end(), by_name);
+        if (!std::is_sorted(silent.begin(), silent.end(), by_name)) std::stable_sort(silent.begin(), silent.end(), by_name);
         std::vector<char> seen(n, 0), done(n, 0);
         std::vector<int> post, stack;
         post.reserve(silent.size());
@@ -165,9 +177,35 @@ struct Net {
         for (int i = 0; i < n; ++i)
             for (const Arc &e : out[order[i]]) lp.push_back(e.logp);
         p.resize(lp.size());
-        if (exp_fn) exp_fn(lp.data(), p.data(), (int64_t)lp.size(), user);
-        else
-            for (size_t k = 0; k < lp.size(); ++k) p[k] = std::exp(lp[k]);
+        {   // exp over the DISTINCT arguments only (a few hundred of several thousand; the caller's exp -- numpy's loop -- gives
+            // an argument the same value wherever it stands in the array, which the bit-identical goldens already rest on)
+            std::vector<uint64_t> keys(2048, ~0ull);                 // open addressing on the bit patterns (NaN never occurs)
+            std::vector<int32_t> slot_of(2048, -1), which(lp.size());
+            std::vector<double> uniq, uexp;
+            bool fits = true;
+            for (size_t k = 0; k < lp.size() && fits; ++k) {
+                uint64_t bits;
+                memcpy(&bits, &lp[k], 8);
+                size_t h = (size_t)((bits ^ (bits >> 19) ^ (bits >> 43)) & 2047u);
+                while (keys[h] != ~0ull && keys[h] != bits) h = (h + 1) & 2047u;
+                if (keys[h] == ~0ull) {
+                    if (uniq.size() >= 1536) { fits = false; break; }
+                    keys[h] = bits;
+                    slot_of[h] = (int32_t)uniq.size();
+                    uniq.push_back(lp[k]);
+                }
+                which[k] = slot_of[h];
+            }
+            if (fits) {
+                uexp.resize(uniq.size());
+                if (exp_fn) exp_fn(uniq.data(), uexp.data(), (int64_t)uniq.size(), user);
+                else
+                    for (size_t k = 0; k < uniq.size(); ++k) uexp[k] = std::exp(uniq[k]);
+                for (size_t k = 0; k < lp.size(); ++k) p[k] = uexp[(size_t)which[k]];
+            } else if (exp_fn) exp_fn(lp.data(), p.data(), (int64_t)lp.size(), user);
+            else
+                for (size_t k = 0; k < lp.size(); ++k) p[k] = std::exp(lp[k]);
+        }
         Rows rows(n + extra_rows);
         size_t k = 0;
         for (int i = 0; i < n; ++i) {
@@ -523,6 +561,22 @@ struct Built {
 // the string tests of advntr/hmm_utils.py:116-286 as class bits (same table as the Python host's state_class_from_name)
 static uint16_t classify(const std::string &nm)
 {
+    // the states of a read matcher are M<k>_<tag>, I<k>_<tag>, D<k>_<tag> by the thousand and a few dozen connectors: the
+    // former need two looks at the name, the latter take the general tests below
+    if (nm.size() >= 3 && (nm[0] == 'M' || nm[0] == 'I' || nm[0] == 'D') && nm[1] >= '0' && nm[1] <= '9') {
+        uint16_t c = nm[0] == 'D' ? 0 : ADVNTR_SC_EMIT;
+        if (nm[0] == 'M') c |= ADVNTR_SC_MATCH;
+        const size_t us = nm.find('_');
+        if (us != std::string::npos && nm.find('_', us + 1) == std::string::npos) {
+            const size_t tl = nm.size() - us - 1;
+            const char *t = nm.c_str() + us + 1;
+            if (tl == 6 && memcmp(t, "suffix", 6) == 0) return c | ADVNTR_SC_SUFFIX | ADVNTR_SC_FIX;
+            if (tl == 6 && memcmp(t, "prefix", 6) == 0) return c | ADVNTR_SC_PREFIX | ADVNTR_SC_FIX;
+            bool digits = tl > 0;
+            for (size_t i = 0; i < tl; ++i) digits = digits && t[i] >= '0' && t[i] <= '9';
+            if (digits) return c;                      // a repeat-copy state: none of the other words occur in its name
+        }
+    }
     uint16_t c = 0;
     if (nm[0] == 'M' || nm[0] == 'I' || starts_with(nm, "start_random_matches") || starts_with(nm, "end_random_matches")) c |= ADVNTR_SC_EMIT;
     if (nm[0] == 'M') c |= ADVNTR_SC_MATCH;
