@@ -55,6 +55,7 @@ SYMBOLS = {
     "advntr_align_repeats": (ctypes.c_int, [_vp, _i32, _vp, _i64, _vp]),
     "advntr_flank_align": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "advntr_built_info": (ctypes.c_int, [_vp, _vp]),
+    "advntr_built_info_many": (ctypes.c_int, [_vp, _i32, _vp]),
     "advntr_built_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "advntr_built_upload": (_vp, [_vp]),
     "advntr_built_upload_many": (ctypes.c_int, [_vp, _i32, _i32, _vp]),
@@ -364,12 +365,13 @@ def _numpy_exp_loop():
 class BuiltModel(object):
     """One model made by the native builder (advntr_built): host arrays + upload to the current device."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, info=None):
         self._h = handle
-        info = np.zeros(6, np.int32)
-        check(load().advntr_built_info(self._h, ptr(info)))
-        self.m, self.silent_start, self.start_index, self.end_index, self.n_edges, self._names_bytes = \
-            [int(x) for x in info]
+        if info is None:
+            info = np.zeros(6, np.int32)
+            check(load().advntr_built_info(self._h, ptr(info)))
+            info = info.tolist()
+        self.m, self.silent_start, self.start_index, self.end_index, self.n_edges, self._names_bytes = info
 
     def arrays(self):
         a = dict(m=self.m, silent_start=self.silent_start, start_index=self.start_index, end_index=self.end_index,
@@ -447,7 +449,22 @@ def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp
     otherwise ("numpy-callback" forces the callback); "libm" lets the library use its own exp (<= 1 ulp away)."""
     L = load()
     n = len(lefts)
-    enc = lambda strs: (ctypes.c_char_p * max(len(strs), 1))(*[x.encode("ascii") for x in strs])
+    keep = []
+
+    def enc(strs):
+        """char*[len(strs)] over ONE encoded copy of the strings (NUL-separated): an encode call and a ctypes object per
+        string were a third of the Python time of a 6 719-locus build."""
+        k = max(len(strs), 1)
+        text = "\0".join(strs).encode("ascii") + b"\0"
+        lens = np.fromiter(map(len, strs), dtype=np.int64, count=len(strs))
+        if int(lens.sum()) + len(strs) != len(text):
+            raise ValueError("sequence with an embedded NUL")
+        at = np.zeros(k, np.uint64)
+        base = ctypes.cast(ctypes.c_char_p(text), ctypes.c_void_p).value
+        if len(strs):
+            at[:len(strs)] = base + np.concatenate([[0], np.cumsum(lens[:-1] + 1)]).astype(np.uint64)
+        keep.append((text, at))                     # alive until the call has returned
+        return ptr(at)
     flat, off = [], np.zeros(n + 1, np.int32)
     for i, rows in enumerate(repeat_lists):
         flat.extend(rows)
@@ -466,7 +483,10 @@ def build_read_matchers(lefts, rights, repeat_lists, copies, max_error_rate, exp
             fn = ctypes.cast(_NUMPY_EXP, ctypes.c_void_p)
     rc = L.advntr_build_read_matchers(n, enc(lefts), enc(rights), enc(flat), ptr(off), ptr(cp), float(max_error_rate),
                                       fn, user, int(threads), flags, out)
-    built = [BuiltModel(h) if h else None for h in list(out)[:n]]
+    handles = list(out)[:n]
+    info = np.zeros((max(n, 1), 6), np.int32)
+    check(L.advntr_built_info_many(out, n, ptr(info)))          # (one call: a call and an array per model were 10 us each)
+    built = [BuiltModel(h, i) if h else None for h, i in zip(handles, info.tolist())]
     if rc != OK:
         msg = last_error()
         for b in built:

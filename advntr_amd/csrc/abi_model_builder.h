@@ -94,6 +94,17 @@ extern "C" int advntr_built_info(const advntr_built *B, int32_t *info)
     return ADVNTR_OK;
 }
 
+extern "C" int advntr_built_info_many(const advntr_built *const *built, int32_t n, int32_t *info)
+{
+    if (n < 0 || (n && (!built || !info))) return fail(ADVNTR_ERR_ARG, "advntr_built_info_many: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (built[i]) (void)advntr_built_info(built[i], info + 6 * (size_t)i);
+        else
+            for (int k = 0; k < 6; ++k) info[6 * (size_t)i + k] = -1;
+    }
+    return ADVNTR_OK;
+}
+
 extern "C" int advntr_built_export(const advntr_built *B, int32_t *in_ptr, int32_t *in_src, double *in_logp,
                                    double *emis_logp, uint16_t *state_class, char *names)
 {

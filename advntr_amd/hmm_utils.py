@@ -37,7 +37,7 @@ def build_read_matcher_models(loci, threads=0, exp="numpy", align=None):
     units of unequal length with the library's own aligner instead of refusing them."""
     loci = list(loci)
     align = settings.ALIGN_REPEATS if align is None else align
-    built = _lib.build_read_matchers([l[0] for l in loci], [l[1] for l in loci], [list(l[2]) for l in loci],
+    built = _lib.build_read_matchers([l[0] for l in loci], [l[1] for l in loci], [l[2] for l in loci],
                                      [int(l[3]) for l in loci], settings.MAX_ERROR_RATE, exp=exp, threads=threads,
                                      align=align)
     return [Model._from_built(b, 'Read Matcher') for b in built]

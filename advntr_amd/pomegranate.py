@@ -528,7 +528,13 @@ class _BuiltHiddenMarkovModel(HiddenMarkovModel):
     log-probabilities."""
 
     def __init__(self, built, name):
-        HiddenMarkovModel.__init__(self, name=name)
+        # (the attributes HiddenMarkovModel.__init__ sets, without the construction graph and the two State objects it makes:
+        # thousands of these are made per run; `start` / `end` appear with `states`)
+        self.name = str(name)
+        self.model = "HiddenMarkovModel"
+        self._start = self._end = None
+        self._device = None
+        self._flank_bases = None
         self.graph = None                      # the construction graph stays inside the native builder
         self._built = built
         self._arrays = None
@@ -537,6 +543,26 @@ class _BuiltHiddenMarkovModel(HiddenMarkovModel):
         self.silent_start, self.start_index, self.end_index = built.silent_start, built.start_index, built.end_index
         self.d = 1
         self.keymap = [{c: i for i, c in enumerate("ACGT")}]
+
+    @property
+    def start(self):
+        if self._start is None:
+            self.states
+        return self._start
+
+    @start.setter
+    def start(self, value):
+        self._start = value
+
+    @property
+    def end(self):
+        if self._end is None:
+            self.states
+        return self._end
+
+    @end.setter
+    def end(self, value):
+        self._end = value
 
     @property
     def states(self):

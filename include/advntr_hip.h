@@ -201,6 +201,8 @@ int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, co
 int advntr_align_repeats(const char *const *units, int32_t n, char *out, int64_t capacity, int32_t *width);
 /* info[6] = m, silent_start, start_index, end_index, n_edges, bytes of the '\n'-joined state names (no NUL) */
 int advntr_built_info(const advntr_built *built, int32_t *info);
+/* the same for n models at once: info[6 i .. 6 i + 5] (a NULL model: six -1) */
+int advntr_built_info_many(const advntr_built *const *built, int32_t n, int32_t *info);
 /* copy out the arrays advntr_hmm_create takes (any pointer may be NULL to skip it) */
 int advntr_built_export(const advntr_built *built, int32_t *in_ptr, int32_t *in_src, double *in_logp,
                         double *emis_logp, uint16_t *state_class, char *names);
