@@ -169,14 +169,27 @@ def encode_ascii(seqs, threads=0):
         np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n), out=off[1:])
     if n and off[n] >= LONG_TEXT_MEAN * n:
         return _encode_texts(seqs, off, threads)
-    raw = "".join(seqs).encode("latin-1", "replace")
-    codes = np.empty(len(raw), np.uint8)
+    text = "".join(seqs)
+    # ASCII text (every read file) is handed over as the joined string's own buffer; anything else goes through latin-1, where a
+    # character outside it becomes '?' -- "another symbol" either way
+    size = ctypes.c_ssize_t(0)
+    try:
+        raw = _as_utf8(text, ctypes.byref(size)) if text else None
+    except UnicodeError:                             # (lone surrogates have no UTF-8 form)
+        raw = None
+    if raw is None or size.value != len(text):
+        raw = text.encode("latin-1", "replace")
+    codes = np.empty(len(text), np.uint8)
     bad = np.zeros(n, np.uint8)
     check(load().advntr_encode_ascii(raw, ptr(off), n, int(threads), ptr(codes), ptr(bad)))
+    del text
     return codes, off, bad
 
 
 LONG_TEXT_MEAN = 2048          # mean read length from which the reads are encoded out of their own buffers
+_as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize          # (for an ASCII str: its own buffer, no copy)
+_as_utf8.restype = ctypes.c_void_p
+_as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
 
 
 def _encode_texts(seqs, off, threads=0):
@@ -184,9 +197,7 @@ def _encode_texts(seqs, off, threads=0):
     re-encoding 40 MB of text in Python costs more than the alignment kernel that follows.  A str whose UTF-8 form is
     not one byte per character (so: not ASCII) goes through latin-1 'replace' like the joined path's text does."""
     n = len(seqs)
-    as_utf8 = ctypes.pythonapi.PyUnicode_AsUTF8AndSize
-    as_utf8.restype = ctypes.c_void_p
-    as_utf8.argtypes = [ctypes.py_object, ctypes.POINTER(ctypes.c_ssize_t)]
+    as_utf8 = _as_utf8
     ptrs = np.zeros(n, np.uint64)
     keep = []                                   # bytes objects made here: alive until the call returns
     size = ctypes.c_ssize_t(0)
