@@ -365,18 +365,18 @@ def main():
     adv_locus("s300_f30_l12_c3", 12, 30, [p12], [p12], 3, 0.05, 48, 60, -1.0, with_forward=True,
               extra=["", "G"])
     # REF150: flank 150, 14-bp pattern, copies 11 -> 1413 / 921 / 4626 (the model adVNTR builds for 150-bp reads)
-    adv_locus("ref150_f150_l14_c11", 13, 150, [p14], [p14], 11, 0.05, 40, 150, -0.9)
+    adv_locus("ref150_f150_l14_c11", 13, 150, [p14], [p14], 11, 0.05, 40, 150, -0.9, with_forward=True)
     # multi-repeat profile from the reference fixture's own 8-row alignment (one insert-prone column)
     units = [r.replace("-", "") for r in fixture_alignment]
     adv_locus("msa8_f50_c4", 14, 50, units, fixture_alignment, 4, 0.05, 40, 100, -1.0, with_forward=True)
     # hand-aligned rows with a majority-gap (insert) column and a deleted column
     rows = ["ACGT-TAGGCA", "ACGT-TAGGCA", "ACGTCTAGGCA", "ACG--TAGGCA", "ACGT-TA-GCA", "ACGT-TTGGCA"]
-    adv_locus("msa_gaps_f40_c5", 15, 40, [r.replace("-", "") for r in rows], rows, 5, 0.05, 40, 80, None)
+    adv_locus("msa_gaps_f40_c5", 15, 40, [r.replace("-", "") for r in rows], rows, 5, 0.05, 40, 80, None, with_forward=True)
     # short pattern, many copies (copies = round(100/6+0.5) = 17)
-    adv_locus("p6_f100_c17", 16, 100, [p6], [p6], 17, 0.05, 30, 100, -1.0)
+    adv_locus("p6_f100_c17", 16, 100, [p6], [p6], 17, 0.05, 30, 100, -1.0, with_forward=True)
     # PacBio settings: error 0.3, flank 100, noisy long reads
     adv_locus("pacbio_f100_l30_c6", 17, 100, [p30], [p30], 6, 0.3, 24, 340, None, sub=0.04, ins=0.05,
-              dele=0.04)
+              dele=0.04, with_forward=True)
     generic_model("generic_finite", 21, 9, 6, True, 40)
     generic_model("generic_infinite", 22, 7, 4, False, 40)
     genotype_cases()
