@@ -65,6 +65,7 @@ SYMBOLS = {
     "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "advntr_genotype_observed": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _vp, _vp]),
     "advntr_comm_available": (ctypes.c_int, []),
     "advntr_comm_unique_id": (ctypes.c_int, [_vp]),
     "advntr_comm_create": (_vp, [_i32, _i32, _vp]),
@@ -203,8 +204,11 @@ def _encode_texts(seqs, off, threads=0):
     size = ctypes.c_ssize_t(0)
     for r, s in enumerate(seqs):
         if isinstance(s, str):
-            p = as_utf8(s, ctypes.byref(size))
-            if p is None or size.value != len(s):
+            try:
+                p = as_utf8(s, ctypes.byref(size))
+            except UnicodeError:                 # a lone surrogate has no UTF-8 form: the latin-1 route maps it to '?'
+                p = None
+            if not p or size.value != len(s):
                 b = s.encode("latin-1", "replace")
                 keep.append(b)
                 p = ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value
@@ -657,6 +661,20 @@ def genotype_illumina(summaries, locus_off, accuracy_filter=False, is_haploid=Fa
     check(load().advntr_genotype_illumina(ptr(summaries), ptr(locus_off), n, flags, int(min_left), int(min_right), int(threads),
                                           ptr(geno), ptr(prob), ptr(counts)))
     return geno, prob, counts
+
+
+def genotype_observed(ru_counts, locus_off, accuracy_filter=False, is_haploid=False, threads=0):
+    """advntr_genotype_observed: the tail of get_dominant_copy_numbers_from_spanning_reads (vntr_finder.py:568-580) per locus:
+    RU counts of the spanning reads in scoring order -> (genotype int32[n_loci][2] with -1 for None, max_prob float64[n_loci]);
+    a locus without reads gets (-1, -1) and probability 0."""
+    ru = np.ascontiguousarray(ru_counts, np.int32)
+    locus_off = np.ascontiguousarray(locus_off, np.int64)
+    n = len(locus_off) - 1
+    geno = np.zeros((max(n, 0), 2), np.int32)
+    prob = np.zeros(max(n, 0), np.float64)
+    flags = (GENOTYPE_ACCURACY_FILTER if accuracy_filter else 0) | (GENOTYPE_HAPLOID if is_haploid else 0)
+    check(load().advntr_genotype_observed(ptr(ru), ptr(locus_off), n, flags, int(threads), ptr(geno), ptr(prob)))
+    return geno, prob
 
 
 def flank_align(reads, flanks, pair_read, pair_flank):

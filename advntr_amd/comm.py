@@ -302,17 +302,22 @@ def init_from_env(backend=None, set_device=True):
     rdzv = FileRendezvous(rank, world)
     if backend == "host":
         return HostComm(rdzv)
-    # RCCL, agreed on by all ranks.  When it cannot be used (librccl missing, driver / IPC configuration) every rank learns
-    # so at the same point of the same sequence of rendezvous steps, and the job ENDS with an error on every rank -- a gather
-    # through host files is not the path this package is about.  ADVNTR_COMM_FALLBACK=1 (explicitly) lets the ranks drop to
-    # the host communicator together instead; the choice is then visible in `.backend` and `.fallback_reason`.
+    # RCCL, agreed on by all ranks.  When it cannot be used at the SET-UP stage (librccl missing or without the entry points,
+    # rank 0 cannot make the unique id: CommSetupError) every rank learns so at the same point of the same sequence of
+    # rendezvous steps, and the job ENDS with an error on every rank -- a gather through host files is not the path this
+    # package is about.  ADVNTR_COMM_FALLBACK=1 (explicitly) lets the ranks drop to the host communicator together instead;
+    # the choice is then visible in `.backend` and `.fallback_reason`.  The fallback covers that stage ONLY: a rank whose
+    # ncclCommInitRank itself fails (driver / IPC configuration, a device error) has peers that are already inside the
+    # collective and cannot be called back, so it ends at once with the error -- the launcher (bench.py's, torchrun) then
+    # ends the job, and a peer left waiting is ended by its own watchdog (ADVNTR_COMM_INIT_TIMEOUT).
     c, err = None, b""
     try:
         c = RcclComm(rdzv)
     except CommSetupError as e:     # raised on every rank alike: nobody is inside a collective
         err = str(e).encode("utf-8", "replace")
-    except Exception as e:          # noqa: BLE001 -- this rank's communicator failed after the others may have entered theirs
-        err = ("rank %d: %s" % (rank, e)).encode("utf-8", "replace")
+    except Exception as e:          # noqa: BLE001 -- past the agreed stage: no collective fallback, no waiting for the others
+        raise RuntimeError("rank %d: RCCL communicator could not be created after every rank had agreed to (%s); the other "
+                           "ranks are inside ncclCommInitRank and end with the job" % (rank, e))
     failures = [x for x in rdzv.allgather(err) if x]
     if not failures:
         return c

@@ -288,7 +288,8 @@ extern "C" int advntr_comm_gather_results_start(advntr_comm *C, advntr_batch *B,
     HIP_TRY(hipEventRecord(C->g0, C->stream));
     // RCCL's send / receive kernels need a few workgroup slots.  The scoring kernels are persistent -- their workgroups stay
     // until the pass is done and fill every compute unit's registers --, so with peers the passes that follow leave a few
-    // slots unclaimed: the gather of pass i then runs beside pass i + 1 instead of behind it (1 % of the slots)
+    // slots unclaimed: the gather of pass i then runs beside pass i + 1 instead of behind it (1 % of the slots).  The request
+    // covers the next advntr_batch_run only and only launches that fill the device honour it (column_launch.h: launch_grid)
     if (C->world > 1) B->col.reserve_workgroups = 8;
     // both arrays in one group: one RCCL launch per rank and pass
     std::vector<int64_t> bytes_l(C->world), bytes_s(C->world);

@@ -41,6 +41,42 @@ extern "C" int advntr_genotype_illumina(const int32_t *summaries, const int64_t 
     return ADVNTR_OK;
 }
 
+extern "C" int advntr_genotype_observed(const int32_t *ru_counts, const int64_t *locus_off, int32_t n_loci, uint32_t flags,
+                                        int32_t n_threads, int32_t *out_genotype, double *out_prob)
+{
+    if (n_loci < 0 || (n_loci && (!locus_off || !out_genotype || !out_prob)))
+        return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: bad argument");
+    if (n_loci == 0) return ADVNTR_OK;
+    if (locus_off[0] < 0) return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: negative offset");
+    for (int i = 0; i < n_loci; ++i)
+        if (locus_off[i + 1] < locus_off[i]) return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: locus_off not monotone at %d", i);
+    if (locus_off[n_loci] > locus_off[0] && !ru_counts) return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: null ru_counts");
+    const bool accuracy = (flags & ADVNTR_GENOTYPE_ACCURACY_FILTER) != 0, haploid = (flags & ADVNTR_GENOTYPE_HAPLOID) != 0;
+    if (n_threads <= 0) n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = std::min(n_threads, std::max(1, n_loci / 64));
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int i0 = next.fetch_add(64);
+            if (i0 >= n_loci) return;
+            for (int i = i0; i < std::min(n_loci, i0 + 64); ++i) {
+                gt::Result r;
+                gt::dominant_copy_numbers(ru_counts + locus_off[i], locus_off[i + 1] - locus_off[i], accuracy, haploid, r);
+                out_genotype[2 * i] = r.a;
+                out_genotype[2 * i + 1] = r.b;
+                out_prob[i] = r.max_prob;
+            }
+        }
+    };
+    if (n_threads <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    return ADVNTR_OK;
+}
+
 // Host-side text handling for genome-scale batches (the Python host spent 0.4 s per 0.8 M reads on encoding, and 0.7 s per
 // 2 M reads around the prefilter kernel): line index of a FASTA text and ASCII -> base codes, on host threads.
 static int host_text_threads(int n_threads, int64_t units, int64_t per_thread)

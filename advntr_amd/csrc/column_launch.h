@@ -23,8 +23,8 @@ struct ColumnLaunch {
     int rows_depth = 1;                     // reads per lane group of the deepest row-blocked tile
     double useful_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per tile list (row-blocked kernels only): trellis cells of the reads,
     double swept_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // and cell slots the sweeps' lane-steps offer (advntr_batch_info)
-    int reserve_workgroups = 0;             // resident workgroup slots the launches leave unclaimed (a multi-GPU run's
-                                            // result gather runs beside the next pass: abi_comm.h)
+    int reserve_workgroups = 0;             // resident workgroup slots the NEXT pass leaves unclaimed (a multi-GPU run's result
+                                            // gather runs beside it: abi_comm.h); consumed by that pass (advntr_batch_run)
     std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,
                                             // [8] = row-blocked kernel for reads of more than 155 bases (row tiles)
     ColTile *d_tiles[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -33,6 +33,16 @@ struct ColumnLaunch {
     int32_t *d_aux = nullptr;
     uint8_t *d_bp = nullptr;
 };
+
+// Workgroups of one launch: the resident set, minus the slots a multi-GPU run's gather asked the NEXT pass to leave free
+// (abi_comm.h) -- honoured only by a launch that would otherwise fill the device (a small grid leaves room by itself, and
+// must not be cut down to a single workgroup), and never more than 1/16 of the grid.
+static inline int launch_grid(const ColumnLaunch &cl, int n_tiles)
+{
+    int reserve = 0;
+    if (cl.reserve_workgroups > 0 && n_tiles >= cl.grid && cl.grid >= 64) reserve = std::min(cl.reserve_workgroups, cl.grid / 16);
+    return std::min(std::max(1, cl.grid - reserve), n_tiles);
+}
 
 template <int K, bool LONG>
 static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream)
@@ -50,7 +60,7 @@ static inline void column_launch_k(const ColumnLaunch &cl, const BatchArgs &a, u
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     if (cl.lds_bytes + 16 > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
@@ -75,7 +85,7 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.rows_depth = cl.rows_depth;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -98,7 +108,7 @@ static inline void column_launch_rows_long(const ColumnLaunch &cl, const BatchAr
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     if (cl.lds_bytes + 16 > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_long_kernel<ROWS_LONG_R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(cl.lds_bytes + 16));
@@ -121,7 +131,7 @@ static inline void column_launch_stream(const ColumnLaunch &cl, const BatchArgs 
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.ring = cl.ring;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + COL_WAVES * COL_STREAM_READS * sizeof(StreamRead);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_columns_stream_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -149,7 +159,7 @@ static inline hipError_t column_launch_fwd(const ColumnLaunch &cl, const BatchAr
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)forward_columns_kernel<K, LONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -172,7 +182,7 @@ static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const Ba
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
-    const int grid = std::min(std::max(1, cl.grid - cl.reserve_workgroups), g.n_tiles);
+    const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

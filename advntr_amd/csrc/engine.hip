@@ -223,7 +223,10 @@ struct advntr_hmm {
     std::mutex gen_mu;            // guards d_gen and the generic-kernel pointers of `dev`
     int device = 0;               // the device that holds the blob
     DevModel dev{};
+    int live_batches = 0;         // batches bound to this model (guarded by g_model_life): a model destroyed while one of them is
+    bool doomed = false;          // alive is only marked and goes with the last of them (advntr_batch_destroy)
 };
+static std::mutex g_model_life;
 
 // One device allocation shared by the models of a bulk upload (advntr_built_upload_many); freed with its last model.
 // (a block of the per-device cache, like a batch's buffers: it goes back there, not to hipFree, which would wait for whatever
@@ -501,9 +504,24 @@ extern "C" advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_
     return H;
 }
 
+static void hmm_release(advntr_hmm *H);
+
+// The contract says a model outlives its batches.  A caller that breaks it (destroys a model while an asynchronous
+// advntr_batch_run may still read it, or before advntr_batch_destroy) used to get its memory reissued at once -- wrong
+// scores, silently.  The destruction is deferred instead: the last batch bound to the model releases it after its stream
+// has been synchronised.
 extern "C" void advntr_hmm_destroy(advntr_hmm *H)
 {
     if (!H) return;
+    {
+        std::lock_guard<std::mutex> lock(g_model_life);
+        if (H->live_batches > 0) { H->doomed = true; return; }
+    }
+    hmm_release(H);
+}
+
+static void hmm_release(advntr_hmm *H)
+{
     if (H->d_blob) (void)hipFree(H->d_blob);
     if (H->d_gen) (void)hipFree(H->d_gen);
     if (H->slab && H->slab->refs.fetch_sub(1) == 1) {
@@ -618,6 +636,10 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     const int32_t n_reads = both ? 2 * n_reads_in : n_reads_in;
     const int64_t total_given = read_off_in[n_reads_in];          // bytes the caller's `bases` holds
     B->models.assign(models, models + n_models);
+    {
+        std::lock_guard<std::mutex> lock(g_model_life);
+        for (advntr_hmm *H : B->models) H->live_batches++;
+    }
     B->n_reads = n_reads;
     B->flags = flags;
     if (read_off[0] != 0) return fail(ADVNTR_ERR_ARG, "batch: read_off[0] must be 0");
@@ -992,6 +1014,13 @@ extern "C" void advntr_batch_destroy(advntr_batch *B)
     if (B->ev0) g_cache.put_event(B->device, B->ev0);
     if (B->ev1) g_cache.put_event(B->device, B->ev1);
     if (B->stream) g_cache.put_stream(B->device, B->stream);
+    std::vector<advntr_hmm *> last;                               // models destroyed by their owner while this batch lived
+    {
+        std::lock_guard<std::mutex> lock(g_model_life);
+        for (advntr_hmm *H : B->models)
+            if (--H->live_batches == 0 && H->doomed) last.push_back(H);
+    }
+    for (advntr_hmm *H : last) hmm_release(H);
     delete B;
 }
 
@@ -1093,6 +1122,7 @@ extern "C" int advntr_batch_run(advntr_batch *B)
         BatchArgs a = generic_args(B);
         hipLaunchKernelGGL(viterbi_generic_kernel, dim3(B->grid_gen), dim3(ADV_WAVE), B->lds_gen, B->stream, a, B->flags);
     }
+    B->col.reserve_workgroups = 0;              // a gather's request covers one pass: the one just queued
     HIP_TRY(hipGetLastError());
     return ADVNTR_OK;
 }

@@ -154,4 +154,28 @@ static inline void repeat_count_from_selected(const int32_t *summ, int64_t n, bo
     genotype_from_observed(covered, haploid, out);
 }
 
+// vntr_finder.py:534-585 after the scoring loop: observed = the RU counts of the spanning reads in scoring order
+static inline void dominant_copy_numbers(const int32_t *ru, int64_t n, bool accuracy_filter, bool haploid, Result &out)
+{
+    if (n < 1) { out.a = out.b = -1; out.max_prob = 0.0; return; }            // "There is no spanning read": (None, 0)
+    std::vector<int> observed(ru, ru + n);
+    if (accuracy_filter) {
+        std::vector<std::pair<int, int>> cnt;
+        for (int v : observed) {
+            bool found = false;
+            for (auto &kv : cnt)
+                if (kv.first == v) { kv.second++; found = true; break; }
+            if (!found) cnt.emplace_back(v, 1);
+        }
+        std::stable_sort(cnt.begin(), cnt.end(),
+                         [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.second > y.second; });
+        std::vector<int> modified;
+        for (const auto &kv : cnt)
+            if (kv.second >= 3) modified.insert(modified.end(), (size_t)kv.second, kv.first);
+        observed.swap(modified);
+    }
+    out.recruited = out.spanning = (int32_t)n;
+    genotype_from_observed(observed, haploid, out);
+}
+
 }  // namespace gt

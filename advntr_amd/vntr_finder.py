@@ -717,6 +717,133 @@ def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, f
 _COMP_STR = str.maketrans("ACGTN", "TGCAN")
 
 
+def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=100):
+    """extract_spanning_reads for many loci in ONE advntr_flank_align call: flank_pairs[i] = (left_flanking_region,
+    right_flanking_region) of locus i, read_lists[i] = its candidate long reads.  Returns one (spanning, length_distribution)
+    pair per locus, each as extract_spanning_reads returns it (reads in input order, forward strand before reverse)."""
+    from . import settings
+    n_loci = len(flank_pairs)
+    flanks, fwd, read_locus = [], [], []
+    for i, ((lf, rf), reads) in enumerate(zip(flank_pairs, read_lists)):
+        flanks += [lf[-flanking_region_size:], rf[:flanking_region_size]]
+        for s in reads:
+            fwd.append(str(s).upper())
+            read_locus.append(i)
+    out = [([], []) for _ in range(n_loci)]
+    n = len(fwd)
+    if n == 0:
+        return out
+    read_locus = np.asarray(read_locus, np.int32)
+    strand_read = np.arange(2 * n, dtype=np.int32) // 2 + (np.arange(2 * n, dtype=np.int32) & 1) * n
+    pair_read = np.repeat(strand_read, 2)
+    pair_flank = (2 * np.repeat(read_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n)).astype(np.int32)
+    score, begin, _, _ = _lib.flank_align(fwd, flanks, pair_read, pair_flank)
+    flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
+    need = flen * (1 - settings.MAX_ERROR_RATE)
+    ok = ((score[0::2] > 0) & (score[0::2] >= need[pair_flank[0::2]]) & (score[1::2] > 0) &
+          (score[1::2] >= need[pair_flank[1::2]]) & (begin[1::2] >= begin[0::2]))
+    for k in np.flatnonzero(ok).tolist():
+        lb, rb = int(begin[2 * k]), int(begin[2 * k + 1])
+        r = k // 2
+        seq = fwd[r] if not (k & 1) else fwd[r].translate(_COMP_STR)[::-1]
+        first = int(np.searchsorted(read_locus, read_locus[r]))
+        spanning, lengths = out[int(read_locus[r])]
+        spanning.append((seq[lb:rb + flanking_region_size], r - first, bool(k & 1)))
+        lengths.append(rb - (lb + flanking_region_size))
+    return out
+
+
+def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=False, chunks=8, threads=0, timings=None,
+                         flanking_region_size=100):
+    """VNTRFinder.find_repeat_count_from_pacbio_reads (vntr_finder.py:652-665) for many loci at once, from the WHOLE long
+    reads to the RU-count genotypes: loci = [(left_flanking_region, right_flanking_region, repeat_segments, pattern), ...],
+    read_lists[i] = the candidate reads of locus i (what the keyword filter hands over).  Per piece of the locus set:
+    spanning-read extraction (both strands x two flanks of every read in one advntr_flank_align call, :324-371), one model
+    per locus sized for its longest trimmed read (:538-549, native builder), every trimmed read scored on the forward strand
+    in one engine batch (:550-555); a preparation thread extracts, builds, uploads and encodes piece k + 1 while the calling
+    thread has piece k scored, as genotype_loci_pipelined does.  The >= 3-reads support filter and the maximum-likelihood
+    call (:568-580) run once at the end on host threads (advntr_genotype_observed).  settings.MAX_ERROR_RATE is the
+    caller's (0.3 for PacBio, advntr_commands.py).  Returns one GenotypeResult per locus, as the reference builds it
+    (:665): GenotypeResult(copy_numbers, n_spanning, n_spanning, 0, max_prob).  timings (a dict) receives wall seconds per
+    stage.  Extraction is PARITY UNPINNED with respect to biopython (see extract_spanning_reads)."""
+    import queue
+    import threading
+    import time
+    from . import hmm_utils
+    n_loci = len(loci)
+    chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
+    cuts = [n_loci * i // chunks for i in range(chunks + 1)]
+    ready = queue.Queue(maxsize=2)
+    T = dict(extract_spanning=0.0, build_models=0.0, upload_models=0.0, encode_reads=0.0, score=0.0, genotype=0.0)
+
+    def prepare():
+        try:
+            for k in range(chunks):
+                lo, hi = cuts[k], cuts[k + 1]
+                t = time.perf_counter()
+                ext = extract_spanning_reads_multi([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
+                T["extract_spanning"] += time.perf_counter() - t
+                t = time.perf_counter()
+                have = [i for i in range(hi - lo) if ext[i][0]]
+                desc = []
+                for i in have:
+                    left, right, segments, pattern = loci[lo + i]
+                    copies = pacbio_max_copies([len(s[0]) for s in ext[i][0]], len(pattern))
+                    desc.append((left[-flanking_region_size:], right[:flanking_region_size], segments, copies))
+                models = hmm_utils.build_read_matcher_models(desc, threads=threads) if desc else []
+                T["build_models"] += time.perf_counter() - t
+                t = time.perf_counter()
+                device_models(models)
+                T["upload_models"] += time.perf_counter() - t
+                t = time.perf_counter()
+                trimmed = [s[0] for i in have for s in ext[i][0]]
+                which = np.repeat(np.arange(len(have), dtype=np.int32), [len(ext[i][0]) for i in have])
+                enc = _lib.encode_reads(trimmed) if trimmed else None
+                T["encode_reads"] += time.perf_counter() - t
+                ready.put((k, have, models, enc, which))
+        except BaseException as e:
+            ready.put(e)
+
+    t0 = time.perf_counter()
+    worker = threading.Thread(target=prepare, name="advntr-prepare-pacbio")
+    worker.start()
+    ru_parts, count = [], np.zeros(n_loci, np.int64)
+    try:
+        for _ in range(chunks):
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            k, have, models, enc, which = item
+            t = time.perf_counter()
+            if enc is not None:
+                _, summ, _ = _lib.viterbi_batch(device_models(models), enc[0], enc[1], which, want_paths=False, want_summary=True)
+                ru_parts.append(summ[:, _lib.SUM_RU].astype(np.int32))
+                np.add.at(count, cuts[k] + np.asarray(have, np.int64)[which], 1)
+            T["score"] += time.perf_counter() - t
+            del models, enc
+    except BaseException:
+        while worker.is_alive():
+            try:
+                ready.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        raise
+    finally:
+        worker.join()
+    t = time.perf_counter()
+    off = np.zeros(n_loci + 1, np.int64)
+    np.cumsum(count, out=off[1:])
+    ru = np.concatenate(ru_parts) if ru_parts else np.zeros(0, np.int32)       # pieces and loci in ascending order: grouped by locus
+    geno, prob = _lib.genotype_observed(ru, off, accuracy_filter, is_haploid, threads)
+    out = [GenotypeResult(None if a < 0 else (a, b), int(c), int(c), 0, p)
+           for (a, b), p, c in zip(geno.tolist(), prob.tolist(), count.tolist())]
+    T["genotype"] = time.perf_counter() - t
+    T["total"] = time.perf_counter() - t0
+    if timings is not None:
+        timings.update(T)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # Model update from the sample's own reads (vntr_finder.py:667-697, the `update` mode of genotyping)
 # ------------------------------------------------------------------------------------------------

@@ -227,3 +227,99 @@ def make_c4(n_loci, seed=20240603, n_reads=20, workers=None, only=None):
         reads += rs
         which += [i] * len(rs)
     return loci, reads, np.asarray(which, dtype=np.int32)
+
+
+def _pacbio_whole_locus(args):
+    """One PacBio locus as _c4_locus draws it, with its reads as the sequencer delivers them: WHOLE reads of
+    U(min_len, max_len) bases, either strand, that hold a noisy copy of (300 flank bases + VNTR at +-20 % of the reference
+    copy number + 300 flank bases) somewhere inside; every tenth read is unrelated sequence (a false candidate of the
+    keyword filter).  Returns ((left_flanking_region, right_flanking_region, repeat_segments, pattern), reads)."""
+    k, seed, n_reads, min_len, max_len = args
+    from .vntr_finder import reverse_complement
+    rng = np.random.default_rng([seed, k])
+    plen = int(rng.integers(10, 61))
+    ref_copies = max(2, int(round(int(rng.integers(100, 1001)) / plen)))
+    left, right, pattern = rand_seq(rng, 500), rand_seq(rng, 500), rand_seq(rng, plen)
+    reads = []
+    for j in range(n_reads):
+        n = int(rng.integers(min_len, max_len + 1))
+        if j % 10 == 9:
+            reads.append(rand_seq(rng, n))
+            continue
+        c = max(1, int(round(ref_copies * (0.8 + 0.4 * rng.random()))))
+        core = noisy_copy(rng, left[-300:] + pattern * c + right[:300])
+        n = max(n, len(core) + 2)
+        at = int(rng.integers(0, n - len(core)))
+        s = rand_seq(rng, at) + core + rand_seq(rng, n - at - len(core))
+        reads.append(s if rng.random() < 0.5 else reverse_complement(s))
+    return (left, right, [pattern], pattern), reads
+
+
+def make_pacbio_whole_reads(n_loci, seed=20240603, n_reads=20, min_len=5000, max_len=15000, workers=None):
+    """(loci, read_lists) for vntr_finder.genotype_pacbio_loci: BASELINE config 5's loci (the C4 recipe) with
+    whole 5-15 kb reads instead of already trimmed ones."""
+    import multiprocessing as mp
+    import os
+    workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
+    jobs = [(k, seed, n_reads, min_len, max_len) for k in range(n_loci)]
+    if workers == 1 or n_loci < 4:
+        res = [_pacbio_whole_locus(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            res = pool.map(_pacbio_whole_locus, jobs, chunksize=4)
+    return [r[0] for r in res], [r[1] for r in res]
+
+
+# ------------------------------------------------------------------------------------------------
+# Upstream stages (SURVEY 8f-3 / 8f-4): the keyword prefilter's and the flank alignment's bench inputs
+# ------------------------------------------------------------------------------------------------
+def make_prefilter_workload(n_loci=6719, n_reads=2000000, read_len=150, locus_every=100, seed=20240604):
+    """The Illumina prefilter at model-database scale: the 15-mer keyword sets of n_loci synthetic loci (a keyword every 5
+    bases over 15 + VNTR + 15, vntr_finder.py:140-153) and n_reads reads of read_len bases as the BYTES OF A TWO-LINE FASTA
+    FILE -- what adVNTR-Filtering reads (filtering/main.cc:247-252); every locus_every-th read is cut from a locus, the rest
+    are windows of random sequence.  Returns (keyword lines [(vntr id, set of keywords)], fasta bytes, record length): every
+    record is b'>r%07d\\n' + bases + b'\\n', so record r starts at r * record length."""
+    from .filtering import get_keywords_for_filtering
+    rng = np.random.default_rng(seed)
+    lines, loci = [], []
+    for v in range(n_loci):
+        plen = int(rng.integers(6, 101))
+        pat = rand_seq(rng, plen)
+        reps = [pat] * int(rng.integers(2, 21))
+        left, right = rand_seq(rng, 15), rand_seq(rng, 15)
+        lines.append((v + 1, get_keywords_for_filtering(left, reps, right, pat, True, 15)))
+        if v < 200:
+            loci.append(left + "".join(reps) + right)
+    big = _ACGT[rng.integers(0, 4, read_len * 50000)]
+    rec_len = 10 + read_len + 1
+    r = np.arange(n_reads, dtype=np.int64)
+    head = np.empty((n_reads, 10), np.uint8)
+    head[:, 0], head[:, 1], head[:, 9] = ord(">"), ord("r"), 10
+    for d in range(7):
+        head[:, 8 - d] = 48 + (r // 10 ** d) % 10
+    start = (r * 137) % (len(big) - read_len)
+    fasta = np.concatenate([head, np.lib.stride_tricks.sliding_window_view(big, read_len)[start],
+                            np.full((n_reads, 1), 10, np.uint8)], axis=1)
+    if locus_every:
+        for k in range(0, n_reads, locus_every):
+            s = loci[k % len(loci)]
+            s = (s * (read_len // len(s) + 1))[:read_len]
+            fasta[k, 10:10 + read_len] = np.frombuffer(s.encode(), np.uint8)
+    return lines, fasta.tobytes(), rec_len
+
+
+def make_flank_align_workload(n_reads=4000, min_len=5000, max_len=15000, seed=11):
+    """PacBio-sized input of advntr_flank_align: two 100-base flanks and n_reads reads of 5-15 kb, a third of which hold a
+    noisy copy (12 %) of flank + repeats + flank.  Returns (left, right, reads)."""
+    rng = np.random.default_rng(seed)
+    left, right, pattern = rand_seq(rng, 100), rand_seq(rng, 100), rand_seq(rng, 40)
+    reads = []
+    for k in range(n_reads):
+        n = int(rng.integers(min_len, max_len + 1))
+        s = rand_seq(rng, n)
+        if k % 3 == 0:
+            core = noisy_copy(rng, left + pattern * int(rng.integers(3, 20)) + right, 0.12)
+            at = int(rng.integers(0, n - len(core)))
+            s = s[:at] + core + s[at + len(core):]
+        reads.append(s)
+    return left, right, reads

@@ -93,9 +93,10 @@ void advntr_trim(void);                      /* release the cached device buffer
 advntr_hmm *advntr_hmm_create(int32_t m, int32_t silent_start, int32_t start_index, int32_t end_index,
                               int32_t n_edges, const int32_t *in_ptr, const int32_t *in_src,
                               const double *in_logp, const double *emis_logp, const uint16_t *state_class);
-void advntr_hmm_destroy(advntr_hmm *model);  /* replaces free_bake_buffers, hmm.pyx:332-346.  A model must outlive the
-                                              * batches made from it (their results fetched or their stream synchronised:
-                                              * its device memory is reused by later uploads)                                */
+void advntr_hmm_destroy(advntr_hmm *model);  /* replaces free_bake_buffers, hmm.pyx:332-346.  A model should outlive the
+                                              * batches made from it; one destroyed earlier is only marked and is released
+                                              * by the last of its batches (advntr_batch_destroy, after that batch's stream
+                                              * has been synchronised) -- its device memory is reused by later uploads      */
 /* 1 if the model was recognised as a flank-repeats-flank read matcher (hmm_utils.py:553-595) and has
  * a column program for the anti-diagonal kernel; 0 if it runs on the generic-CSR kernel.              */
 int advntr_hmm_has_column_program(const advntr_hmm *model);
@@ -266,6 +267,14 @@ int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flag
 int advntr_genotype_illumina(const int32_t *summaries, const int64_t *locus_off, int32_t n_loci, uint32_t flags,
                              int32_t min_left_flank, int32_t min_right_flank, int32_t n_threads,
                              int32_t *out_genotype, double *out_prob, int32_t *out_counts);
+/* The PacBio counterpart: the tail of VNTRFinder.get_dominant_copy_numbers_from_spanning_reads
+ * (/root/reference/advntr/vntr_finder.py:568-580) for many loci at once.  ru_counts: the RU count of every spanning read
+ * (ADVNTR_SUM_RU of its summary record) in the order the reads were scored, locus i = ru_counts[locus_off[i] ..
+ * locus_off[i+1]); with ADVNTR_GENOTYPE_ACCURACY_FILTER only RU counts seen in >= 3 reads survive
+ * (Counter.most_common order, :571-575); then find_genotype_based_on_observed_repeats (:485-532).  A locus without reads
+ * gets -1, -1 and probability 0 (the reference returns (None, 0), :535-537).  Outputs as above.                       */
+int advntr_genotype_observed(const int32_t *ru_counts, const int64_t *locus_off, int32_t n_loci, uint32_t flags,
+                             int32_t n_threads, int32_t *out_genotype, double *out_prob);
 
 /* ---- multi-GPU: the gather of the result records over RCCL / xGMI --------------------------------------------
  * One process per GPU; whole loci (with all their reads) are assigned to ranks (advntr_amd/sharding.py), so scoring

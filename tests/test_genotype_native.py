@@ -83,3 +83,41 @@ def test_argument_errors():
     import pytest
     with pytest.raises(_lib.EngineError):
         _lib.genotype_illumina(np.zeros((2, 8), np.int32), np.array([0, 3, 2]))
+
+
+def test_genotype_observed_on_the_reference_goldens_and_the_python_mirror():
+    """advntr_genotype_observed = the tail of get_dominant_copy_numbers_from_spanning_reads (vntr_finder.py:568-580): the
+    reference's own genotype cases bit-equal; with the >= 3-reads filter against the Python mirror on random loci."""
+    from collections import Counter
+    g = load_golden("genotype_cases")
+    for haploid in (False, True):
+        cases = [c for c in g["cases"] if bool(c["haploid"]) == haploid]
+        ru = np.array([r for c in cases for r in c["observed"]], np.int32)
+        off = np.concatenate([[0], np.cumsum([len(c["observed"]) for c in cases])])
+        geno, prob = _lib.genotype_observed(ru, off, is_haploid=haploid)
+        for c, ab, p in zip(cases, geno.tolist(), prob.tolist()):
+            assert (None if ab[0] < 0 else ab) == c["genotype"], c
+            assert p == c["max_prob"], c
+    rng = np.random.default_rng(5)
+    groups = [[int(v) for v in np.maximum(0, rng.integers(0, 12) + rng.choice([0, 0, 0, 1, -1, 4], int(rng.integers(0, 30))))]
+              for _ in range(400)] + [[], [0, 0, 0], [4], [7] * 30 + [8] * 29]
+    ru = np.array([v for grp in groups for v in grp], np.int32)
+    off = np.concatenate([[0], np.cumsum([len(grp) for grp in groups])])
+    for accuracy in (False, True):
+        for haploid in (False, True):
+            for threads in (1, 4):
+                geno, prob = _lib.genotype_observed(ru, off, accuracy, haploid, threads)
+                for grp, ab, p in zip(groups, geno.tolist(), prob.tolist()):
+                    if not grp:
+                        assert ab == [-1, -1] and p == 0.0        # "There is no spanning read": (None, 0)
+                        continue
+                    obs = list(grp)
+                    if accuracy:
+                        obs = [k for k, c in Counter(obs).most_common() if c >= 3 for _ in range(c)]
+                    with np.errstate(all="ignore"):
+                        want, wp = vntr_finder.find_genotype_based_on_observed_repeats(obs, haploid)
+                    assert (None if ab[0] < 0 else tuple(ab)) == want, (accuracy, haploid, grp)
+                    assert p == wp
+    import pytest
+    with pytest.raises(_lib.EngineError):
+        _lib.genotype_observed(np.zeros(2, np.int32), np.array([0, 3, 2]))

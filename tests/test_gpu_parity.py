@@ -996,3 +996,40 @@ def test_reads_of_a_hundred_thousand_bases():
     for i, r in enumerate(reads):
         olp, opath = O.viterbi(r, path_cap=4 * (len(r) + a["m"]))
         assert logp[i] == olp and paths[i] == opath, (i, len(r))
+
+
+def test_model_destroyed_before_its_batch_is_released_by_the_batch():
+    """advntr_hmm_destroy on a model that a live batch is bound to (a C-ABI caller breaking the ownership contract) must
+    not hand the model's memory to the next upload: the release is deferred to advntr_batch_destroy.  The batch keeps
+    scoring correctly while other models are uploaded over the cache the memory would have gone to."""
+    import gc
+    from advntr_amd import _lib, workloads, hmm_utils
+    from advntr_amd.pomegranate import device_models
+    rng = np.random.default_rng(77)
+    L = _lib.load()
+    specs = []
+    for k in (9, 14, 33):
+        loc = workloads.make_locus(rng, 150, k, 4, n_units=2)
+        specs.append((loc.left, loc.right, loc.units, loc.copies))
+    reads = [workloads.rand_seq(rng, 150) for _ in range(64)] + [s[2][0] * 6 for s in specs]
+    bases, off = _lib.encode_reads(reads * 3)
+    which = np.repeat(np.arange(3, dtype=np.int32), len(reads))
+    models = hmm_utils.build_read_matcher_models(specs)
+    dms = device_models(models)                                     # one slab for the three
+    want = _lib.viterbi_batch(dms, bases, off, which)
+    batch = _lib.DeviceBatch(dms, bases, off, which)
+    for d in dms:                                                   # the owner lets go while the batch is alive
+        L.advntr_hmm_destroy(d._h)
+        d._h = None
+    del dms, models
+    gc.collect()
+    others = []
+    for _ in range(3):                                              # uploads that would reuse a released slab
+        more = hmm_utils.build_read_matcher_models([(workloads.rand_seq(rng, 150), workloads.rand_seq(rng, 150),
+                                                     [workloads.rand_seq(rng, 21)], 5) for _ in range(3)])
+        others.append((more, device_models(more)))
+    batch.run()
+    logp, summ = batch.fetch()
+    assert np.array_equal(logp, want[0]) and np.array_equal(summ, want[1])
+    batch.models = []                                               # (the wrapper's references: handles are gone already)
+    batch.close()

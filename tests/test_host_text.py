@@ -52,6 +52,7 @@ def test_long_reads_are_encoded_out_of_their_own_buffers():
     alphabet = np.array(list("ACGTacgtNn-"))
     seqs = ["".join(rng.choice(alphabet[:11 if k % 7 == 0 else (10 if k % 3 == 0 else 8)], int(rng.integers(0, 9000)))) for k in range(120)]
     seqs[5] = "ACGT\u00e9" * 900
+    seqs[9] = "ACGT" * 600 + "\ud800" + "ACGT" * 100            # a lone surrogate (no UTF-8 form at all) in a long read
     as_text = list(seqs)
     seqs[7] = seqs[7].encode()
     off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
@@ -62,7 +63,7 @@ def test_long_reads_are_encoded_out_of_their_own_buffers():
     finally:
         _lib.LONG_TEXT_MEAN = limit
     assert np.array_equal(c, c2) and np.array_equal(o, o2) and np.array_equal(b, b2)
-    assert b[5] == 2 and set(b.tolist()) == {0, 1, 2}
+    assert b[5] == 2 and b[9] == 2 and set(b.tolist()) == {0, 1, 2}
     c3, _, b3 = _lib.encode_ascii(as_text)                         # mean length above LONG_TEXT_MEAN: the pointer route
     assert off[-1] >= _lib.LONG_TEXT_MEAN * len(seqs) and np.array_equal(c3, c2) and np.array_equal(b3, b2)
     with pytest.raises(_lib.EngineError):
