@@ -39,6 +39,7 @@ SYMBOLS = {
     "advntr_batch_destroy": (None, [_vp]),
     "advntr_batch_run": (ctypes.c_int, [_vp]),
     "advntr_batch_sync": (ctypes.c_int, [_vp]),
+    "advntr_batch_reserve_next": (ctypes.c_int, [_vp, _i32]),
     "advntr_batch_run_timed": (ctypes.c_int, [_vp, _i32, _vp]),
     "advntr_batch_forward": (ctypes.c_int, [_vp]),
     "advntr_batch_forward_timed": (ctypes.c_int, [_vp, _i32, _vp]),
@@ -589,6 +590,10 @@ class DeviceBatch(object):
 
     def sync(self):
         check(load().advntr_batch_sync(self._h))
+
+    def reserve_next(self, n_workgroups):
+        """The next run() leaves n workgroup slots free (what the multi-GPU gather asks for; one pass)."""
+        check(load().advntr_batch_reserve_next(self._h, int(n_workgroups)))
 
     def run_timed(self, iters):
         ms = ctypes.c_float(0)

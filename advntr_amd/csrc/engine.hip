@@ -1127,6 +1127,13 @@ extern "C" int advntr_batch_run(advntr_batch *B)
     return ADVNTR_OK;
 }
 
+extern "C" int advntr_batch_reserve_next(advntr_batch *B, int32_t n_workgroups)
+{
+    if (!B || n_workgroups < 0) return fail(ADVNTR_ERR_ARG, "advntr_batch_reserve_next: bad argument");
+    B->col.reserve_workgroups = n_workgroups;
+    return ADVNTR_OK;
+}
+
 extern "C" int advntr_batch_sync(advntr_batch *B)
 {
     if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_sync: null batch");

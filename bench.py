@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-c2", action="store_true",
                     help="c1 at --gpus 1: leave out the `c2` and `end_to_end` sub-records (the 6719-locus target configuration)")
     ap.add_argument("--c2-loci", type=int, default=6719, help="loci of the `c2` / `end_to_end` sub-records")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="one process, one GPU: partition the C3 locus set for this many ranks (LPT, as --gpus N does), run every "
+                         "rank's share as its own resident batch with the multi-GPU launch parameters and print a "
+                         "`scale_rehearsal` record -- a PROJECTION of the strong-scaling line, not a measurement of it")
     ap.add_argument("--no-upstream", action="store_true",
                     help="c1 at --gpus 1: leave out the `c4`, `pacbio_end_to_end`, `prefilter` and `flank_align` sub-records")
     ap.add_argument("--c4-loci", type=int, default=8960, help="loci of the `c4` sub-record (BASELINE config 5)")
@@ -511,11 +515,16 @@ def main(argv=None):
             out["log_probability"] = forward_record(_lib, locus, batch, bases, off, n_reads, n, args)
             if c2_input is not None:
                 out["end_to_end"], out["c2"] = target_configuration_records(_lib, workloads, c2_input, flags, args)
+                out["scale_rehearsal"] = out["c2"].pop("scale_rehearsal")
             if upstream_input is not None:
                 out["c4"] = c4_record(_lib, workloads, upstream_input, flags, args)
                 out["pacbio_end_to_end"] = pacbio_end_to_end_record(_lib, upstream_input, args)
                 out["flank_align"] = flank_align_record(_lib, upstream_input, args)
                 out["prefilter"] = prefilter_record(_lib, upstream_input, args)
+        if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3"):
+            out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
+                                                     {"calls": int(n_reads), "loop_ms": elapsed / args.steps * 1e3,
+                                                      "kernel_ms": kernel_ms}, flags, max(1, args.steps))
         if workload == "c1" and world == 1 and not args.no_cpu:
             cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
@@ -604,6 +613,61 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     return rec
 
 
+def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps):
+    """What a 1-GPU lease can say about the north star's "strong scaling to 8 GPUs": the C3 locus set partitioned for
+    n_ranks ranks exactly as `--gpus N` partitions it (whole loci, LPT on calls x (n+1) x states, sharding.partition_loci), and
+    every rank's share run on THIS GPU as its own resident batch with the launch parameters of the multi-GPU job (the slots
+    the gather asks each pass to leave free: advntr_batch_reserve_next(8)).  projected_efficiency = T(whole set, 1 rank) /
+    (n_ranks x slowest share): what load balance, the per-launch costs that do not shrink with the batch and the partial last
+    round of resident wavefronts leave of perfect strong scaling, BEFORE the gather (43 MB over xGMI per pass, overlapped with
+    the next pass by design) and before any difference between GPUs.  A projection, labelled as such; the measured curve is
+    the driver's SCALE run."""
+    lens = np.diff(off)
+    ms = np.array([d.m for d in dms])
+    calls = np.bincount(which, minlength=len(dms))
+    work = [int(calls[k]) * 151 * int(ms[k]) for k in range(len(dms))]
+    parts = sharding.partition_loci(work, n_ranks)
+    loads = [float(sum(work[int(k)] for k in p)) for p in parts]
+    uniform = bool(len(lens) and lens.min() == lens.max())
+    shares = []
+    for r, mine in enumerate(parts):
+        remap = np.full(len(dms), -1, np.int32)
+        remap[mine] = np.arange(len(mine), dtype=np.int32)
+        sel = remap[which] >= 0
+        if uniform:
+            sub_bases = bases.reshape(len(lens), -1)[sel].reshape(-1)
+        else:
+            sub_bases = bases[np.repeat(sel, lens)]
+        sub_off = np.zeros(int(sel.sum()) + 1, np.int64)
+        np.cumsum(lens[sel], out=sub_off[1:])
+        batch = _lib.DeviceBatch([dms[int(k)] for k in mine], sub_bases, sub_off, remap[which[sel]], flags=flags)
+        for _ in range(2):
+            batch.reserve_next(8)
+            batch.run()
+        batch.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            batch.reserve_next(8)
+            batch.run()
+        batch.sync()
+        loop_ms = (time.perf_counter() - t0) / steps * 1e3
+        kernel_ms = batch.run_timed(steps)                  # (no reservation: the kernel alone)
+        shares.append({"rank": r, "loci": int(len(mine)), "calls": int(sel.sum()), "loop_ms": loop_ms, "kernel_ms": kernel_ms})
+        batch.close()
+    worst_loop = max(x["loop_ms"] for x in shares)
+    worst_kernel = max(x["kernel_ms"] for x in shares)
+    return {"projection": True, "ranks": n_ranks, "whole_set": whole, "shares": shares,
+            "sum_of_shares_loop_ms": sum(x["loop_ms"] for x in shares), "slowest_share_loop_ms": worst_loop,
+            "load_imbalance_max_over_mean": max(loads) / (sum(loads) / n_ranks),
+            "projected_efficiency": whole["loop_ms"] / (n_ranks * worst_loop),
+            "projected_efficiency_kernels_only": whole["kernel_ms"] / (n_ranks * worst_kernel),
+            "projected_value_calls_per_s": float(len(lens)) / (worst_loop * 1e-3),
+            "excludes": "the RCCL gather of the result records (40 B per call to rank 0, queued behind pass i and overlapped with "
+                        "pass i + 1) and differences between the GPUs of a node",
+            "note": "ONE GPU ran the %d shares one after the other; each share is a rank's whole batch (its models, its calls), "
+                    "launched as the multi-GPU job launches it" % n_ranks}
+
+
 def target_configuration_records(_lib, workloads, c2_input, flags, args):
     """The north star's target configuration on one GPU (BASELINE config 2: 6719 Illumina loci x a 30x-equivalent read
     batch) as two sub-records of the C1 line.
@@ -690,6 +754,9 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
                        "frac": achieved / HBM_PEAK_GBPS, "algorithmic_gb_per_launch": alg / 1e9,
                        "traffic": traffic / 1e9 if traffic else None, "traffic_source": pmc.get("file"),
                        "note": "exact sum over the calls of n + (n+1) m + (n+m) + 32 bytes (SURVEY 8d) / HIP-event kernel time"}}
+    from advntr_amd import sharding
+    c2["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
+                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps)
     if not args.no_cpu:
         # per-locus sample against the oracle: log-probabilities bit for bit, repeat-unit counts as hmm_utils derives them
         # from the oracle's path; its single-thread rate on these models prices the whole set for the reference

@@ -130,6 +130,11 @@ advntr_batch *advntr_batch_create(advntr_hmm *const *models, int32_t n_models, c
 void advntr_batch_destroy(advntr_batch *batch);
 int advntr_batch_run(advntr_batch *batch);
 int advntr_batch_sync(advntr_batch *batch);
+/* The NEXT advntr_batch_run leaves up to n_workgroups resident workgroup slots unclaimed (launches that would fill the
+ * device only, at most 1/16 of a launch): what advntr_comm_gather_results_start asks for with peers, so that RCCL's
+ * kernels run beside the pass -- exported so that a one-GPU rehearsal of a rank's share runs with the launch parameters
+ * of the multi-GPU job (bench.py --emulate-ranks).  The request covers one pass.                                      */
+int advntr_batch_reserve_next(advntr_batch *batch, int32_t n_workgroups);
 int advntr_batch_run_timed(advntr_batch *batch, int32_t iters, float *ms_per_run);
 /* Model.log_probability over a resident batch (hmm.pyx:1258-1313): the sum-product kernels on the uploaded reads,
  * results in the batch's logp array (fetch with advntr_batch_fetch; summaries untouched); _timed as run_timed.     */
