@@ -65,17 +65,53 @@ __device__ __forceinline__ int fa_window(const uint8_t *__restrict__ read, const
     return c > 3 ? 4 : (rev ? 3 - c : c);
 }
 
-// One (read, flank) pair per wavefront.  The READ BASES travel through the lanes like the scores do: lane j works on read
-// position i = s - j at step s, so the base it needs is the one its left neighbour used a step earlier -- one DPP shift per
-// chunk and step -- and the base that enters at lane 0 comes out of a 64-base window register (lane l <- read[64 w + l],
-// loaded once per 64 steps, one window ahead, rotated by one lane per step).  No per-lane load, no address arithmetic and no
-// clamping inside the sweep (the first version fetched read[clamp(i + 2)] per lane, chunk and step: the sweep then ran at six
-// cycles per vector instruction, waiting for those loads).  Rows before the read need no masking (every input of such a cell is
-// zero and its base matches nothing); rows past the read's end occur only in the last lf - 1 steps, which run in a loop of
-// their own; columns past the flank's end are masked with a loop-invariant lane mask.  The running best is ONE register per
-// chunk, score << 23 | (read position + 1): a later row wins a tie by being the larger number.
+// ---- two passes per (read, flank) pair ------------------------------------------------------------------------------
+// Pass 1 finds the best local score and the LAST best cell in row-major order with a sweep that carries nothing but scores:
+// a flank has at most 128 bases, so a score fits 16 bits and the two 64-column chunks of a lane travel in the two halves of
+// ONE register (v_pk_add_i16 / v_pk_max_i16 / v_pk_min_u16 / v_pk_mad_i16): 19 vector instructions per step of 128 cells where
+// the sweep that also carried the start coordinates took 56.
+//   * the read bases move through the lanes as before (one DPP shift per step, lane 0 fed from a 64-base window register),
+//     both chunks in one register: the base that leaves lane 63 of the low half enters lane 0 of the high half (the value
+//     shifted left by 16 and rotated by one lane is the `old` operand of the shift);
+//   * match / mismatch of both halves without a compare: x = bases ^ flank, t = min_u16(x, 1), m = 1 - 2 t;
+//   * the running best is one 32-bit key per chunk, score << 24 | (read position + 1), built with one v_perm_b32 and kept with
+//     one v_max_u32: a later row wins a tie by being the larger number;
+//   * nothing is masked: columns past the flank's end and rows past the read's end only ever see mismatches, so a cell there
+//     stays below the best real cell it descends from, and rows before the read are all-zero; the lanes past the flank are left
+//     out of the final reduction.
+// Pass 2 recovers `begin` for that cell: the walk-back of a local alignment that ends at (ei, ej) with score sc stays within
+// 2 (ej + 1) rows of ei (every prefix of the path has a positive score, so mismatches + gaps < matches <= ej + 1), and on the
+// cells of that path a sweep that starts from zeros at the top of this window computes the values of the full matrix -- off the
+// path it can only be lower, which never turns a failed test of the walk-back's preference order (horizontal, diagonal,
+// vertical) into a successful one.  So the sweep that carries the start coordinates (the one this kernel used to run over
+// the whole read) runs over those rows only and is read out at (ei, ej): a few percent of a 10 kb read.
+typedef short fa_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short fa_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int fa_pk_add(int a, int b) { return __builtin_bit_cast(int, (fa_s16x2)(__builtin_bit_cast(fa_s16x2, a) + __builtin_bit_cast(fa_s16x2, b))); }
+__device__ __forceinline__ int fa_pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(fa_s16x2, a), __builtin_bit_cast(fa_s16x2, b))); }
+// (as inline assembly: given min(x, 1) the compiler rewrites the match / mismatch arithmetic below into two 16-bit compares,
+// two selects and a byte permute -- five instructions for the two this takes with the multiply-add that follows)
+__device__ __forceinline__ int fa_pk_minu(int a, int b)
+{
+    int r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int fa_pk_mad(int a, int b, int c)
+{
+    return __builtin_bit_cast(int, (fa_s16x2)(__builtin_bit_cast(fa_s16x2, a) * __builtin_bit_cast(fa_s16x2, b) + __builtin_bit_cast(fa_s16x2, c)));
+}
+// both halves one lane on: lane i <- v[i-1]; lane 0: high half <- low half of lane 63, low half <- lane0_lo (lane 0's, high half 0)
+__device__ __forceinline__ int fa_pk_shr1(int v, int lane0_lo)
+{
+    int old = __builtin_amdgcn_mov_dpp(v << 16, 0x13C, 0xf, 0xf, false);       // wave_ror:1: lane 0 <- lane 63
+    old |= lane0_lo;
+    return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);         // wave_shr:1, lane 0 keeps `old`
+}
+
 __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
 {
+    static_assert(FA_K == 2, "two chunks of 64 columns: the halves of a packed register");
     const int lane = threadIdx.x & 63;
     for (;;) {
         int q = 0;
@@ -90,85 +126,123 @@ __global__ void __launch_bounds__(FA_WAVES * 64) flank_align_kernel(FaArgs a)
         const int n = __builtin_amdgcn_readfirstlane((int)(a.read_off[r + 1] - a.read_off[r]));
         const uint8_t *flank = a.flank_bases + a.flank_off[f];
         const int lf = __builtin_amdgcn_readfirstlane(a.flank_off[f + 1] - a.flank_off[f]);
-        int b[FA_K], H[FA_K], S[FA_K], dH[FA_K], dS[FA_K], bestpk[FA_K], bS[FA_K], ai[FA_K], ij[FA_K];
-        bool colok[FA_K];
+        int b[FA_K];
 #pragma unroll
         for (int k = 0; k < FA_K; ++k) {
             const int j = 64 * k + lane;
             b[k] = j < lf ? (int)flank[j] : 255;
             if (b[k] == 4) b[k] = 5;                                   // a non-ACGT flank symbol matches nothing, not even a read's N
-            colok[k] = j < lf;
-            H[k] = S[k] = dH[k] = dS[k] = bS[k] = 0;
-            bestpk[k] = 0x007fffff;                                    // (score 0 never beats it; reads stay far below 2^23 bases)
-            ai[k] = 4;                                                 // rows before the read
-            ij[k] = ((0 - j) << 8) | j;                                // (i << 8) | j of step 0; + 256 per step
         }
-        int ip1 = 1 - lane;                                            // i + 1 of chunk 0 at step 0 (chunk k: - 64 k)
-        int win = fa_window(read, n, 0, lane, rev), winn = fa_window(read, n, 64, lane, rev);
-        auto step = [&](const int s, const bool tail) {
-            if ((s & 63) == 0 && s > 0) { win = winn; winn = fa_window(read, n, s + 64, lane, rev); }
-            // the bases move on by one lane; lane 0 of chunk 0 takes read[s] from the window
-            const int a_hi = FA_K > 1 ? fa_shr1_from(ai[FA_K - 1], ai[0]) : 0;
-            ai[0] = fa_shr1(ai[0], win);
-            if (FA_K > 1) ai[1] = a_hi;
-            win = fa_rol1(win);
-            int nH[FA_K], nS[FA_K];
+        // ---------------------------------------------------------------- pass 1: score and last best cell
+        int sc = 0, key = 0;
+        if (n > 0 && lf > 0) {
+            const int b_pk = b[0] | (b[1] << 16);
+            const int one = 0x00010001, minus1 = (int)0xffffffff, minus2 = (int)0xfffefffe;
+            int ai = 0x00040004;                                       // rows before the read match nothing
+            int H = 0, dH = 0;
+            unsigned best0 = 0, best1 = 0;
+            int row = 1 - lane;                                        // read position + 1 of chunk 0 (chunk 1: - 64)
+            int win = fa_window(read, n, 0, lane, rev), winn = fa_window(read, n, 64, lane, rev);
+            const int s_end = n + lf - 2;                              // last step with a cell of the matrix
+            auto step = [&]() {
+                ai = fa_pk_shr1(ai, win);
+                win = fa_rol1(win);
+                const int t = fa_pk_minu(ai ^ b_pk, one);              // 0: the bases are equal, 1: they differ
+                const int m = fa_pk_mad(t, minus2, one);               // +1 / -1
+                const int lH = fa_pk_shr1(H, 0);                       // (i, j-1); what it was a step earlier is (i-1, j-1)
+                const int d = fa_pk_add(dH, m);
+                const int g = fa_pk_add(fa_pk_max(H, lH), minus1);     // the better of the two gap moves
+                const int h = fa_pk_max(fa_pk_max(d, g), 0);
+                // score << 24 | (read position + 1): byte 0 of the low half / byte 2 of the high half on top of the row's three bytes
+                best0 = max(best0, __builtin_amdgcn_perm((unsigned)h, (unsigned)row, 0x04020100u));
+                best1 = max(best1, __builtin_amdgcn_perm((unsigned)h, (unsigned)row, 0x06020100u));
+                dH = lH;
+                H = h;
+                ++row;
+            };
+            for (int s0 = 0; s0 <= s_end; s0 += 64) {
+                if (s0 > 0) { win = winn; winn = fa_window(read, n, s0 + 64, lane, rev); }
+                const int cnt = min(64, s_end + 1 - s0);
+                if (cnt == 64) {
+#pragma unroll 4
+                    for (int u = 0; u < 64; ++u) step();
+                } else {
+                    for (int u = 0; u < cnt; ++u) step();
+                }
+            }
+            // best cell of the wave: score, then read position, then flank position -- the last best cell in row-major order.
+            // Position and column travel as ONE key ((read position + 1) << 8 | flank position)
 #pragma unroll
-            for (int k = FA_K - 1; k >= 0; --k) {
-                // left neighbour's values of the previous step = (i, j-1); what was shifted in one step earlier = (i-1, j-1)
-                const int lH = k == 0 ? fa_shr1(H[0], 0) : fa_shr1_from(H[k], H[k - 1]);
-                const int lS = k == 0 ? fa_shr1(S[0], 0) : fa_shr1_from(S[k], S[k - 1]);
-                const int m = ai[k] == b[k] ? 1 : -1;
-                const int d = dH[k] + m, u = H[k] - 1, l = lH - 1;
-                int h = max(max(d, u), max(l, 0));
-                // the start the walk-back reaches: horizontal first, then diagonal (a diagonal step out of a cell whose
-                // score is not positive begins the alignment here), then vertical.  (Starts of cells with score 0 are never
-                // read: whoever takes one has seen a positive score there.)
-                const int st_d = dH[k] > 0 ? dS[k] : ij[k];
-                const int st_du = d == h ? st_d : S[k];
-                const int st = l == h ? lS : st_du;
-                bool ok = colok[k];
-                if (tail) ok = ok && (ip1 - 64 * k) <= n;              // rows past the read's end
-                h = ok ? h : 0;
-                // score << 23 | (row + 1): later rows win ties; a row before the read has a negative row number and a score
-                // of zero -- a negative key, which never wins the signed comparison
-                const int pk = (h << 23) | (ip1 - 64 * k);
-                const bool upd = pk > bestpk[k];
-                bestpk[k] = upd ? pk : bestpk[k];
-                bS[k] = upd ? st : bS[k];
-                dH[k] = lH;
-                dS[k] = lS;
-                nH[k] = h;
-                nS[k] = st;
-                ij[k] += 256;
+            for (int k = 0; k < FA_K; ++k) {
+                const unsigned bk = k == 0 ? best0 : best1;
+                const int best = (int)(bk >> 24);
+                // (sign-extended 24-bit row field: rows before the read are negative, and then the score is 0)
+                const int bi1 = best > 0 ? (((int)(bk << 8)) >> 8) - 64 * k : 0;
+                const int kk = (bi1 << 8) | (64 * k + lane);
+                if (64 * k + lane < lf && (best > sc || (best == sc && best > 0 && kk > key))) { sc = best; key = kk; }
             }
 #pragma unroll
-            for (int k = 0; k < FA_K; ++k) { H[k] = nH[k]; S[k] = nS[k]; }
-            ++ip1;
-        };
-        const int s_end = n + lf - 2;                                  // last step with an active cell
-        int s = 0;
-        for (; s + 1 < n; s += 2) { step(s, false); step(s + 1, false); }      // every lane's row lies inside the read (or before it)
-        for (; s <= s_end; ++s) step(s, true);
-        // best cell of the wave: score, then read position, then flank position -- the last best cell in row-major order.
-        // Position and column travel as ONE key ((read position + 1) << 8 | flank position)
-        int sc = 0, key = 0, st = 0;
-#pragma unroll
-        for (int k = 0; k < FA_K; ++k) {
-            const int best = bestpk[k] >> 23, bi1 = best > 0 ? (bestpk[k] & 0x7fffff) : 0;
-            const int kk = (bi1 << 8) | (64 * k + lane);
-            if (best > sc || (best == sc && best > 0 && kk > key)) { sc = best; key = kk; st = bS[k]; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const int osc = __shfl_xor(sc, o, 64), okey = __shfl_xor(key, o, 64);
+                if (osc > sc || (osc == sc && osc > 0 && okey > key)) { sc = osc; key = okey; }
+            }
         }
+        sc = __builtin_amdgcn_readfirstlane(sc);
+        key = __builtin_amdgcn_readfirstlane(key);
+        const int ei = sc > 0 ? (key >> 8) - 1 : -1, ej = key & 0xff;
+        // ---------------------------------------------------------------- pass 2: the start of the walk-back from (ei, ej)
+        int begin = -1;
+        if (sc > 0) {
+            const int r0 = max(0, ei - 2 * (ej + 1) - 1);              // first row of the window
+            int H[FA_K], S[FA_K], dH[FA_K], dS[FA_K], ai[FA_K], ij[FA_K];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int osc = __shfl_xor(sc, o, 64), okey = __shfl_xor(key, o, 64), ost = __shfl_xor(st, o, 64);
-            if (osc > sc || (osc == sc && osc > 0 && okey > key)) { sc = osc; key = okey; st = ost; }
+            for (int k = 0; k < FA_K; ++k) {
+                const int j = 64 * k + lane;
+                H[k] = S[k] = dH[k] = dS[k] = 0;
+                ai[k] = 4;
+                ij[k] = ((r0 - j) << 8) | j;                           // (i << 8) | j of step 0; + 256 per step
+            }
+            int win = fa_window(read, n, r0, lane, rev), winn = fa_window(read, n, r0 + 64, lane, rev);
+            const int s_cap = (ei - r0) + ej;                          // the step on which lane ej works on row ei
+            for (int s = 0; s <= s_cap; ++s) {
+                if ((s & 63) == 0 && s > 0) { win = winn; winn = fa_window(read, n, r0 + s + 64, lane, rev); }
+                const int a_hi = fa_shr1_from(ai[1], ai[0]);
+                ai[0] = fa_shr1(ai[0], win);
+                ai[1] = a_hi;
+                win = fa_rol1(win);
+                int nH[FA_K], nS[FA_K];
+#pragma unroll
+                for (int k = FA_K - 1; k >= 0; --k) {
+                    // left neighbour's values of the previous step = (i, j-1); what was shifted in one step earlier = (i-1, j-1)
+                    const int lH = k == 0 ? fa_shr1(H[0], 0) : fa_shr1_from(H[k], H[k - 1]);
+                    const int lS = k == 0 ? fa_shr1(S[0], 0) : fa_shr1_from(S[k], S[k - 1]);
+                    const int m = ai[k] == b[k] ? 1 : -1;
+                    const int d = dH[k] + m, u = H[k] - 1, l = lH - 1;
+                    const int h = max(max(d, u), max(l, 0));
+                    // the start the walk-back reaches: horizontal first, then diagonal (a diagonal step out of a cell whose
+                    // score is not positive begins the alignment here), then vertical.  (Starts of cells with score 0 are never
+                    // read: whoever takes one has seen a positive score there.)
+                    const int st_d = dH[k] > 0 ? dS[k] : ij[k];
+                    const int st_du = d == h ? st_d : S[k];
+                    const int st = l == h ? lS : st_du;
+                    dH[k] = lH;
+                    dS[k] = lS;
+                    nH[k] = h;
+                    nS[k] = st;
+                    ij[k] += 256;
+                }
+#pragma unroll
+                for (int k = 0; k < FA_K; ++k) { H[k] = nH[k]; S[k] = nS[k]; }
+            }
+            const int st = __builtin_amdgcn_readlane(ej >= 64 ? S[1] : S[0], ej & 63);
+            begin = max(st >> 8, st & 0xff);
         }
-        const int ei = sc > 0 ? (key >> 8) - 1 : -1;
-        if (lane == 0) {
-            a.out_score[p] = sc;
-            a.out_begin[p] = sc > 0 ? max(st >> 8, st & 0xff) : -1;
-            a.out_end[p] = ei;
+        // (three lanes, one result each -- not `if (lane == 0)`: with the same condition at both ends of the loop body the
+        // compiler threads lane 0 from this store straight into the next iteration's atomic and builds a lane-divergent loop
+        // around the body, in which the other lanes take the same pair again and again)
+        if (lane < 3) {
+            int32_t *dst = lane == 0 ? a.out_score : (lane == 1 ? a.out_begin : a.out_end);
+            dst[p] = lane == 0 ? sc : (lane == 1 ? begin : ei);
         }
     }
 }

@@ -985,19 +985,25 @@ def flank_align_record(_lib, inp, args):
     lens = np.fromiter(map(len, reads), dtype=np.int64, count=n)
     cells = float(lens.sum()) * 4 * 100
     bytes_alg = float(lens.sum()) * 4
-    chunk_steps = float((lens + 99).sum()) * 4 * 2
-    valu_per_chunk_step = 28
-    peak = 64.0 / (valu_per_chunk_step * 2) * SIMDS * CLOCK_GHZ * 1e9
-    rec = {"alignments": int(len(pr)), "reads": n, "value": len(pr) / (ms * 1e-3), "unit": "alignments/s", "dtype": "i32",
+    # the sweep of a pair takes n + lf - 1 steps of 128 cells (both 64-column chunks of a lane in the halves of one register);
+    # instruction census of a step (ISA of flank_align_kernel, pass 1): 21 wave64 vector instructions -- 5 DPP moves, 8 packed
+    # 16-bit operations, 2 byte permutes and a three-way maximum (all 64-bit encodings: ~4.5 cycles each on this part,
+    # profiles/r01_valu_ubench.txt) and 5 plain 32-bit ones (~2.6)
+    steps = float((lens + 99).sum()) * 4
+    valu_per_step = 21
+    peak = 128.0 / (valu_per_step * 2) * SIMDS * CLOCK_GHZ * 1e9
+    rec = {"alignments": int(len(pr)), "reads": n, "value": len(pr) / (ms * 1e-3), "unit": "alignments/s", "dtype": "i16 (packed pairs)",
            "kernel_ms": ms, "call_ms_incl_pcie_and_host": wall * 1e3, "cells_per_s": cells / (ms * 1e-3),
            "spanning_found": int(((score[0::2] >= 70) & (score[1::2] >= 70) & (begin[1::2] >= begin[0::2])).sum()),
            "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                        "note": "tier rule (HBM: each alignment streams its read once) only; the binding roof is int32 VALU issue",
-                        "bound_actual": {"bound": "valu_int32", "unit": "DP cells/s", "achieved": cells / (ms * 1e-3),
-                                         "valu_per_chunk_step": valu_per_chunk_step, "peak": peak,
+                        "note": "tier rule (HBM: each alignment streams its read once) only; the binding roof is VALU issue",
+                        "bound_actual": {"bound": "valu_int", "unit": "DP cells/s", "achieved": cells / (ms * 1e-3),
+                                         "valu_per_step_of_128_cells": valu_per_step, "peak": peak,
+                                         "peak_note": "every instruction at the nominal 2 cycles per wave64 instruction",
                                          "frac": cells / (ms * 1e-3) / peak,
-                                         "cycles_per_chunk_step_measured": ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS / chunk_steps}}}
+                                         "cycles_per_step_measured": ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS / steps,
+                                         "cycles_per_step_at_measured_issue_rates": 16 * 4.5 + 5 * 2.6}}}
     if not args.no_cpu:
         n_cpu = 24
         t0 = time.perf_counter()

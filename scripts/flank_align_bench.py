@@ -39,7 +39,7 @@ wall = time.perf_counter() - t0
 cells = float(sum(len(strands[r]) for r in pr)) * 100
 bytes_alg = float(sum(len(strands[r]) for r in pr))
 # steps of the sweep: read length + flank length - 1 anti-diagonals, two 64-column chunks each (a 100-base flank fills 100 of 128)
-chunk_steps = float(sum(len(strands[r]) + 99 for r in pr)) * 2
+steps = float(sum(len(strands[r]) + 99 for r in pr))           # steps of 128 cells (two 64-column chunks packed in one register)
 n_cpu = 24
 t0 = time.perf_counter()
 for p in range(n_cpu):
@@ -54,22 +54,16 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                   "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                "frac": bytes_alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                                "note": "tier rule (HBM) only: the binding roof is int32 VALU issue, see bound_actual",
-                               "bound_actual": {"bound": "valu_int32", "unit": "DP cells/s",
+                               "bound_actual": {"bound": "valu_int", "unit": "DP cells/s",
                                                 "achieved": cells / (ms * 1e-3),
-                                                # 28 wave64 VALU instructions per 64-cell chunk-step (round 2: 37; DESIGN.md
-                                                # section 10) at the nominal 2 cycles each on 1024 SIMDs at 2.4 GHz
-                                                "valu_per_chunk_step": 28,
-                                                "peak": 64.0 / (28 * 2) * 1024 * 2.4e9,
-                                                "frac": cells / (ms * 1e-3) / (64.0 / (28 * 2) * 1024 * 2.4e9),
-                                                "frac_at_round2_instruction_count_37": cells / (ms * 1e-3) / (64.0 / (37 * 2) * 1024 * 2.4e9),
-                                                # what a chunk-step takes, per SIMD, next to what its 28 instructions price at with the
-                                                # issue rates scripts/ubench measured on this device at 8 wavefronts per SIMD
-                                                # (profiles/r01_valu_ubench.txt, r02_f64_issue_ubench.txt: 2.6 cycles for a
-                                                # two-operand 32-bit instruction, 4.5 for DPP moves, v_cndmask with a scalar mask
-                                                # and three-operand forms: 10 x 2.6 + 18 x 4.5); SQ_INSTS_VALU of the launch: 27.3
-                                                # per chunk-step, 4.3 cycles each
-                                                "cycles_per_chunk_step_measured": ms * 1e-3 * 2.4e9 * 1024 / chunk_steps,
-                                                "cycles_per_chunk_step_at_measured_issue_rates": 10 * 2.6 + 18 * 4.5}},
+                                                # 21 wave64 VALU instructions per step of 128 cells (round 3: 28 per 64 cells), at the
+                                                # nominal 2 cycles each on 1024 SIMDs at 2.4 GHz; 16 of them are DPP / VOP3P / VOP3
+                                                # encodings, which this part issues at ~4.5 cycles (profiles/r01_valu_ubench.txt)
+                                                "valu_per_step_of_128_cells": 21,
+                                                "peak": 128.0 / (21 * 2) * 1024 * 2.4e9,
+                                                "frac": cells / (ms * 1e-3) / (128.0 / (21 * 2) * 1024 * 2.4e9),
+                                                "cycles_per_step_measured": ms * 1e-3 * 2.4e9 * 1024 / steps,
+                                                "cycles_per_step_at_measured_issue_rates": 16 * 4.5 + 5 * 2.6}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
                                              "unpinned); results equal to the GPU's" % n_cpu}}))
