@@ -182,6 +182,7 @@ static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const Ba
     g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
+    g.rows_depth = cl.rows_depth;
     const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
     if (lds > 48 * 1024 &&

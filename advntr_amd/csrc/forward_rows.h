@@ -14,10 +14,9 @@
 // value x transition probability over its in-edges, and ONE logarithm is taken at the end (cycle counters in the kernel: the
 // log-domain version was 19 % of a wavefront's time).  Tail values of earlier tail states are kept in the same scale.
 __device__ __forceinline__ double rows_tail_forward_linear(const ColProgram *__restrict__ cp, double *__restrict__ row,
-                                                           const int NC, const int rows, const int lane)
+                                                           double *__restrict__ tailv, const int rows, const int lane)
 {
     const ColFinishTables F = col_finish_tables(cp);
-    double *tailv = row + 3 * NC;
     const int n_tail = F.n_tail, end_tail = F.end_tail;
     double result = 0.0;
     int e1 = F.tptr[0];
@@ -48,10 +47,18 @@ __device__ __forceinline__ double rows_tail_forward_linear(const ColProgram *__r
 // {b_c(0), entry term of M_c} from a table padded like the info table (one running address, no clamping).  The
 // multiply-adds are explicit fma()s: the build contracts nothing by itself (-ffp-contract=off, for the Viterbi kernels and
 // the host builder), and 11 fused operations per cell instead of 17 separate ones is a third of this kernel's arithmetic.
+// Back-to-back sweeps as in rows_sweep (viterbi_rows.h): a lane group takes up to ROWS_DEPTH reads one behind the
+// other along the step axis (`queue` = the lane's rows of the reads after the first, rows_pack_read; `depth` = reads per
+// group), so the W - 1 steps of filling and draining the lanes are paid once per sweep instead of once per read.  Nothing is
+// reset between reads: column 0 of a column program takes nothing from a previous column (probability 0 here), the fan-in
+// accumulators are 0 after the last sink; the info and row-0 tables hold copies of columns 0 .. 32 behind the last column, the
+// table pointers step back by NC records once every lane of the group is on its next read.  Row n of read k lands at
+// rown[cap_base + 3 (W + k NC + c)].  The plain stretches between two reads run the step without any of this.
 template <int R, int G>
 __device__ __forceinline__ void rows_sweep_fwd(const LdsTables &L, const int NC, const int s_end,
                                                const uint8_t *__restrict__ seq, const int n, const int lp, const int lane,
-                                               double *__restrict__ rown, const unsigned cap_base)
+                                               double *__restrict__ rown, const unsigned cap_base,
+                                               unsigned long long queue = 0ull, const int depth = 1)
 {
     constexpr int W = 64 / G;
     double I[R], M[R], B[R], er[R];
@@ -62,7 +69,7 @@ __device__ __forceinline__ void rows_sweep_fwd(const LdsTables &L, const int NC,
         const int t = R * lp + k + 1;
         esym[k] = L.epair_base + (unsigned)((t <= n) ? (int)seq[t - 1] : 4) * L.epair_sym_stride;     // rows past the read: emission 0
     }
-    const int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : -1;
+    int kcap = (n >= 1 && (n - 1) / R == lp) ? (n - 1) - lp * R : 7;          // slot of the read's last row (7: not in this lane)
     const bool first_lane = lp == 0;
     const bool fix = G == 2 && lane == 32;
     double nI = 0.0, nM = 0.0, nB = 0.0, qI = 0.0, qM = 0.0;      // group-first lanes keep 0 for the whole sweep
@@ -71,7 +78,8 @@ __device__ __forceinline__ void rows_sweep_fwd(const LdsTables &L, const int NC,
     uint2 meta = lds_uint2(pa + 8u);
     const unsigned cap_lane = cap_base + (unsigned)(W - lp) * 3u;
     int sstep = 0;
-    auto step = [&](double &nI, double &nM, double &qI, double &qM) {
+    auto step = [&](auto WIN, double &nI, double &nM, double &qI, double &qM, const int uw, const bool more) {
+        constexpr int win_kind = decltype(WIN)::value;
         const adv_f64x2 f0 = *(LdsDouble2 *)(size_t)pf;          // {row-0 value of b_c, entry term of M_c} of the lane's column
         pa += 16u; pf += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
@@ -123,16 +131,47 @@ __device__ __forceinline__ void rows_sweep_fwd(const LdsTables &L, const int NC,
 #pragma unroll
             for (int k = 0; k < R; ++k) er[k] = fma(B[k], erw, er[k]);
         }
+        if (win_kind != 0) {
+            // lane uw of a group is on its read's last column on this step: it takes its rows of the next read out of the queue
+            const bool mine = lp == uw;
+            if (more) {
+                if (mine) {
+                    const unsigned w = (unsigned)queue;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) esym[k] = L.epair_base + __umul24((w >> (3 * k)) & 7u, L.epair_sym_stride);
+                    kcap = (int)((w >> (3 * R)) & 7u);
+                    queue >>= 3 * R + 3;
+                }
+                if (uw == W) { pa -= 16u * (unsigned)NC; pf -= 16u * (unsigned)NC; }     // every lane of the group is on its next read
+            } else {
+                kcap = mine ? 7 : kcap;          // behind the last read nothing is captured: the lanes walk on over copied columns
+            }
+        }
         ++sstep;
         meta = meta_next;
     };
+    using Plain = std::integral_constant<int, 0>;
+    using Window = std::integral_constant<int, 1>;
     int s = 0;
-    for (; s < s_end; s += 2) { step(nI, nM, qI, qM); step(qI, qM, nI, nM); }
-    if (s == s_end) step(nI, nM, qI, qM);
+    for (int k = 0; k < depth; ++k) {
+        const int first_turn = (k + 1) * NC - 1;                  // the step on which lane 0 is on its last column
+        for (const int s1 = s + ((first_turn - s) & ~1); s < s1; s += 2) {
+            step(Plain{}, nI, nM, qI, qM, 0, false);
+            step(Plain{}, qI, qM, nI, nM, 0, false);
+        }
+        const bool more = k + 1 < depth;
+        for (const int s1 = more ? first_turn + W + 1 : s_end + 1; s < s1; s += 2) {     // (a step too many does nothing)
+            step(Window{}, nI, nM, qI, qM, s - first_turn, more);
+            step(Window{}, qI, qM, nI, nM, s + 1 - first_turn, more);
+        }
+    }
 }
 
+#ifndef FWD_WAVES_PER_SIMD
+#define FWD_WAVES_PER_SIMD ROWS_WAVES_PER_SIMD
+#endif
 template <int R, int G>
-__global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(COL_WAVES * 64, FWD_WAVES_PER_SIMD)
 forward_rows_kernel(ColArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -160,7 +199,7 @@ forward_rows_kernel(ColArgs g)
             cur_model = tile.model;
             M = g.a.models[cur_model];
             cp = M.cols;
-            padded = stage_model<1, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
+            padded = stage_model<1, true, true>(cp, tables, g.lds_tables, g.lds_level, L, tid);
             // to the linear domain, in place (forward_columns.h): transition classes -> probabilities, emission pairs ->
             // probability times the per-row scale 16 (the fifth symbol row, -inf, becomes 0), row-0 / entry terms into a table of
             // their own behind the staged ones, padded like the info table (64 records in front, clamped at either end)
@@ -172,39 +211,71 @@ forward_rows_kernel(ColArgs g)
             const double *fw = (const double *)((const uint8_t *)cp + cp->off_fwd);
             const int ncol = cp->n_cols;
             for (int i = tid; i < 2 * (ncol + 128); i += COL_WAVES * 64) {
-                const int c = min(max((i >> 1) - 64, 0), ncol - 1);
+                int c = (i >> 1) - 64;
+                // behind the last column: copies of columns 0 .. 32, like the padded info table (back-to-back sweeps)
+                if (c >= ncol && c - ncol <= 32 && c - ncol < ncol) c -= ncol;
+                c = min(max(c, 0), ncol - 1);
                 lin[i] = exp(fw[2 * c + (i & 1)]);
             }
             L.fwd_lin = lds_addr(lin);
             __syncthreads();
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
-        const int64_t row_doubles = 3 * (int64_t)(NC + 2 * W) + COL_MAX_TAIL;
-        for (int j = wave * G; j < tile.count; j += COL_WAVES * G) {
-            const bool have = j + grp < tile.count;
-            const int r = have ? g.a.order[tile.first + j + grp] : 0;
-            const uint8_t *seq = g.a.bases + g.a.read_off[r];
-            const int n = have ? (int)(g.a.read_off[r + 1] - g.a.read_off[r]) : 0;
-            int nmax = n;
+        // per lane group: the row-n values of its reads one behind the other (padded by W columns either side); the tail values
+        // of the read being finished sit behind the groups -- the layout of viterbi_rows_kernel, whose scratch this is
+        const int dmax = NC >= ROWS_STREAM_MIN_COLS ? g.rows_depth : 1;
+        const int64_t grp_doubles = 3 * ((int64_t)dmax * NC + 2 * W);
+        double *tailv = rown + G * grp_doubles;
+        for (int j0 = 0; j0 < tile.count; j0 += COL_WAVES * G * dmax) {
+            const int jw = j0 + wave * G;
+            if (jw >= tile.count) break;
+            const int depth = min(dmax, (tile.count - jw + COL_WAVES * G - 1) / (COL_WAVES * G));
+            // the reads of this sweep: lane k * G + q fetches what read k of lane group q is
+            int fr = -1, fn = 0;
+            long long fo = 0;
+            {
+                const int k = lane / G, q = lane - k * G;
+                const int idx = jw + k * COL_WAVES * G + q;
+                if (k < depth && idx < tile.count) {
+                    fr = g.a.order[tile.first + idx];
+                    fo = g.a.read_off[fr];
+                    fn = (int)(g.a.read_off[fr + 1] - fo);
+                }
+            }
+            int nbad = (!padded || fn > R * (W - (G == 2 ? 1 : 0))) ? 1 : 0;
 #pragma unroll
-            for (int o = 32; o >= W; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-            nmax = __builtin_amdgcn_readfirstlane(nmax);
-            if (!padded || nmax > R * (W - (G == 2 ? 1 : 0))) {                       // the host never routes such a tile here
-                if (have && lp == 0) g.a.out_logp[r] = __longlong_as_double(0x7ff8000000000000ll);
+            for (int o = 32; o >= 1; o >>= 1) nbad |= __shfl_xor(nbad, o, 64);
+            if (__builtin_amdgcn_readfirstlane(nbad)) {                    // the host never routes such a tile here
+                if (fr >= 0) g.a.out_logp[fr] = __longlong_as_double(0x7ff8000000000000ll);
                 continue;
             }
-            rows_sweep_fwd<R, G>(L, NC, NC - 1 + (nmax - 1) / R, seq, n, lp, lane, rown, (unsigned)(grp * row_doubles));
+            unsigned long long queue = 0ull;
+            for (int k = depth - 1; k >= 1; --k) {
+                const int src = k * G + grp;
+                const int nk = __shfl(fn, src, 64);
+                const long long ok = ((long long)__shfl((int)(fo >> 32), src, 64) << 32) | (unsigned)__shfl((int)fo, src, 64);
+                queue = (queue << (3 * R + 3)) | rows_pack_read<R>(g.a.bases + ok, nk, lp);
+            }
+            const int n = __shfl(fn, grp, 64);
+            const uint8_t *seq = g.a.bases + (((long long)__shfl((int)(fo >> 32), grp, 64) << 32) | (unsigned)__shfl((int)fo, grp, 64));
+            int nlast = 0;
+#pragma unroll
+            for (int q = 0; q < G; ++q) nlast = max(nlast, __builtin_amdgcn_readlane(fn, (depth - 1) * G + q));
+            const int s_end = depth * NC - 1 + (max(nlast, 1) - 1) / R;
+            rows_sweep_fwd<R, G>(L, NC, s_end, seq, n, lp, lane, rown, (unsigned)(grp * grp_doubles), queue, depth);
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-            for (int q = 0; q < G; ++q) {
-                if (j + q >= tile.count) break;
-                const int rq = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + j + q]);
-                const int nq = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[rq + 1] - g.a.read_off[rq]));
-                double *final_row = rown + q * row_doubles + 3 * W;
-                const double logp = rows_tail_forward_linear(cp, final_row, NC, nq, lane);
-                if (lane == 0) g.a.out_logp[rq] = logp;
-                __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < depth; ++k) {
+#pragma unroll 1
+                for (int q = 0; q < G; ++q) {
+                    if (jw + k * COL_WAVES * G + q >= tile.count) break;
+                    const int src = k * G + q;
+                    const int rq = __builtin_amdgcn_readlane(fr, src), nq = __builtin_amdgcn_readlane(fn, src);
+                    const double logp = rows_tail_forward_linear(cp, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv, nq, lane);
+                    if (lane == 0) g.a.out_logp[rq] = logp;
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     }
