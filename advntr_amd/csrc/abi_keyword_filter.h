@@ -241,10 +241,12 @@ static int kwfilter_scan_spans(advntr_kwfilter *F, const uint8_t *bytes, int64_t
             kernel = ascii ? (wide ? (const void *)keyword_filter_short_kernel<true, true> : (const void *)keyword_filter_short_kernel<true, false>)
                            : (wide ? (const void *)keyword_filter_short_kernel<false, true> : (const void *)keyword_filter_short_kernel<false, false>);
         }
-        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KWF_BITSET_BITS / 8)));
+        // (the short-keyword kernel keeps a queue per wavefront behind its filter)
+        const size_t lds = F->dev.short_ok ? (size_t)KWF_SHORT_LDS_BYTES : (size_t)(KWF_BITSET_BITS / 8);
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipEventRecord(e0, nullptr));
         void *kargs[] = {(void *)&a};
-        HIP_TRY(hipLaunchKernel(kernel, dim3(grid), dim3(KWF_BLOCK), kargs, KWF_BITSET_BITS / 8, nullptr));
+        HIP_TRY(hipLaunchKernel(kernel, dim3(grid), dim3(KWF_BLOCK), kargs, lds, nullptr));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));

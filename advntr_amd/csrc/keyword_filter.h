@@ -356,7 +356,20 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
 //     4-byte gather and a mask compare instead of a 16-byte bucket and eight fingerprint compares; 0.2 % of all windows go on
 //     to the exact table.
 // Everything behind that (exact table, tallies, wave-aggregated output) is the general kernel's.
+// Round 4: the levels behind the first are WAVE-COOPERATIVE.  A lane's survivors of the LDS filter used to be looked up by
+// that lane, four at a time, until the lane with the most survivors was through (3.4 of 16 windows survive on average, the
+// busiest of 64 lanes has 8: the wavefront executed the second level for 512 slots to serve 220), and a read cut from a locus
+// -- two dozen true hits -- kept its wavefront's other 63 lanes waiting while it walked the exact table: the levels behind
+// the first were 60 % of the kernel's vector instructions (SQ_INSTS_VALU 68 per position-wave, 27 of them first level and
+// decoding).  Now the survivors of a 16-base word of all 64 reads go into a queue of the wavefront in LDS (an exclusive prefix
+// sum of the lanes' survivor counts by ballots and mbcnt: no LDS, no DPP chain), and the wavefront drains it 64 entries at a
+// time: one L2-filter gather per lane and round, the exact table for the few that pass, a hit written out as a (read, VNTR, 1)
+// record under one atomic per wavefront and round -- the host sums the records of a (read, VNTR) pair as it always did.
+// All loops are wave-uniform (bounds from the longest read of the 64), so that the cooperative steps run converged.
 // WIDE: keywords of 15 or 16 bases -- the window needs no mask before it is hashed.
+#define KWF_QCAP 384                         // queue entries per wavefront (a word of 64 reads has 220 survivors on average, 1 024
+                                             // at most: a fuller queue is drained in passes)
+#define KWF_SHORT_LDS_BYTES (KWF_BITSET_BITS / 8 + (KWF_BLOCK / 64) * KWF_QCAP * 5)
 template <bool ASCII, bool WIDE>
 __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs a)
 {
@@ -367,18 +380,28 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
         for (int i = threadIdx.x; i < (int)(KWF_BLOOM_WORDS / 4); i += KWF_BLOCK) dst[i] = src[i];
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *qwin = bits + KWF_BLOOM_WORDS + wave * KWF_QCAP;
+    uint8_t *qsrc = (uint8_t *)(bits + KWF_BLOOM_WORDS + (KWF_BLOCK / 64) * KWF_QCAP) + wave * KWF_QCAP;
     const int L0 = a.f.length[0];
     const uint32_t mask0 = L0 >= 16 ? 0xffffffffu : ((1u << (2 * L0)) - 1u);
     const uint32_t l2_mask = a.f.short_l2_mask;
     const int l2_bits = 32 - __builtin_clz(l2_mask);                 // bits of the word index (l2_mask = words - 1 >= 32767)
-    for (int r = blockIdx.x * KWF_BLOCK + threadIdx.x; r < a.n_reads; r += gridDim.x * KWF_BLOCK) {
-        const uint8_t *seq = a.bases + a.span_start[r];
-        const int n = (int)(a.span_end[r] - a.span_start[r]);
+    for (int r0 = blockIdx.x * KWF_BLOCK + wave * 64; r0 < a.n_reads; r0 += gridDim.x * KWF_BLOCK) {
+        const int r = r0 + lane;
+        const bool have = r < a.n_reads;
+        const uint8_t *seq = a.bases + (have ? a.span_start[r] : 0);
+        const int n = have ? (int)(a.span_end[r] - a.span_start[r]) : 0;
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
         int svid[KWF_SLOTS], scnt[KWF_SLOTS];
 #pragma unroll
         for (int s = 0; s < KWF_SLOTS; ++s) { svid[s] = -1; scnt[s] = 0; }
         uint32_t prevP = 0, prevG = 0;           // the 16 bases before the current word, and which of them were good
-        for (int pb = 0; pb < n; pb += 64) {     // one 64-byte sector of the read per outer step
+        for (int pb = 0; pb < nmax; pb += 64) {  // one 64-byte sector of every read per outer step
             uint32_t d[16];
             if (pb + 64 <= n) {
                 __builtin_memcpy(d, seq + pb, 64);
@@ -390,10 +413,10 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
                     else for (int q = 0; pb + 4 * w + q < n; ++q) d[w] |= (uint32_t)seq[pb + 4 * w + q] << (8 * q);
                 }
             }
-            const int left = n - pb;                                  // bases of the read in this sector and beyond
+            const int left = n - pb;                                  // bases of this lane's read in this sector and beyond (<= 0: none)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (16 * j >= left) break;
+                if (16 * j >= nmax - pb) break;                       // (wave-uniform)
                 // 16 bases -> P (two bits per base, first base in the top bits) and G (one bit per base: a base A, C, G, T)
                 uint32_t P = 0, G = 0;
 #pragma unroll
@@ -419,7 +442,8 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
                     G = (G << 4) | g4;
                 }
                 const int here = left - 16 * j;                       // bases of the read from this word on
-                if (here < 16) G &= 0xffffu << (16 - here);           // past the read's end: no base
+                if (here <= 0) G = 0;                                 // past the read's end: no base
+                else if (here < 16) G &= 0xffffu << (16 - here);
                 // windows: bit b of `ok` <-> the window that ends at base 15 - b exists (L0 good bases, in the read)
                 const uint32_t c0 = (prevG << 16) | (G & 0xffffu);
                 const uint32_t c1 = c0 & (c0 >> 1), c2 = c1 & (c1 >> 2), c3 = c2 & (c2 >> 4);
@@ -431,7 +455,7 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
                 if (L0 & 2) { ok &= c1 >> done; done += 2; }
                 if (L0 & 1) ok &= c0 >> done;
                 ok &= 0xffffu;
-                if (ok != 0u) {
+                if (__ballot(ok != 0u) != 0ull) {
                     // first level, the 16 windows of the word, no branch: bit e of `live` <-> the window that ends at base e
                     // passed the LDS filter
                     uint32_t live = 0;
@@ -445,75 +469,102 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs
                         live |= (uint32_t)((bits[y & (KWF_BLOOM_WORDS - 1)] & m) == m) << e;
                     }
                     live &= __builtin_bitreverse32(ok) >> 16;
-                    // second level: up to four survivors of a lane per round, their words of the L2 filter loaded together
-                    uint32_t cand = 0;
-                    while (live != 0u) {
-                        int ee[4];
-                        uint32_t zz[4], w2[4];
+                    // where this lane's survivors go in the wavefront's queue: exclusive prefix sum of the lanes' counts, bit by
+                    // bit of the count (a count is at most 16: five ballots, each lane counts the set bits below it)
+                    const int cnt = __popc(live);
+                    int before = 0, total = 0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            ee[i] = live ? __builtin_ctz(live) : -1;
-                            live &= live - 1u;
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (ee[i] >= 0) {
-                                zz[i] = kwf_h24b(kwf_h24(__builtin_amdgcn_alignbit(prevP, P, 2 * (15 - ee[i])) & mask0));
-                                w2[i] = a.f.short_l2[zz[i] & l2_mask];
-                            }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (ee[i] >= 0) {
-                                const uint32_t m2 = kwf_bloom_mask2(zz[i], l2_bits);
-                                if ((w2[i] & m2) == m2) cand |= 1u << ee[i];
-                            }
+                    for (int b = 0; b < 5; ++b) {
+                        const unsigned long long m = __ballot((cnt >> b) & 1);
+                        before += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
+                        total += __popcll(m) << b;
                     }
-                    // the exact table for what is left (0.2 % of all windows, and the true hits -- two dozen per read that
-                    // comes from a locus, while the wavefront's other lanes wait): two entries of a lane in flight per round,
-                    // one 8-byte entry per look-up, the VNTR in the entry itself when the keyword has one owner
-                    while (cand != 0u) {
-                        int ee[2];
-                        uint32_t kk[2], sl[2];
-                        uint2 ent[2];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            ee[i] = cand ? __builtin_ctz(cand) : -1;
-                            cand &= cand - 1u;
+                    for (int q0 = 0; q0 < total; q0 += KWF_QCAP) {            // (one pass unless more than KWF_QCAP windows survived)
+                        {
+                            uint32_t lv = live;
+                            int pos = before - q0;
+                            while (lv != 0u) {
+                                const int e = __builtin_ctz(lv);
+                                lv &= lv - 1u;
+                                if (pos >= 0 && pos < KWF_QCAP) {
+                                    qwin[pos] = __builtin_amdgcn_alignbit(prevP, P, 2 * (15 - e)) & mask0;
+                                    qsrc[pos] = (uint8_t)lane;
+                                }
+                                ++pos;
+                            }
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int queued = min(KWF_QCAP, total - q0);
+                        // four rounds of 64 entries at a time: their L2-filter gathers are in flight together (a round is a chain of
+                        // dependent memory accesses -- queue, gather, test --, and a wavefront has three others beside it to hide it)
+                        for (int i0 = 0; i0 < queued; i0 += 4 * 64) {
+                            uint32_t kk[4], zz[4], w2[4];
+                            int src[4];
+                            bool act[4];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (ee[i] >= 0) {
-                                kk[i] = __builtin_amdgcn_alignbit(prevP, P, 2 * (15 - ee[i])) & mask0;
-                                sl[i] = kwf_short_slot(kwf_h24b(kwf_h24(kk[i]))) & a.f.short_table_mask;
-                                ent[i] = a.f.short_table[sl[i]];
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = i0 + 64 * u + lane;
+                                act[u] = i < queued;
+                                kk[u] = act[u] ? qwin[i] : 0u;
+                                src[u] = act[u] ? (int)qsrc[i] : lane;
+                                zz[u] = kwf_h24b(kwf_h24(kk[u]));
                             }
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            if (ee[i] >= 0) {
-                                uint2 en = ent[i];
-                                uint32_t at = sl[i];
-                                for (uint32_t probes = 0; probes <= a.f.short_table_mask && en.y != KWF_SHORT_EMPTY; ++probes) {
-                                    if (en.x == kk[i]) {
-                                        if (en.y & KWF_SHORT_ONE) kwf_tally_one(a, (int)(en.y & 0xffffffu), r, svid, scnt);
-                                        else kwf_tally(a, en.y, r, svid, scnt);
-                                        break;
+                            for (int u = 0; u < 4; ++u) w2[u] = act[u] ? a.f.short_l2[zz[u] & l2_mask] : 0u;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (i0 + 64 * u >= queued) break;                              // (wave-uniform)
+                                const uint32_t m2 = kwf_bloom_mask2(zz[u], l2_bits);
+                                const bool cand = act[u] && (w2[u] & m2) == m2;
+                                if (__ballot(cand) == 0ull) continue;
+                                // the exact table for what is left (0.2 % of all windows, and the true hits): one 8-byte entry per
+                                // look-up, the VNTR in the entry itself when the keyword has one owner
+                                uint32_t val = KWF_SHORT_EMPTY;
+                                if (cand) {
+                                    uint32_t at = kwf_short_slot(zz[u]) & a.f.short_table_mask;
+                                    uint2 en = a.f.short_table[at];
+                                    for (uint32_t probes = 0; probes <= a.f.short_table_mask && en.y != KWF_SHORT_EMPTY; ++probes) {
+                                        if (en.x == kk[u]) { val = en.y; break; }
+                                        at = (at + 1u) & a.f.short_table_mask;
+                                        en = a.f.short_table[at];
                                     }
-                                    at = (at + 1u) & a.f.short_table_mask;
-                                    en = a.f.short_table[at];
+                                }
+                                // a hit goes to the lane that owns the read (its four (VNTR, count) slots, flushed once per read):
+                                // the wavefront walks the lanes that found one -- one or two a round, two dozen over a read
+                                // that comes from a locus
+                                unsigned long long mh = __ballot(val != KWF_SHORT_EMPTY);
+                                while (mh != 0ull) {
+                                    const int lh = __builtin_amdgcn_readfirstlane(__ffsll((long long)mh) - 1);
+                                    mh &= mh - 1ull;
+                                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)val, lh);
+                                    const int owner = __builtin_amdgcn_readlane(src[u], lh);
+                                    if (v & KWF_SHORT_ONE) {
+                                        if (lane == owner) kwf_tally_one(a, (int)(v & 0xffffffu), r, svid, scnt);
+                                    } else {                                            // a keyword string that several VNTRs share
+                                        const int first = (int)(v & 0xffffffu), cntv = (int)(v >> 24);
+                                        for (int q = 0; q < cntv; ++q) {
+                                            const int vid = a.f.ids[first + q];
+                                            if (lane == owner) kwf_tally_one(a, vid, r, svid, scnt);
+                                        }
+                                    }
                                 }
                             }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
                 prevP = P;
                 prevG = G & 0xffffu;
             }
         }
+        // wave-aggregated output: one atomic per wavefront and slot (a single device-wide counter saturates at ~88 atomics/us)
 #pragma unroll
         for (int s = 0; s < KWF_SLOTS; ++s) {
             const bool need = svid[s] >= 0;
             const unsigned long long m = __ballot(need);
             if (m == 0ull) continue;
-            const int lane = threadIdx.x & 63;
             const int leader = __ffsll((long long)m) - 1;
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(a.n_out, (unsigned long long)__popcll(m));

@@ -690,28 +690,7 @@ def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, f
     spanning = [(trimmed sequence = read[left_begin : right_begin + flank size], read index, is_reverse_strand)],
     length_distribution = [right_begin - (left_begin + flank size)].  PARITY UNPINNED with respect to biopython
     (absent from the image): scores are plain Smith-Waterman; `begin` follows pairwise2's documented conventions."""
-    from . import settings
-    left = left_flanking_region[-flanking_region_size:]
-    right = right_flanking_region[:flanking_region_size]
-    fwd = [str(s).upper() for s in reads]
-    if not fwd:
-        return [], []
-    n = len(fwd)
-    # strand k of the reference's loop = read k // 2, reverse strand for odd k; the reverse complements are made on the device
-    # (pair_read = n + read), in Python only for the reads that turn out to span
-    strand_read = np.arange(2 * n, dtype=np.int32) // 2 + (np.arange(2 * n, dtype=np.int32) & 1) * n
-    pair_read = np.repeat(strand_read, 2)
-    pair_flank = np.tile(np.array([0, 1], np.int32), 2 * n)
-    score, begin, _, _ = _lib.flank_align(fwd, [left, right], pair_read, pair_flank)
-    ok = ((score[0::2] > 0) & (score[0::2] >= len(left) * (1 - settings.MAX_ERROR_RATE)) &
-          (score[1::2] > 0) & (score[1::2] >= len(right) * (1 - settings.MAX_ERROR_RATE)) & (begin[1::2] >= begin[0::2]))
-    spanning, lengths = [], []
-    for k in np.flatnonzero(ok).tolist():
-        lb, rb = int(begin[2 * k]), int(begin[2 * k + 1])
-        seq = fwd[k // 2] if not (k & 1) else fwd[k // 2].translate(_COMP_STR)[::-1]
-        spanning.append((seq[lb:rb + flanking_region_size], k // 2, bool(k & 1)))
-        lengths.append(rb - (lb + flanking_region_size))
-    return spanning, lengths
+    return extract_spanning_reads_multi([(left_flanking_region, right_flanking_region)], [list(reads)], flanking_region_size)[0]
 
 
 _COMP_STR = str.maketrans("ACGTN", "TGCAN")
@@ -720,35 +699,41 @@ _COMP_STR = str.maketrans("ACGTN", "TGCAN")
 def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=100):
     """extract_spanning_reads for many loci in ONE advntr_flank_align call: flank_pairs[i] = (left_flanking_region,
     right_flanking_region) of locus i, read_lists[i] = its candidate long reads.  Returns one (spanning, length_distribution)
-    pair per locus, each as extract_spanning_reads returns it (reads in input order, forward strand before reverse)."""
+    pair per locus, each as extract_spanning_reads returns it (reads in input order, forward strand before reverse).  The
+    reads go to the device as they are (the encoder folds case); only the trimmed piece of a spanning read -- a few hundred
+    bases of its 5-15 kb -- is upper-cased and, for the reverse strand, reverse-complemented on the host."""
     from . import settings
     n_loci = len(flank_pairs)
-    flanks, fwd, read_locus = [], [], []
-    for i, ((lf, rf), reads) in enumerate(zip(flank_pairs, read_lists)):
+    flanks, reads, first = [], [], np.zeros(n_loci + 1, np.int64)
+    for i, ((lf, rf), rl) in enumerate(zip(flank_pairs, read_lists)):
         flanks += [lf[-flanking_region_size:], rf[:flanking_region_size]]
-        for s in reads:
-            fwd.append(str(s).upper())
-            read_locus.append(i)
+        reads += [s if isinstance(s, str) else str(s) for s in rl]
+        first[i + 1] = len(reads)
     out = [([], []) for _ in range(n_loci)]
-    n = len(fwd)
+    n = len(reads)
     if n == 0:
         return out
-    read_locus = np.asarray(read_locus, np.int32)
+    read_locus = np.repeat(np.arange(n_loci, dtype=np.int32), np.diff(first))
     strand_read = np.arange(2 * n, dtype=np.int32) // 2 + (np.arange(2 * n, dtype=np.int32) & 1) * n
     pair_read = np.repeat(strand_read, 2)
     pair_flank = (2 * np.repeat(read_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n)).astype(np.int32)
-    score, begin, _, _ = _lib.flank_align(fwd, flanks, pair_read, pair_flank)
+    score, begin, _, _ = _lib.flank_align(reads, flanks, pair_read, pair_flank)
     flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
     need = flen * (1 - settings.MAX_ERROR_RATE)
     ok = ((score[0::2] > 0) & (score[0::2] >= need[pair_flank[0::2]]) & (score[1::2] > 0) &
           (score[1::2] >= need[pair_flank[1::2]]) & (begin[1::2] >= begin[0::2]))
-    for k in np.flatnonzero(ok).tolist():
-        lb, rb = int(begin[2 * k]), int(begin[2 * k + 1])
-        r = k // 2
-        seq = fwd[r] if not (k & 1) else fwd[r].translate(_COMP_STR)[::-1]
-        first = int(np.searchsorted(read_locus, read_locus[r]))
-        spanning, lengths = out[int(read_locus[r])]
-        spanning.append((seq[lb:rb + flanking_region_size], r - first, bool(k & 1)))
+    hits = np.flatnonzero(ok)
+    lbs, rbs = begin[2 * hits].tolist(), begin[2 * hits + 1].tolist()
+    for k, lb, rb in zip(hits.tolist(), lbs, rbs):
+        r = k >> 1
+        s = reads[r]
+        if k & 1:       # coordinates of the reverse complement: its piece [lb, rb + F) is the reverse complement of this one
+            piece = s[max(len(s) - (rb + flanking_region_size), 0):len(s) - lb].upper().translate(_COMP_STR)[::-1]
+        else:
+            piece = s[lb:rb + flanking_region_size].upper()
+        i = int(read_locus[r])
+        spanning, lengths = out[i]
+        spanning.append((piece, r - int(first[i]), bool(k & 1)))
         lengths.append(rb - (lb + flanking_region_size))
     return out
 
