@@ -50,8 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")
     ap.add_argument("--stream", action="store_true", help="experimental stream-packed column kernel")
     ap.add_argument("--antidiagonal", action="store_true", help="one-read-per-wavefront anti-diagonal kernel")
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "c4"],
-                    help="default: c1 at --gpus 1, c3 at --gpus > 1.  c1: 1 REF150 locus x --reads per GPU (weak); c2: --loci "
+    ap.add_argument("--workload", default=None, choices=["c1", "s300", "c2", "c3", "c4"],
+                    help="default: c1 at --gpus 1, c3 at --gpus > 1.  c1: 1 REF150 locus x --reads per GPU (weak); s300: the same "
+                         "recipe on the metric's ~300-state shape (the launch the `s300` sub-record times, alone: for profilers); c2: --loci "
                          "synthetic loci x ~160 calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by "
                          "estimated work (strong scaling, BASELINE config 3), records gathered to rank 0 over RCCL; "
                          "c4: --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads per GPU")
@@ -210,6 +211,17 @@ def load_json(*parts):
         return None
 
 
+def measured_clock_ghz():
+    """The shader clock under the bench kernel, measured once per round with GRBM_GUI_ACTIVE over the dispatch duration
+    (scripts/clock_measure.sh -> profiles/r04_clock_summary.json; MI355X_MICROARCH.md, DVFS); None without the profile."""
+    d = load_json("profiles", "r04_clock_summary.json") or {}
+    for k, v in d.items():
+        if "viterbi_rows_kernel" in k and v.get("effective_clock_mhz"):
+            # (the counter is summed over the chip's 8 XCDs)
+            return v["effective_clock_mhz"] / 8.0 / 1e3
+    return None
+
+
 def pmc_section(workload, n_calls, kernel):
     """Counters per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench);
     None when no committed profile describes this workload / kernel / size."""
@@ -335,7 +347,7 @@ def main(argv=None):
         relax_total = float(np.sum((lens + 1) * edges_per_locus[which]))
     else:
         c2_input = upstream_input = None
-        if world == 1 and not args.no_c2 and not args.no_s300:
+        if world == 1 and workload == "c1" and not args.no_c2 and not args.no_s300:
             # the target configuration of the north star rides on the C1 line as sub-records `c2` / `end_to_end`; its
             # synthetic reads come out of a process pool, which must have gone before the GPU is touched (see above)
             t_gen = time.perf_counter()
@@ -346,7 +358,7 @@ def main(argv=None):
             import gc
             gc.collect()
             gc.freeze()
-        locus = workloads.ref150()
+        locus = workloads.s300() if workload == "s300" else workloads.ref150()
         a = locus.model.baked_arrays()
         m, P, E = a["m"], a["silent_start"], len(a["in_src"])
         n_reads = args.reads
@@ -456,7 +468,10 @@ def main(argv=None):
         traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
         traffic = traffic / 1e9 if traffic else None
         valu_insts = pmc.get("valu_insts_per_launch")
-        if workload == "c1":
+        if workload == "s300":
+            metric = "reads/sec Viterbi-scored (150 bp reads, S300 profile HMM: %d states / %d edges)" % (m, E)
+            wl = "S300: 1 VNTR locus (flank 30, 12-bp pattern, 3 copies) x 100k synthetic 150-bp reads per GPU, seed 20240601"
+        elif workload == "c1":
             metric = "reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
             wl = ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic 150-bp reads per GPU, "
                   "seed 20240601")
@@ -510,6 +525,17 @@ def main(argv=None):
                                                "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "issue_bound_ms": bound_ms,
                                                "kernel_ms": kernel_ms, "frac": bound_ms / kernel_ms,
                                                "source": pmc.get("file"), "stale": pmc.get("stale")}
+            ghz = measured_clock_ghz()
+            if ghz:
+                # at the clock the chip really holds under this kernel, and at the rate it really issues 64-bit-encoded vector
+                # instructions (fp64 arithmetic, DPP, three-operand forms: ~4.5 cycles each at 3-4 wavefronts per SIMD,
+                # profiles/r01_valu_ubench.txt, r02_f64_issue_ubench.txt) -- nominal: 4 cycles at 2.4 GHz
+                b = out["roofline"]["bound_actual"]
+                b["clock_ghz_measured"] = ghz
+                b["clock_source"] = "profiles/r04_clock_summary.json (GRBM_GUI_ACTIVE / dispatch duration)"
+                b["issue_bound_ms_at_measured_clock"] = valu_insts * 4 / (SIMDS * ghz * 1e9) * 1e3
+                b["frac_at_measured_clock"] = b["issue_bound_ms_at_measured_clock"] / kernel_ms
+                b["frac_at_measured_clock_and_4p5_cycles_per_inst"] = b["issue_bound_ms_at_measured_clock"] * 4.5 / 4 / kernel_ms
         if workload == "c1" and not args.no_s300:
             out["s300"] = s300_record(_lib, workloads, flags, args)
             out["log_probability"] = forward_record(_lib, locus, batch, bases, off, n_reads, n, args)
@@ -595,9 +621,11 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     if nc:
         cells = float(n_reads) * n * nc
         tflops = cells * FORWARD_FMA_PER_CELL * 2 / (kernel_ms * 1e-3) / 1e12
+        ghz = measured_clock_ghz()
         rec["roofline"] = {"bound": "valu_f64", "achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": tflops / F64_PEAK_TFLOPS, "cells": cells, "fma_per_cell": FORWARD_FMA_PER_CELL,
-                           "columns": nc,
+                           "columns": nc, "clock_ghz_measured": ghz,
+                           "frac_at_measured_clock": tflops / (F64_PEAK_TFLOPS * ghz / CLOCK_GHZ) if ghz else None,
                            "note": "trellis cells (read length x model columns x reads) x 11 fused multiply-adds x 2 flop over the "
                                    "HIP-event kernel time, against the fp64 vector peak (16 lanes/cycle/SIMD x 1024 SIMDs x 2.4 GHz)"}
     if not args.no_cpu:
@@ -1110,6 +1138,25 @@ def s300_record(_lib, workloads, flags, args):
         rec["cpu_1thread_reads_per_s"] = k / (time.perf_counter() - t0)
         logp, _ = batch.fetch()
         assert np.array_equal(cpu_logp, logp[:k]), "GPU/oracle log-prob mismatch on the S300 sample"
+    # the sum-product twin on the same resident batch (the back-to-back sweeps matter most on this narrow model)
+    dm = locus.model.device_model()
+    nc = dm.n_columns()
+    batch.forward()
+    batch.sync()
+    fwd_ms = batch.forward_timed(max(1, args.steps))
+    lp, _ = batch.fetch()
+    tflops = float(n_reads) * n * nc * FORWARD_FMA_PER_CELL * 2 / (fwd_ms * 1e-3) / 1e12
+    rec["log_probability"] = {"kernel_ms": fwd_ms, "value": n_reads / (fwd_ms * 1e-3), "unit": "reads/s",
+                              "kernel": "forward_rows_kernel<5, 2>", "columns": nc,
+                              "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": tflops / F64_PEAK_TFLOPS}}
+    if not args.no_cpu:
+        worst = 0.0
+        for i in range(min(100, n_reads)):
+            want = O.forward(bases[off[i]:off[i + 1]])
+            worst = max(worst, abs(lp[i] - want) / max(1.0, abs(want)))
+        rec["log_probability"]["max_rel_diff_vs_oracle"] = worst
+        assert worst <= 1e-9, "GPU/oracle log_probability mismatch on the S300 sample"
     batch.close()
     return rec
 
