@@ -696,6 +696,15 @@ def extract_spanning_reads(left_flanking_region, right_flanking_region, reads, f
 _COMP_STR = str.maketrans("ACGTN", "TGCAN")
 
 
+def _spanning_piece(read, begin, end, reverse):
+    """str(read).upper()[begin:end] -- or, for the reverse strand, reverse_complement(read).upper()[begin:end] -- touching only
+    that piece of the read: the piece [begin, end) of the reverse complement is the reverse complement of [n - end, n - begin)."""
+    if not reverse:
+        return read[begin:end].upper()
+    n = len(read)
+    return read[max(n - end, 0):max(n - begin, 0)].upper().translate(_COMP_STR)[::-1]
+
+
 def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=100):
     """extract_spanning_reads for many loci in ONE advntr_flank_align call: flank_pairs[i] = (left_flanking_region,
     right_flanking_region) of locus i, read_lists[i] = its candidate long reads.  Returns one (spanning, length_distribution)
@@ -727,10 +736,7 @@ def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=1
     for k, lb, rb in zip(hits.tolist(), lbs, rbs):
         r = k >> 1
         s = reads[r]
-        if k & 1:       # coordinates of the reverse complement: its piece [lb, rb + F) is the reverse complement of this one
-            piece = s[max(len(s) - (rb + flanking_region_size), 0):len(s) - lb].upper().translate(_COMP_STR)[::-1]
-        else:
-            piece = s[lb:rb + flanking_region_size].upper()
+        piece = _spanning_piece(s, lb, rb + flanking_region_size, bool(k & 1))
         i = int(read_locus[r])
         spanning, lengths = out[i]
         spanning.append((piece, r - int(first[i]), bool(k & 1)))

@@ -319,7 +319,8 @@ def make_flank_align_workload(n_reads=4000, min_len=5000, max_len=15000, seed=11
         s = rand_seq(rng, n)
         if k % 3 == 0:
             core = noisy_copy(rng, left + pattern * int(rng.integers(3, 20)) + right, 0.12)
-            at = int(rng.integers(0, n - len(core)))
-            s = s[:at] + core + s[at + len(core):]
+            if len(core) < n:
+                at = int(rng.integers(0, n - len(core)))
+                s = s[:at] + core + s[at + len(core):]
         reads.append(s)
     return left, right, reads

@@ -6,14 +6,17 @@ B="--no-cpu --no-s300 --no-c2"
 for w in c1 s300 c2 c4; do timeout 200 python3 bench.py --workload $w $B --steps 2 > $out/${w}_quick.json 2> $out/${w}_quick.err; done
 cd /tmp && export TMPDIR=/tmp
 # the sum-product kernels alone (REF150 and S300, resident batches)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd.log 2>&1 < /dev/null
+export FWD_NO_GENERIC=1
+FWD_SHAPES=REF150 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd.log 2>&1 < /dev/null
+FWD_SHAPES=S300 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_fwd_s300 -- python3 $root/scripts/forward_bench.py > $root/$out/trace_fwd_s300.log 2>&1 < /dev/null
+unset FWD_NO_GENERIC
 declare -A passes=([c1]="--steps 20 --warmup 5" [s300]="--steps 20 --warmup 5" [c2]="--steps 10 --warmup 3" [c4]="--steps 5 --warmup 2")
 for w in c1 s300 c2 c4; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_$w -- python3 $root/bench.py --workload $w $B ${passes[$w]} > $root/$out/trace_$w.log 2>&1 < /dev/null
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_${w}_$c -- python3 $root/bench.py --workload $w $B --steps 1 --warmup 0 > $root/$out/pmc_${w}_$c.log 2>&1 < /dev/null
   done
-  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU_ADD_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $root/$out/pmc_${w}_sq -- python3 $root/bench.py --workload $w $B --steps 1 --warmup 0 > $root/$out/pmc_${w}_sq.log 2>&1 < /dev/null
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU_ADD_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $root/$out/pmc_${w}_sq -- python3 $root/bench.py --workload $w $B --steps 1 --warmup 0 > $root/$out/pmc_${w}_sq.log 2>&1 < /dev/null
 done
 cd $root
 python3 - "$out" <<'PY'
@@ -46,6 +49,8 @@ for w in ("c1", "s300", "c2", "c4"):
         open("%s/%s_kernel_stats.csv" % (out, w), "w").write(open(f).read())
 for f in glob.glob("%s/trace_fwd/**/*kernel_stats.csv" % out, recursive=True):
     open("%s/forward_rows_kernel_stats.csv" % out, "w").write(open(f).read())
+for f in glob.glob("%s/trace_fwd_s300/**/*kernel_stats.csv" % out, recursive=True):
+    open("%s/forward_rows_s300_kernel_stats.csv" % out, "w").write(open(f).read())
 json.dump({"note": "per-launch counters of the dominant kernel of `python bench.py --workload W` (rocprofv3 --pmc, separate "
                    "passes); FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (WRITE + 2 x FETCH) x 1024",
            "sections": sections}, open(out + "/pmc_summary.json", "w"), indent=1)

@@ -112,3 +112,34 @@ def test_reference_genotyping_unit_tests_replayed():
     empty = np.zeros(8, np.int32)
     assert vntr_finder.recruit_read(-20, empty, -50, 100) is True
     assert vntr_finder.recruit_read(-60, empty, -50, 100) is False
+
+
+def test_spanning_piece_equals_slicing_the_whole_strand():
+    """extract_spanning_reads_multi upper-cases and reverse-complements only the trimmed piece of a long read: the same string
+    as slicing the upper-cased (reverse-complemented) whole read, as the reference does (vntr_finder.py:362,367-371)."""
+    import numpy as np
+    from advntr_amd import vntr_finder as vf
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        n = int(rng.integers(0, 400))
+        read = "".join(rng.choice(list("ACGTacgtN"), n))
+        b = int(rng.integers(0, n + 2))
+        e = int(rng.integers(b, n + 120))
+        fwd = read.upper()
+        rev = fwd.translate(str.maketrans("ACGTN", "TGCAN"))[::-1]
+        assert vf._spanning_piece(read, b, e, False) == fwd[b:e]
+        assert vf._spanning_piece(read, b, e, True) == rev[b:e]
+
+
+def test_round4_workload_generators_are_seeded_and_shaped():
+    from advntr_amd import workloads
+    loci, reads = workloads.make_pacbio_whole_reads(3, seed=5, n_reads=10, min_len=1200, max_len=2000, workers=1)
+    again = workloads.make_pacbio_whole_reads(3, seed=5, n_reads=10, min_len=1200, max_len=2000, workers=1)
+    assert reads == again[1] and len(loci) == 3 and all(len(r) == 10 for r in reads)
+    assert all(len(l[0]) == 500 and len(l[1]) == 500 and l[2] == [l[3]] for l in loci)
+    lines, fasta, rec = workloads.make_prefilter_workload(20, 300, read_len=50, locus_every=10)
+    assert len(fasta) == 300 * rec and rec == 10 + 50 + 1 and len(lines) == 20
+    assert fasta[:rec] == b">r0000000\n" + fasta[10:60] + b"\n" and fasta[rec:rec + 10] == b">r0000001\n"
+    assert set(fasta[10:60]) <= set(b"ACGT") and all(len(k) == 15 for _, kws in lines for k in kws)
+    left, right, long_reads = workloads.make_flank_align_workload(6, min_len=500, max_len=900)
+    assert len(left) == len(right) == 100 and len(long_reads) == 6 and all(500 <= len(s) <= 900 for s in long_reads)
