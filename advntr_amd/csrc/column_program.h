@@ -36,11 +36,18 @@
                                      // over (reads are trimmed to the VNTR + 100-base flanks, VNTRs are capped at 10 kb:
                                      // vntr_finder.py:362,415, models.py:164,174) and what the GPU suite covers (100 000)
 
-struct ColClass {             // 11 doubles = 88 B: an odd multiple of 8 B, so records that differ by less than 32
-                              // classes never share an LDS bank at the same field (64 banks x 4 B for ds_read_b64)
+struct ColClass {             // 12 doubles = 96 B: six 16-byte LDS words.  (Rounds 1-3: 11 doubles = 88 B, an odd multiple of 8 B that
+                              // kept the 8-byte reads of the anti-diagonal kernel off each other's banks; the row-blocked sweeps read
+                              // the whole record every step, and as six ds_read_b128 -- 4 LDS cycles each -- instead of five
+                              // ds_read2_b64 + one ds_read_b64 -- 8 each -- they run 2.6 % (Viterbi, REF150) and 2.9 % (sum-product)
+                              // faster: DESIGN.md 4.1)
     double iI, iM, iD, mI;    // I_c <- I_c, M_c, b_c (prev row);   M_c <- I_{c-1}
     double mM, mX, mD, dI;    // M_c <- M_{c-1}, X (row 0 only, value incl. source), b_{c-1};  b_c <- I_{c-1}
     double dM, dD, erw;       // b_c <- M_{c-1}, b_{c-1};  feed weight
+    double pad16;
+#ifdef COL_CLASS_112
+    double pad112[2];         // (experiment: 112-byte records -- 7 slots of 16 bytes, coprime with the 16 slots of an LDS line)
+#endif
 };
 #define COL_EMIS_STRIDE 5     // doubles per emission class (4 used): 40-B records, bank-conflict free below 32 classes
 
@@ -474,7 +481,7 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         emap[key] = id;
         return id;
     };
-    ColClass none;
+    ColClass none{};
     none.iI = none.iM = none.iD = none.mI = none.mM = none.mX = none.mD = none.dI = none.dM = none.dD = none.erw = NINF;
     const int none_class = class_of(none);
     const double noe[4] = {NINF, NINF, NINF, NINF};

@@ -83,9 +83,11 @@ __device__ __forceinline__ void rows_sweep_fwd(const LdsTables &L, const int NC,
         const adv_f64x2 f0 = *(LdsDouble2 *)(size_t)pf;          // {row-0 value of b_c, entry term of M_c} of the lane's column
         pa += 16u; pf += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
-        LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
-        const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
-        const double erw_c = T->erw;
+        // the column's transition class record, 96 bytes as six 16-byte words (ColClass)
+        LdsDouble2 *T2 = (LdsDouble2 *)(size_t)(meta.x & 0xffffu);
+        const adv_f64x2 t0 = T2[0], t1 = T2[1], t2 = T2[2], t3 = T2[3], t4 = T2[4], t5 = T2[5];
+        const double iI = t0.x, iM = t0.y, iD = t1.x, mI = t1.y, mM = t2.x, mD = t3.x, dI = t3.y, dM = t4.x, dD = t4.y;
+        const double erw_c = t5.x;
         const unsigned epo = meta.y;
         const bool on_sink = (meta.x >> 24) != 0u;
         const unsigned feedb = (meta.x >> 16) & 0xffu;

@@ -217,8 +217,10 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         pa += 16u;
         const uint2 meta_next = lds_uint2(pa + 8u);
         const double v0b_next = *(LdsDouble *)(size_t)pa;
-        LdsClass *T = (LdsClass *)(size_t)(meta.x & 0xffffu);
-        const double iI = T->iI, iM = T->iM, iD = T->iD, mI = T->mI, mM = T->mM, mD = T->mD, dI = T->dI, dM = T->dM, dD = T->dD;
+        // the column's transition class record, 96 bytes as six 16-byte words (ColClass)
+        LdsDouble2 *T2 = (LdsDouble2 *)(size_t)(meta.x & 0xffffu);
+        const adv_f64x2 t0 = T2[0], t1 = T2[1], t2 = T2[2], t3 = T2[3], t4 = T2[4], t5 = T2[5];
+        const double iI = t0.x, iM = t0.y, iD = t1.x, mI = t1.y, mM = t2.x, mD = t3.x, dI = t3.y, dM = t4.x, dD = t4.y;
         const unsigned epo = meta.y;                 // this column's offset inside a symbol row of the emission pair table
         // flags of the lane's column (stage_model<1, true>): byte 3 = fan-in sink, byte 2 = feeder | fed sink's index << 1
         const bool on_sink = (meta.x >> 24) != 0u;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void rows_sweep(const LdsTables &L, const int NC, con
         // maximum `er`; a feeder that beats it writes its column straight into the sink's back-pointer slot of that row
         // (later winners overwrite earlier ones), so no winner register is carried.  Lanes that are not on a feeder
         // column carry weight -inf and never win.
-        const double erw_c = T->erw, mX = T->mX;      // read with the rest of the record: one LDS round trip per step
+        const double erw_c = t5.x, mX = t2.y;         // read with the rest of the record: one LDS round trip per step
         const bool anyfeed = __ballot(on_feed) != 0;      // wave-uniform: false while the wave is in a flank
         const unsigned *bps = bpw + (int64_t)sstep * (64 * WORDS);    // the step's back-pointer slab (scalar address)
         double *capq = rown + 3 * sstep + cap_lane;          // where this column's row-n values go (lane holding the last row)
