@@ -44,10 +44,7 @@ struct ColClass {             // 12 doubles = 96 B: six 16-byte LDS words.  (Rou
     double iI, iM, iD, mI;    // I_c <- I_c, M_c, b_c (prev row);   M_c <- I_{c-1}
     double mM, mX, mD, dI;    // M_c <- M_{c-1}, X (row 0 only, value incl. source), b_{c-1};  b_c <- I_{c-1}
     double dM, dD, erw;       // b_c <- M_{c-1}, b_{c-1};  feed weight
-    double pad16;
-#ifdef COL_CLASS_112
-    double pad112[2];         // (experiment: 112-byte records -- 7 slots of 16 bytes, coprime with the 16 slots of an LDS line)
-#endif
+    double pad16;             // (112-byte records -- 7 slots, coprime with the 16 slots of an LDS line -- measured: no difference)
 };
 #define COL_EMIS_STRIDE 5     // doubles per emission class (4 used): 40-B records, bank-conflict free below 32 classes
 
