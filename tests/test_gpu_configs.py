@@ -173,6 +173,46 @@ def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
     assert np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
 
 
+def test_scale_rehearsal_partitions_the_set_like_the_multi_gpu_job():
+    """bench.py --workload c3 --emulate-ranks 4 (one process, one GPU): the shares are the LPT partition `--gpus 4` makes --
+    whole loci, every call exactly once --, each runs as its own resident batch with the multi-GPU launch parameters, and the
+    record is labelled a projection."""
+    d = _bench(["--workload", "c3", "--loci", "240", "--steps", "2", "--warmup", "1", "--no-cpu", "--emulate-ranks", "4"])
+    r = d["scale_rehearsal"]
+    assert r["projection"] is True and r["ranks"] == 4 and len(r["shares"]) == 4
+    assert sum(x["calls"] for x in r["shares"]) == d["config"]["calls_this_rank"] == r["whole_set"]["calls"]
+    assert sum(x["loci"] for x in r["shares"]) == 240
+    assert all(x["loop_ms"] > 0 and x["kernel_ms"] > 0 for x in r["shares"])
+    assert 0.0 < r["projected_efficiency"] <= 1.5 and r["load_imbalance_max_over_mean"] >= 1.0
+    from advntr_amd import sharding, workloads
+    plan = workloads.c2_plan(240, seed=20240602)
+    parts = sharding.partition_loci([c * 151 * m for c, m in plan], 4)
+    assert sorted(x["calls"] for x in r["shares"]) == sorted(int(sum(plan[int(k)][0] for k in p)) for p in parts)
+
+
+def test_reserved_workgroups_cover_one_pass_only():
+    """advntr_batch_reserve_next (what the gather of a multi-GPU job asks for): same results, and a small batch -- whose grid
+    does not fill the device -- is not cut down to a single workgroup."""
+    from advntr_amd import _lib, workloads
+    locus = workloads.s300()
+    reads = workloads.make_reads(np.random.default_rng(3), locus, 3000, 150)
+    bases, off = _lib.encode_reads(reads)
+    batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(len(reads), np.int32))
+    batch.run()
+    want = batch.fetch()
+    batch.reserve_next(8)
+    batch.run()
+    got = batch.fetch()
+    assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    t_plain = batch.run_timed(5)
+    batch.reserve_next(8)
+    t_reserved = batch.run_timed(1)
+    assert t_reserved < 3 * t_plain + 1.0
+    with pytest.raises(_lib.EngineError):
+        batch.reserve_next(-1)
+    batch.close()
+
+
 def test_c3_rccl_communicator_world_size_1(tmp_path):
     """The RCCL path with the one rank a 1-GPU box allows (what torch.distributed.run --nproc-per-node 1 sets up): unique
     id through the rendezvous, ncclCommInitRank, the small collectives, the overlapped gather of the result records inside
