@@ -126,11 +126,14 @@ __device__ __forceinline__ int rows_bp_at_split(const unsigned *__restrict__ bpw
     const int lp = lp_in < 0 ? ln : lp_in;
     // masks of a cell in relaxation order: aM bM | aI bI | aB bB (a: the 2nd candidate won, b: the last one did)
     const int grp = st == 1 ? 0 : (st == 0 ? 1 : 2);
-    const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + grp * 4 + (ln >> 5);
+    const unsigned *cell = bpw + (int64_t)(cc + lp) * (64 * WORDS) + k * 12 + grp * 4;
     const int sh = ln & 31;
-    // (the masks were written with scalar stores, which do not pass through the vector L1: read around it)
-    const unsigned a = (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
-    const unsigned b = (__hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> sh) & 1u;
+    // both masks of the state (16 bytes, one line) in ONE load; the masks were written with scalar stores, which do not pass
+    // through the vector L1: read around it (sc1)
+    uint4 w;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(cell) : "memory");
+    const unsigned a = ((ln & 32 ? w.y : w.x) >> sh) & 1u;
+    const unsigned b = ((ln & 32 ? w.w : w.z) >> sh) & 1u;
     return (int)((a << 1 | b) << (st == 1 ? 2 : (st == 0 ? 4 : 0)));
 }
 
