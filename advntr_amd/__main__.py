@@ -97,6 +97,13 @@ def genotype(args):
     settings.MAX_ERROR_RATE = 0.3 if args.pacbio else 0.05                      # advntr_commands.py:66-71
     if args.pacbio:
         def pacbio_job(indices):
+            if args.extract_spanning:
+                # whole long reads: extraction, per-locus models, scoring and the call for all of this rank's loci at once
+                # (find_repeat_count_from_pacbio_reads, vntr_finder.py:652-665; every read is a candidate of every locus)
+                desc = [(loci[i]["left"], loci[i]["right"], loci[i]["repeat_segments"], loci[i]["pattern"]) for i in indices]
+                res = vntr_finder.genotype_pacbio_loci(desc, [seqs] * len(desc), accuracy_filter=args.accuracy_filter,
+                                                       is_haploid=args.haploid, chunks=max(1, min(8, len(desc) // 4)))
+                return [row(loci[i], r) for i, r in zip(indices, res)]
             out = []
             for i in indices:
                 loc = loci[i]
