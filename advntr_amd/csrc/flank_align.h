@@ -97,9 +97,11 @@ __device__ __forceinline__ int fa_pk_minu(int a, int b)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ int fa_pk_mad(int a, int b, int c)
+__device__ __forceinline__ int fa_pk_mad(int a, int b, int c)          // (one v_pk_mad_i16: left to itself the compiler emits a shift and a subtraction)
 {
-    return __builtin_bit_cast(int, (fa_s16x2)(__builtin_bit_cast(fa_s16x2, a) * __builtin_bit_cast(fa_s16x2, b) + __builtin_bit_cast(fa_s16x2, c)));
+    int r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 // both halves one lane on: lane i <- v[i-1]; lane 0: high half <- low half of lane 63, low half <- lane0_lo (lane 0's, high half 0)
 __device__ __forceinline__ int fa_pk_shr1(int v, int lane0_lo)
