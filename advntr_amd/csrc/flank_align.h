@@ -106,7 +106,11 @@ __device__ __forceinline__ int fa_pk_mad(int a, int b, int c)          // (one v
 // both halves one lane on: lane i <- v[i-1]; lane 0: high half <- low half of lane 63, low half <- lane0_lo (lane 0's, high half 0)
 __device__ __forceinline__ int fa_pk_shr1(int v, int lane0_lo)
 {
-    int old = __builtin_amdgcn_mov_dpp(v << 16, 0x13C, 0xf, 0xf, false);       // wave_ror:1: lane 0 <- lane 63
+    // (low half of the lane below) << 16 in ONE instruction: a 24-bit multiply by 65536 of the rotated register (the high half
+    // leaves through the top) -- instead of a shift and a DPP move: 6.75 -> 6.1 ms per 16 000 alignments.  Hand-written DPP: the
+    // two wait states between a vector write of `v` and its DPP read are spelled out (the compiler does not look into the asm).
+    int old;
+    asm volatile("s_nop 1\n\tv_mul_u32_u24_dpp %0, %1, %2 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(old) : "v"(v), "v"(65536));
     old |= lane0_lo;
     return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);         // wave_shr:1, lane 0 keeps `old`
 }

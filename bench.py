@@ -1014,11 +1014,11 @@ def flank_align_record(_lib, inp, args):
     cells = float(lens.sum()) * 4 * 100
     bytes_alg = float(lens.sum()) * 4
     # the sweep of a pair takes n + lf - 1 steps of 128 cells (both 64-column chunks of a lane in the halves of one register);
-    # instruction census of a step (ISA of flank_align_kernel, pass 1): 20 wave64 vector instructions -- 5 DPP moves, 7 packed
+    # instruction census of a step (ISA of flank_align_kernel, pass 1): 18 wave64 vector instructions -- 5 DPP operations, 7 packed
     # 16-bit operations, 2 byte permutes and a three-way maximum (all 64-bit encodings: ~4.5 cycles each on this part,
-    # profiles/r01_valu_ubench.txt) and 5 plain 32-bit ones (~2.6)
+    # profiles/r01_valu_ubench.txt) and 3 plain 32-bit ones (~2.6)
     steps = float((lens + 99).sum()) * 4
-    valu_per_step = 20
+    valu_per_step = 18
     peak = 128.0 / (valu_per_step * 2) * SIMDS * CLOCK_GHZ * 1e9
     rec = {"alignments": int(len(pr)), "reads": n, "value": len(pr) / (ms * 1e-3), "unit": "alignments/s", "dtype": "i16 (packed pairs)",
            "kernel_ms": ms, "call_ms_incl_pcie_and_host": wall * 1e3, "cells_per_s": cells / (ms * 1e-3),
@@ -1031,7 +1031,7 @@ def flank_align_record(_lib, inp, args):
                                          "peak_note": "every instruction at the nominal 2 cycles per wave64 instruction",
                                          "frac": cells / (ms * 1e-3) / peak,
                                          "cycles_per_step_measured": ms * 1e-3 * CLOCK_GHZ * 1e9 * SIMDS / steps,
-                                         "cycles_per_step_at_measured_issue_rates": 15 * 4.5 + 5 * 2.6}}}
+                                         "cycles_per_step_at_measured_issue_rates": 15 * 4.5 + 3 * 2.6}}}
     if not args.no_cpu:
         n_cpu = 24
         t0 = time.perf_counter()

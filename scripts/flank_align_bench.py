@@ -56,14 +56,14 @@ print(json.dumps({"metric": "flank alignments/s (100-base flank vs 5-15 kb read,
                                "note": "tier rule (HBM) only: the binding roof is int32 VALU issue, see bound_actual",
                                "bound_actual": {"bound": "valu_int", "unit": "DP cells/s",
                                                 "achieved": cells / (ms * 1e-3),
-                                                # 20 wave64 VALU instructions per step of 128 cells (round 3: 28 per 64 cells), at the
+                                                # 18 wave64 VALU instructions per step of 128 cells (round 3: 28 per 64 cells), at the
                                                 # nominal 2 cycles each on 1024 SIMDs at 2.4 GHz; 15 of them are DPP / VOP3P / VOP3
                                                 # encodings, which this part issues at ~4.5 cycles (profiles/r01_valu_ubench.txt)
-                                                "valu_per_step_of_128_cells": 20,
-                                                "peak": 128.0 / (20 * 2) * 1024 * 2.4e9,
-                                                "frac": cells / (ms * 1e-3) / (128.0 / (20 * 2) * 1024 * 2.4e9),
+                                                "valu_per_step_of_128_cells": 18,
+                                                "peak": 128.0 / (18 * 2) * 1024 * 2.4e9,
+                                                "frac": cells / (ms * 1e-3) / (128.0 / (18 * 2) * 1024 * 2.4e9),
                                                 "cycles_per_step_measured": ms * 1e-3 * 2.4e9 * 1024 / steps,
-                                                "cycles_per_step_at_measured_issue_rates": 15 * 4.5 + 5 * 2.6}},
+                                                "cycles_per_step_at_measured_issue_rates": 15 * 4.5 + 3 * 2.6}},
                   "cpu_baseline": {"value": cpu, "unit": "alignments/s", "cores": 1, "kind": "port",
                                    "sample": "first %d alignments, oracle/flank_align_oracle.c (biopython itself is absent: parity "
                                              "unpinned); results equal to the GPU's" % n_cpu}}))
