@@ -5,9 +5,14 @@ A "step" is one pass of the hot path (Viterbi DP + traceback + path summaries) o
 reads; inputs are in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
   --gpus 1 (default): config C1 of BASELINE.json / SURVEY 8d -- one REF150 locus (flank 150, 14-bp pattern, 11 copies:
-      1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp reads.  The line also carries the S300 shape
-      (the "~300-state" label of the metric), the roofline object, the VALU bound that actually binds, and the CPU
-      baseline (the C oracle on the host cores, with its calibration against the vendored pomegranate).
+      1413 states / 921 emitting / 4626 edges), 100 000 synthetic 150-bp reads.  The line also carries the roofline object,
+      the VALU bound that actually binds (nominal, at the measured clock, at the measured issue rate), the CPU baseline (the C
+      oracle on the host cores, with its calibration against the vendored pomegranate), and as sub-records everything else that
+      has a number: `s300` (the "~300-state" label of the metric, Viterbi and log_probability), `log_probability`, `c2` and
+      `end_to_end` (BASELINE config 2: 6 719 loci, kernel alone and candidate reads -> genotypes), `scale_rehearsal` (the 8-rank
+      strong-scaling line projected from this one GPU), `c4` and `pacbio_end_to_end` (BASELINE config 5: 8 960 PacBio loci;
+      whole 5-15 kb reads -> genotypes), `prefilter` and `flank_align` (the two kernels upstream of the scoring path).  About
+      30 s on the GPU box.
   --gpus N > 1: config C3 -- ONE set of 6 719 synthetic Illumina loci (~1.07 M calls) partitioned over the N GPUs by
       estimated work (strong scaling; whole loci per rank, LPT), every rank scores its share with no exchange, and the
       per-call result records are gathered to rank 0 over RCCL inside the timed region (the gather of pass i overlaps
