@@ -168,6 +168,14 @@ static inline hipError_t column_launch_fwd(const ColumnLaunch &cl, const BatchAr
     return hipSuccess;
 }
 
+// forward_rows_kernel keeps, behind the row-0 table, the tail states' in-edge weights in the linear domain (two fan-in states
+// with an edge from every column, a few more): 16 bytes per column and then some -- when that still fits a compute unit
+static inline int forward_rows_tailw_cap(const size_t tables, const int nc_max)
+{
+    const size_t want = 2 * ((size_t)nc_max + 64);
+    return forward_lds_bytes(tables, nc_max) + 8 * want <= 160 * 1024 ? (int)want : 0;
+}
+
 // sum-product on the row-blocked layout: the short reads of a large batch (tile list 5 + cfg)
 template <int R, int G>
 static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const BatchArgs &a, hipStream_t stream, const int cfg)
@@ -183,8 +191,9 @@ static inline hipError_t column_launch_fwd_rows(const ColumnLaunch &cl, const Ba
     g.lds_tables = (int32_t)cl.lds_bytes;
     g.lds_level = cl.lds_level;
     g.rows_depth = cl.rows_depth;
+    g.fwd_tailw_cap = forward_rows_tailw_cap(cl.lds_bytes, cl.nc_max);
     const int grid = launch_grid(cl, g.n_tiles);
-    const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max);
+    const size_t lds = forward_lds_bytes(cl.lds_bytes, cl.nc_max) + 8 * (size_t)g.fwd_tailw_cap;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute((const void *)forward_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return hipErrorInvalidValue;

@@ -13,8 +13,12 @@
 // wave reduction, after every one of the 3 NC row values was taken to the log domain; here a tail state is the plain sum of
 // value x transition probability over its in-edges, and ONE logarithm is taken at the end (cycle counters in the kernel: the
 // log-domain version was 19 % of a wavefront's time).  Tail values of earlier tail states are kept in the same scale.
+// tw: the in-edge weights exp(transition log-probability) of the model, made once when the model was staged (LDS), or null:
+// then every read exponentiates them again -- a thousand exponentials per read on a model whose tail states collect an edge
+// from every column, 3 % of the kernel.
 __device__ __forceinline__ double rows_tail_forward_linear(const ColProgram *__restrict__ cp, double *__restrict__ row,
-                                                           double *__restrict__ tailv, const int rows, const int lane)
+                                                           double *__restrict__ tailv, const int rows, const int lane,
+                                                           const double *__restrict__ tw)
 {
     const ColFinishTables F = col_finish_tables(cp);
     const int n_tail = F.n_tail, end_tail = F.end_tail;
@@ -29,7 +33,7 @@ __device__ __forceinline__ double rows_tail_forward_linear(const ColProgram *__r
         for (int e = e0 + lane; e < e1; e += 64) {
             const TailEdge ed = F.edges[e];
             const double v = ed.loc >= 0 ? row[(ed.loc >> 2) * 3 + (ed.loc & 3)] : tailv[-ed.loc - 1];
-            sum = fma(v, exp(ed.logp), sum);
+            sum = fma(v, tw ? tw[e] : exp(ed.logp), sum);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -190,6 +194,7 @@ forward_rows_kernel(ColArgs g)
     LdsTables L{};
     const ColProgram *cp = nullptr;
     DevModel M{};
+    double *tailw = nullptr;
     for (;;) {
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
@@ -220,6 +225,16 @@ forward_rows_kernel(ColArgs g)
                 lin[i] = exp(fw[2 * c + (i & 1)]);
             }
             L.fwd_lin = lds_addr(lin);
+            // the tail states' in-edge weights in the linear domain, behind the row-0 table, when the launch left room for them
+            {
+                const ColFinishTables F = col_finish_tables(cp);
+                const int n_te = F.tptr[F.n_tail];
+                tailw = nullptr;
+                if (n_te <= g.fwd_tailw_cap) {
+                    tailw = lin + 2 * (ncol + 128);
+                    for (int e = tid; e < n_te; e += COL_WAVES * 64) tailw[e] = exp(F.edges[e].logp);
+                }
+            }
             __syncthreads();
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
@@ -274,7 +289,7 @@ forward_rows_kernel(ColArgs g)
                     if (jw + k * COL_WAVES * G + q >= tile.count) break;
                     const int src = k * G + q;
                     const int rq = __builtin_amdgcn_readlane(fr, src), nq = __builtin_amdgcn_readlane(fn, src);
-                    const double logp = rows_tail_forward_linear(cp, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv, nq, lane);
+                    const double logp = rows_tail_forward_linear(cp, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv, nq, lane, tailw);
                     if (lane == 0) g.a.out_logp[rq] = logp;
                     __builtin_amdgcn_wave_barrier();
                 }

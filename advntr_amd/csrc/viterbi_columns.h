@@ -66,6 +66,8 @@ struct ColArgs {
     int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
     int32_t ring;            // stream kernel: back-pointer slabs per wave (row tiles kept for the traceback)
     int32_t rows_depth;      // row-blocked kernels: reads per lane group of the deepest tile (back-to-back sweeps, viterbi_rows.h)
+    int32_t fwd_tailw_cap;   // forward_rows_kernel: tail-edge weights (exp of the transition log-probabilities) that fit the LDS
+                             // behind the row-0 table; 0: none, the weights are exponentiated per read
     int32_t lds_level;       // which tables of the column program are staged in LDS: 2 = all; 1 = all but the traceback's
                              // column->state table; 0 = only classes and emissions (+ the padded info copy the sweep
                              // indexes).  The rest is read from the model blob in HBM/L2, which leaves room for more
