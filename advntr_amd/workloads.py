@@ -213,6 +213,24 @@ def _c4_locus(args):
     return (left[-100:], right[:100], [pattern], max(1, copies), 0.3), reads
 
 
+def c4_plan(n_loci, seed=20240603, n_reads=20):
+    """[(calls, expected read length, expected states)] of every C4 locus WITHOUT generating a read -- what the multi-GPU
+    partitioner gets (sharding.partition_loci on calls x (length + 1) x states), and all a real run knows about a locus before
+    its reads have been extracted: the pattern length and the reference VNTR length.  _c4_locus draws both FIRST from the locus's
+    own generator, so this replays exactly those two draws; the reads then come out at 0.8-1.2 x the reference copy number
+    with indel noise, and the model is sized for the longest of them (vntr_finder.py:538-549): expected read length =
+    VNTR + 200 flank bases, expected copies = round((1.2 x VNTR + 100) / pattern), states = 6 F + 3 C (L + 1) + 18 (F = 100)."""
+    out = []
+    for k in range(n_loci):
+        rng = np.random.default_rng([seed, k])
+        plen = int(rng.integers(10, 61))
+        ref_copies = max(2, int(round(int(rng.integers(100, 1001)) / plen)))
+        vntr = ref_copies * plen
+        copies = max(1, int(round((1.2 * vntr + 100) / float(plen))))
+        out.append((n_reads, vntr + 200, 6 * 100 + 3 * copies * (plen + 1) + 18))
+    return out
+
+
 def make_c4(n_loci, seed=20240603, n_reads=20, workers=None, only=None):
     """([Locus], reads, read_locus) of the PacBio configuration; models built by the native builder (error 0.3)."""
     import multiprocessing as mp

@@ -10,13 +10,15 @@ reads; inputs are in HBM before the timed region.  Prints ONE JSON line on rank 
       oracle on the host cores, with its calibration against the vendored pomegranate), and as sub-records everything else that
       has a number: `s300` (the "~300-state" label of the metric, Viterbi and log_probability), `log_probability`, `c2` and
       `end_to_end` (BASELINE config 2: 6 719 loci, kernel alone and candidate reads -> genotypes), `scale_rehearsal` (the 8-rank
-      strong-scaling line projected from this one GPU), `c4` and `pacbio_end_to_end` (BASELINE config 5: 8 960 PacBio loci;
-      whole 5-15 kb reads -> genotypes), `prefilter` and `flank_align` (the two kernels upstream of the scoring path).  About
-      30 s on the GPU box.
+      strong-scaling line projected from this one GPU), `c4`, `c4_scale_rehearsal` and `pacbio_end_to_end` (BASELINE config 5:
+      8 960 PacBio loci, its 8-rank split rehearsed; whole 5-15 kb reads -> genotypes), `prefilter` and `flank_align` (the two
+      kernels upstream of the scoring path).  About 30 s on the GPU box.
   --gpus N > 1: config C3 -- ONE set of 6 719 synthetic Illumina loci (~1.07 M calls) partitioned over the N GPUs by
       estimated work (strong scaling; whole loci per rank, LPT), every rank scores its share with no exchange, and the
       per-call result records are gathered to rank 0 over RCCL inside the timed region (the gather of pass i overlaps
       the kernels of pass i+1; all gathers complete before the clock stops).  `value` = calls of the WHOLE set per second.
+  --workload c4 --gpus N: BASELINE config 5 the same way -- ONE set of 8 960 PacBio loci (179 200 calls), whole loci to ranks
+      by LPT on what is known of a locus before its reads exist (workloads.c4_plan), records gathered over RCCL, "strong".
 
 Launching: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (the driver's way; only the
 launcher is torch, this file imports none of it) the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; started
@@ -60,7 +62,8 @@ def parse_args(argv=None):
                          "recipe on the metric's ~300-state shape (the launch the `s300` sub-record times, alone: for profilers); c2: --loci "
                          "synthetic loci x ~160 calls per GPU (weak); c3: ONE set of --loci loci partitioned over the GPUs by "
                          "estimated work (strong scaling, BASELINE config 3), records gathered to rank 0 over RCCL; "
-                         "c4: --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads per GPU")
+                         "c4: ONE set of --loci PacBio loci (flank 100, error 0.3) x 20 trimmed spanning reads, partitioned over "
+                         "the GPUs like c3 (strong scaling, BASELINE config 5)")
     ap.add_argument("--loci", type=int, default=None, help="c2/c3: default 6719; c4: default 8960")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-s300", action="store_true")
@@ -68,7 +71,7 @@ def parse_args(argv=None):
                     help="c1 at --gpus 1: leave out the `c2` and `end_to_end` sub-records (the 6719-locus target configuration)")
     ap.add_argument("--c2-loci", type=int, default=6719, help="loci of the `c2` / `end_to_end` sub-records")
     ap.add_argument("--emulate-ranks", type=int, default=0,
-                    help="one process, one GPU: partition the C3 locus set for this many ranks (LPT, as --gpus N does), run every "
+                    help="one process, one GPU (--workload c3 or c4): partition the locus set for this many ranks (LPT, as --gpus N does), run every "
                          "rank's share as its own resident batch with the multi-GPU launch parameters and print a "
                          "`scale_rehearsal` record -- a PROJECTION of the strong-scaling line, not a measurement of it")
     ap.add_argument("--no-upstream", action="store_true",
@@ -298,17 +301,23 @@ def main(argv=None):
              _lib.FLAG_ANTIDIAGONAL if args.antidiagonal else 0)
     total_calls, t_build, plan_info = None, 0.0, {}
     host_workers = max(1, min(32, (os.cpu_count() or 2) // world - 1))
-    if workload == "c3":
+    if workload in ("c3", "c4"):
         # every rank derives the same plan and the same LPT partition without communicating
-        plan = workloads.c2_plan(n_loci, seed=20240602)
-        work = [calls * 151 * states for calls, states in plan]
+        if workload == "c3":
+            plan = workloads.c2_plan(n_loci, seed=20240602)
+            work = [calls * 151 * states for calls, states in plan]
+        else:
+            # (PacBio: what is known of a locus before its reads are extracted -- pattern and reference VNTR length -- prices it)
+            plan = workloads.c4_plan(n_loci, seed=20240603)
+            work = [calls * (length + 1) * states for calls, length, states in plan]
         parts = sharding.partition_loci(work, world)
         mine = parts[rank]
-        total_calls = int(sum(c for c, _ in plan))
+        total_calls = int(sum(p[0] for p in plan))
         loads = [float(sum(work[int(k)] for k in p)) for p in parts]
         plan_info = {"loci_per_rank": [int(len(p)) for p in parts],
                      "calls_per_rank": [int(sum(plan[int(k)][0] for k in p)) for p in parts],
-                     "load_imbalance_max_over_mean": max(loads) / (sum(loads) / world)}
+                     "load_imbalance_max_over_mean": max(loads) / (sum(loads) / world),
+                     "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0)}
     if args.dry_run:
         counts = comm.allgather_i64(plan_info["calls_per_rank"][rank] if plan_info else args.reads) if comm else [args.reads]
         if comm:
@@ -317,7 +326,7 @@ def main(argv=None):
             assert got == float(world - 1), got
         if rank == 0:
             emit({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
-                  "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload == "c3" else "weak",
+                  "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload in ("c3", "c4") else "weak",
                   "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
                                   "comm": comm.backend if comm else None}, **plan_info)})
         if comm:
@@ -325,7 +334,7 @@ def main(argv=None):
         return 0
     if workload in ("c2", "c3", "c4"):
         if workload == "c4":
-            loci, reads, which = workloads.make_c4(n_loci, seed=20240603 + rank, workers=host_workers)
+            loci, reads, which = workloads.make_c4(n_loci, seed=20240603, workers=host_workers, only=mine)
         elif workload == "c3":
             loci, reads, which = workloads.make_c2_parallel(n_loci, seed=20240602, build=False, only=mine, workers=host_workers)
         else:
@@ -439,6 +448,8 @@ def main(argv=None):
     if comm:
         rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
                           "kernel_ms": kernel_ms, "model_build_s": t_build,
+                          # the share's ACTUAL work (the plan prices a locus before its reads exist)
+                          "relaxations": relax_total, "cells": float(np.sum((np.diff(off) + 1) * ms[which])) if workload in ("c2", "c3", "c4") else None,
                           # the last gather of the timed region on the communicator's stream (HIP events): the transfer alone
                           # when it ran beside the next pass, about a pass when it had to wait for that pass's kernels
                           "gather_ms": state.get("gather_ms")}).encode()
@@ -450,12 +461,12 @@ def main(argv=None):
         assert np.array_equal(gathered[0][at:at + n_reads], logp), "RCCL gather returned different log-probabilities"
         assert np.array_equal(gathered[1][at:at + n_reads], summ), "RCCL gather returned different summaries"
         assert len(gathered[0]) == sum(counts)
-        if workload == "c3":
+        if workload in ("c3", "c4"):
             assert sum(counts) == total_calls, (sum(counts), total_calls)
 
     if args.dump_records:
-        if workload == "c3":                                # global call id = position in the whole set's locus order
-            first = np.concatenate([[0], np.cumsum([c for c, _ in plan])])
+        if workload in ("c3", "c4"):                        # global call id = position in the whole set's locus order
+            first = np.concatenate([[0], np.cumsum([p[0] for p in plan])])
             ids = np.concatenate([np.arange(first[int(k)], first[int(k) + 1]) for k in mine]) if len(mine) else np.zeros(0, np.int64)
         else:
             ids = np.arange(n_reads, dtype=np.int64) + rank * n_reads
@@ -481,11 +492,12 @@ def main(argv=None):
             wl = ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic 150-bp reads per GPU, "
                   "seed 20240601")
         elif workload == "c4":
-            metric = ("calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs, "
-                      "mean %d states)" % (n, n_loci, m))
+            metric = ("calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs%s, "
+                      "mean %d states)" % (n, n_loci, " partitioned over %d GPUs" % world if world > 1 else "", m))
             wl = ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x 20 trimmed "
-                  "spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution noise, seed 20240603; "
-                  "host model build %.2f s" % (n_loci, t_build))
+                  "spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution noise, seed 20240603 "
+                  "(ONE set; whole loci assigned to ranks by LPT on calls x (reference VNTR length + 201) x expected states; "
+                  "%d calls in total); host model build %.2f s" % (n_loci, total_calls, t_build))
         else:
             metric = ("calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (n_loci, world)
                       if workload == "c3" else
@@ -498,7 +510,7 @@ def main(argv=None):
         out = {
             "metric": metric, "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if workload == "c3" else "weak",
+            "scaling": "strong" if workload in ("c3", "c4") else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": dict({"workload": wl, "states": int(m), "emitting": int(P), "edges": int(E),
                             "calls_this_rank": int(n_reads), "read_len": n, "kernel": kernel,
@@ -549,13 +561,15 @@ def main(argv=None):
                 out["scale_rehearsal"] = out["c2"].pop("scale_rehearsal")
             if upstream_input is not None:
                 out["c4"] = c4_record(_lib, workloads, upstream_input, flags, args)
+                out["c4_scale_rehearsal"] = out["c4"].pop("scale_rehearsal")
                 out["pacbio_end_to_end"] = pacbio_end_to_end_record(_lib, upstream_input, args)
                 out["flank_align"] = flank_align_record(_lib, upstream_input, args)
                 out["prefilter"] = prefilter_record(_lib, upstream_input, args)
-        if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3"):
+        if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3", "c4"):
             out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
                                                      {"calls": int(n_reads), "loop_ms": elapsed / args.steps * 1e3,
-                                                      "kernel_ms": kernel_ms}, flags, max(1, args.steps))
+                                                      "kernel_ms": kernel_ms}, flags, max(1, args.steps),
+                                                     planned_work=work if workload == "c4" else None)
         if workload == "c1" and world == 1 and not args.no_cpu:
             cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
@@ -646,7 +660,7 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     return rec
 
 
-def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps):
+def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps, planned_work=None):
     """What a 1-GPU lease can say about the north star's "strong scaling to 8 GPUs": the C3 locus set partitioned for
     n_ranks ranks exactly as `--gpus N` partitions it (whole loci, LPT on calls x (n+1) x states, sharding.partition_loci), and
     every rank's share run on THIS GPU as its own resident batch with the launch parameters of the multi-GPU job (the slots
@@ -658,9 +672,13 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
     lens = np.diff(off)
     ms = np.array([d.m for d in dms])
     calls = np.bincount(which, minlength=len(dms))
-    work = [int(calls[k]) * 151 * int(ms[k]) for k in range(len(dms))]
+    # planned_work: the per-locus estimates the multi-GPU job partitions by when it cannot know a locus's calls exactly (C4:
+    # workloads.c4_plan); otherwise the plan is exact (C3: calls x 151 x states)
+    work = list(planned_work) if planned_work is not None else [int(calls[k]) * 151 * int(ms[k]) for k in range(len(dms))]
     parts = sharding.partition_loci(work, n_ranks)
     loads = [float(sum(work[int(k)] for k in p)) for p in parts]
+    cells = np.bincount(which, weights=(lens + 1) * ms[which], minlength=len(dms))       # actual work: trellis cells per locus
+    actual = [float(cells[p].sum()) for p in parts]
     uniform = bool(len(lens) and lens.min() == lens.max())
     shares = []
     for r, mine in enumerate(parts):
@@ -692,9 +710,13 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
     return {"projection": True, "ranks": n_ranks, "whole_set": whole, "shares": shares,
             "sum_of_shares_loop_ms": sum(x["loop_ms"] for x in shares), "slowest_share_loop_ms": worst_loop,
             "load_imbalance_max_over_mean": max(loads) / (sum(loads) / n_ranks),
+            "actual_cells_imbalance_max_over_mean": max(actual) / (sum(actual) / n_ranks),
+            "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0),
             "projected_efficiency": whole["loop_ms"] / (n_ranks * worst_loop),
             "projected_efficiency_kernels_only": whole["kernel_ms"] / (n_ranks * worst_kernel),
             "projected_value_calls_per_s": float(len(lens)) / (worst_loop * 1e-3),
+            "partitioned_by": ("estimated work per locus (calls x (reference VNTR length + 201) x expected states, workloads.c4_plan)"
+                               if planned_work is not None else "exact work per locus (calls x 151 x states)"),
             "excludes": "the RCCL gather of the result records (40 B per call to rank 0, queued behind pass i and overlapped with "
                         "pass i + 1) and differences between the GPUs of a node",
             "note": "ONE GPU ran the %d shares one after the other; each share is a rank's whole batch (its models, its calls), "
@@ -921,6 +943,11 @@ def c4_record(_lib, workloads, inp, flags, args):
         rec["roofline"]["bound_actual"] = {"bound": "valu_f64", "valu_insts_per_launch": valu, "cycles_per_inst": 4,
                                            "issue_bound_ms": bound_ms, "kernel_ms": kernel_ms, "frac": bound_ms / kernel_ms,
                                            "source": pmc.get("file")}
+    from advntr_amd import sharding
+    plan = workloads.c4_plan(len(loci), seed=20240603)
+    rec["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
+                                             {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
+                                             planned_work=[c * (ln + 1) * st for c, ln, st in plan])
     if not args.no_cpu:
         from oracle import oracle as Or
         sample = np.linspace(0, len(loci) - 1, 12).astype(int)

@@ -26,6 +26,17 @@ def test_gpus_2_spawns_two_ranks():
     assert sum(cfg["loci_per_rank"]) == 48 and cfg["load_imbalance_max_over_mean"] < 1.05
 
 
+def test_c4_gpus_2_is_one_set_partitioned():
+    """--workload c4 --gpus 2 (BASELINE config 5): ONE PacBio locus set split by the planned work, 20 calls per locus."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "c4",
+                          "--loci", "40"], cwd=ROOT, stdout=subprocess.PIPE, check=True, timeout=300).stdout
+    d = _line(out)
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cfg["workload"] == "c4"
+    assert sum(cfg["loci_per_rank"]) == 40 and sum(cfg["calls_per_rank"]) == 800 == sum(cfg["calls_seen_by_ranks"])
+    assert cfg["load_imbalance_max_over_mean"] < 1.05 and cfg["per_locus_work_max_over_min"] > 3
+
+
 def test_gpus_3_under_torch_distributed_run():
     """The driver's launch line: torch is only the launcher; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",

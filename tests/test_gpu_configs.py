@@ -173,6 +173,41 @@ def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
     assert np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
 
 
+def test_c4_two_ranks_gather_equals_one_rank(tmp_path):
+    """bench.py --workload c4 --gpus 2 (BASELINE config 5 in its sharded form, 60 loci here): ONE PacBio locus set, whole
+    loci to ranks by the planned work, each rank's share scored by the long-read kernel, every call's record gathered to rank
+    0; the result equals the 1-rank run record for record."""
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    common = ["--workload", "c4", "--loci", "60", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    d1 = _bench(common + ["--gpus", "1", "--dump-records", one])
+    d2 = _bench(common + ["--gpus", "2", "--dump-records", two], env=dict(os.environ, ADVNTR_DIST_BACKEND="host"))
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d1["scaling"] == d2["scaling"] == "strong"
+    assert d2["config"]["comm"] == "host" and len(d2["config"]["per_rank"]) == 2
+    assert sum(d2["config"]["calls_per_rank"]) == d1["config"]["calls_this_rank"] == 1200
+    assert sum(r["cells"] for r in d2["config"]["per_rank"]) > 0
+    assert d2["config"]["kernel"].startswith("viterbi_rows_long_kernel")
+    a, b = np.load(one), np.load(two)
+    assert np.array_equal(a["ids"], np.arange(1200)) and np.array_equal(b["ids"], a["ids"])
+    assert np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
+    assert np.all(a["summary"][:, 0] > 0)
+
+
+def test_c4_scale_rehearsal_reports_the_planned_and_the_actual_imbalance():
+    """bench.py --workload c4 --emulate-ranks 4: the shares are the partition `--gpus 4` makes from workloads.c4_plan (whole
+    loci, every call once); the record carries the planned imbalance, the imbalance of the ACTUAL work and the spread of the
+    per-locus work (more than an order of magnitude on this set)."""
+    d = _bench(["--workload", "c4", "--loci", "120", "--steps", "2", "--warmup", "1", "--no-cpu", "--emulate-ranks", "4"])
+    r = d["scale_rehearsal"]
+    assert r["projection"] is True and r["ranks"] == 4 and len(r["shares"]) == 4
+    assert sum(x["calls"] for x in r["shares"]) == 2400 and sum(x["loci"] for x in r["shares"]) == 120
+    assert 1.0 <= r["load_imbalance_max_over_mean"] < 1.05 and 1.0 <= r["actual_cells_imbalance_max_over_mean"] < 1.15
+    assert r["per_locus_work_max_over_min"] > 5 and "c4_plan" in r["partitioned_by"]
+    from advntr_amd import sharding, workloads
+    plan = workloads.c4_plan(120, seed=20240603)
+    parts = sharding.partition_loci([c * (n + 1) * m for c, n, m in plan], 4)
+    assert sorted(x["loci"] for x in r["shares"]) == sorted(len(p) for p in parts)
+
+
 def test_scale_rehearsal_partitions_the_set_like_the_multi_gpu_job():
     """bench.py --workload c3 --emulate-ranks 4 (one process, one GPU): the shares are the LPT partition `--gpus 4` makes --
     whole loci, every call exactly once --, each runs as its own resident batch with the multi-GPU launch parameters, and the

@@ -120,6 +120,32 @@ def test_c3_plan_matches_the_generated_share():
     assert reads2 == reads[:len(reads2)]
 
 
+def test_c4_plan_prices_a_locus_before_its_reads_exist():
+    """bench.py --workload c4 --gpus N: the plan replays the two draws _c4_locus makes first (pattern length, reference VNTR
+    length), so every rank prices every locus without generating a read; the generated share is exactly the planned loci, and
+    the estimate tracks the actual work (trellis cells of the 20 noisy reads on the model sized for the longest) closely
+    enough for the LPT split to balance it."""
+    import numpy as np
+    from advntr_amd import sharding, workloads
+    plan = workloads.c4_plan(48, seed=20240603)
+    assert all(c == 20 for c, _, _ in plan)
+    est = np.array([c * (n + 1) * m for c, n, m in plan], np.float64)
+    parts = sharding.partition_loci(est, 4)
+    assert sorted(int(k) for p in parts for k in p) == list(range(48))
+    loci, reads, which = workloads.make_c4(48, seed=20240603, workers=2)
+    workloads.build_models(loci)
+    lens = np.array([len(r) for r in reads]).reshape(48, 20)
+    actual = (lens + 1).sum(1) * np.array([l.model.n_states for l in loci], np.float64)
+    assert np.all(np.abs(actual / est - 1.0) < 0.25) and np.corrcoef(actual, est)[0, 1] > 0.99
+    loads = [actual[p].sum() for p in parts]
+    assert max(loads) / (sum(loads) / 4) < 1.08
+    mine, reads1, which1 = workloads.make_c4(48, seed=20240603, workers=1, only=parts[1])
+    assert len(mine) == len(parts[1]) and len(reads1) == 20 * len(parts[1])
+    for j, k in enumerate(parts[1]):
+        assert (mine[j].left, mine[j].units, mine[j].copies) == (loci[int(k)].left, loci[int(k)].units, loci[int(k)].copies)
+        assert reads1[20 * j:20 * j + 20] == reads[20 * int(k):20 * int(k) + 20]
+
+
 def _sharded_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
