@@ -11,23 +11,44 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <type_traits>
 
 namespace {
 
 struct RcclApi {
     void *handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
+    // every pointer has the type of the prototype in <rccl/rccl.h> itself (no hand-written copy that could drift from the
+    // header the library was built with: a changed argument list shows up as a compile error at the call sites below)
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&::ncclAllReduce) AllReduce = nullptr;
+    decltype(&::ncclAllGather) AllGather = nullptr;
+    decltype(&::ncclSend) Send = nullptr;
+    decltype(&::ncclRecv) Recv = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
     std::string error;
 };
+
+// what the calls below assume of those prototypes, checked against the header at compile time
+static_assert(std::is_same_v<decltype(&::ncclSend), ncclResult_t (*)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>,
+              "ncclSend(sendbuff, count, datatype, peer, comm, stream)");
+static_assert(std::is_same_v<decltype(&::ncclRecv), ncclResult_t (*)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t)>,
+              "ncclRecv(recvbuff, count, datatype, peer, comm, stream)");
+static_assert(std::is_same_v<decltype(&::ncclAllGather), ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>,
+              "ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream)");
+static_assert(std::is_same_v<decltype(&::ncclAllReduce),
+                             ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>,
+              "ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream)");
+static_assert(std::is_same_v<decltype(&::ncclCommInitRank), ncclResult_t (*)(ncclComm_t *, int, ncclUniqueId, int)>,
+              "ncclCommInitRank(comm, nranks, commId BY VALUE, rank)");
+static_assert(std::is_same_v<decltype(&::ncclGetUniqueId), ncclResult_t (*)(ncclUniqueId *)> &&
+              std::is_same_v<decltype(&::ncclCommDestroy), ncclResult_t (*)(ncclComm_t)> &&
+              std::is_same_v<decltype(&::ncclGetErrorString), const char *(*)(ncclResult_t)> &&
+              std::is_same_v<decltype(&::ncclGroupStart), ncclResult_t (*)()> && std::is_same_v<decltype(&::ncclGroupEnd), ncclResult_t (*)()>,
+              "ncclGetUniqueId / ncclCommDestroy / ncclGetErrorString / ncclGroupStart / ncclGroupEnd");
 
 RcclApi *rccl_api()
 {

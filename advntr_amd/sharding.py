@@ -15,16 +15,21 @@ def locus_work(n_bases_per_read, n_edges):
     return int((np.asarray(n_bases_per_read, dtype=np.int64) + 1).sum() * int(n_edges))
 
 
-def partition_loci(work, world_size):
+def partition_loci(work, world_size, capacity=None):
     """Longest-processing-time greedy: heaviest locus first onto the least loaded rank.  Returns a list of
     index arrays (one per rank); every locus appears exactly once; ties broken by locus index so that
-    every rank computes the same partition without communicating."""
+    every rank computes the same partition without communicating.  capacity (optional, one positive number per rank):
+    rank r's load counts as load / capacity[r] -- the root of the result gather also hosts the receive side of every
+    peer's records, so a job may give it a slightly smaller share (bench.py --root-capacity)."""
     work = np.asarray(work, dtype=np.int64)
+    cap = [1.0] * world_size if capacity is None else [float(c) for c in capacity]
+    if len(cap) != world_size or min(cap) <= 0:
+        raise ValueError("partition_loci: capacity needs one positive number per rank")
     order = sorted(range(len(work)), key=lambda i: (-int(work[i]), i))
     load = [0] * world_size
     parts = [[] for _ in range(world_size)]
     for i in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
+        r = min(range(world_size), key=lambda k: (load[k] / cap[k], k))
         parts[r].append(i)
         load[r] += int(work[i])
     return [np.array(sorted(p), dtype=np.int64) for p in parts]

@@ -713,19 +713,32 @@ def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=1
     bases of its 5-15 kb -- is upper-cased and, for the reverse strand, reverse-complemented on the host."""
     from . import settings
     n_loci = len(flank_pairs)
-    flanks, reads, first = [], [], np.zeros(n_loci + 1, np.int64)
+    # a read that is a candidate of several loci (the same str object in several lists, or one list handed over for every
+    # locus) is encoded and uploaded ONCE; the pairs of every locus index that copy
+    flanks, reads, slot_of, uses, first = [], [], {}, [], np.zeros(n_loci + 1, np.int64)
     for i, ((lf, rf), rl) in enumerate(zip(flank_pairs, read_lists)):
         flanks += [lf[-flanking_region_size:], rf[:flanking_region_size]]
-        reads += [s if isinstance(s, str) else str(s) for s in rl]
-        first[i + 1] = len(reads)
+        for s in rl:
+            u = slot_of.get(id(s))
+            if u is None:
+                u = slot_of[id(s)] = len(reads)
+                reads.append(s if isinstance(s, str) else str(s))
+            uses.append(u)
+        first[i + 1] = len(uses)
     out = [([], []) for _ in range(n_loci)]
-    n = len(reads)
-    if n == 0:
+    n_uses, n = len(uses), len(reads)
+    if n_uses == 0:
         return out
-    read_locus = np.repeat(np.arange(n_loci, dtype=np.int32), np.diff(first))
-    strand_read = np.arange(2 * n, dtype=np.int32) // 2 + (np.arange(2 * n, dtype=np.int32) & 1) * n
+    total_bases = sum(map(len, reads))
+    if 4 * n_uses >= 2 ** 31 or total_bases >= 2 ** 31:
+        raise ValueError("extract_spanning_reads_multi: %d alignments over %d read bases in one call exceed the 32-bit indices of "
+                         "advntr_flank_align; hand the loci over in pieces (genotype_pacbio_loci does)" % (4 * n_uses, total_bases))
+    uses = np.asarray(uses, np.int32)
+    use_locus = np.repeat(np.arange(n_loci, dtype=np.int32), np.diff(first))
+    # per (locus, read) use: forward strand then reverse strand (read index + n), each against the left then the right flank
+    strand_read = np.repeat(uses, 2) + np.tile(np.array([0, n], np.int32), n_uses)
     pair_read = np.repeat(strand_read, 2)
-    pair_flank = (2 * np.repeat(read_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n)).astype(np.int32)
+    pair_flank = (2 * np.repeat(use_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n_uses)).astype(np.int32)
     score, begin, _, _ = _lib.flank_align(reads, flanks, pair_read, pair_flank)
     flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
     need = flen * (1 - settings.MAX_ERROR_RATE)
@@ -734,10 +747,10 @@ def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=1
     hits = np.flatnonzero(ok)
     lbs, rbs = begin[2 * hits].tolist(), begin[2 * hits + 1].tolist()
     for k, lb, rb in zip(hits.tolist(), lbs, rbs):
-        r = k >> 1
-        s = reads[r]
+        r = k >> 1                                   # the (locus, read) use; k & 1 = strand
+        s = reads[int(uses[r])]
         piece = _spanning_piece(s, lb, rb + flanking_region_size, bool(k & 1))
-        i = int(read_locus[r])
+        i = int(use_locus[r])
         spanning, lengths = out[i]
         spanning.append((piece, r - int(first[i]), bool(k & 1)))
         lengths.append(rb - (lb + flanking_region_size))
@@ -762,7 +775,12 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     import time
     from . import hmm_utils
     n_loci = len(loci)
-    chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
+    # a piece's extraction is ONE advntr_flank_align call: at most 2^22 alignments (4 per candidate read and locus; seconds
+    # of kernel time, result arrays of 50 MB), whatever `chunks` asks for -- a locus set whose loci all share one long read
+    # list (every read a candidate of every locus) otherwise overflows the call's 32-bit pair index
+    n_pairs = 4 * sum(len(rl) for rl in read_lists)
+    chunks = max(int(chunks), -(-n_pairs // (1 << 22)))
+    chunks = max(1, min(chunks, n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
     ready = queue.Queue(maxsize=2)
     T = dict(extract_spanning=0.0, build_models=0.0, upload_models=0.0, encode_reads=0.0, score=0.0, genotype=0.0)

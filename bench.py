@@ -74,6 +74,9 @@ def parse_args(argv=None):
                     help="one process, one GPU (--workload c3 or c4): partition the locus set for this many ranks (LPT, as --gpus N does), run every "
                          "rank's share as its own resident batch with the multi-GPU launch parameters and print a "
                          "`scale_rehearsal` record -- a PROJECTION of the strong-scaling line, not a measurement of it")
+    ap.add_argument("--root-capacity", type=float, default=0.99,
+                    help="c3/c4 with more than one rank: rank 0 (the root of the result gather, which also hosts the receive side "
+                         "of every peer's records) gets this fraction of an equal share of the planned work (1.0 = equal shares)")
     ap.add_argument("--no-upstream", action="store_true",
                     help="c1 at --gpus 1: leave out the `c4`, `pacbio_end_to_end`, `prefilter` and `flank_align` sub-records")
     ap.add_argument("--c4-loci", type=int, default=8960, help="loci of the `c4` sub-record (BASELINE config 5)")
@@ -310,13 +313,15 @@ def main(argv=None):
             # (PacBio: what is known of a locus before its reads are extracted -- pattern and reference VNTR length -- prices it)
             plan = workloads.c4_plan(n_loci, seed=20240603)
             work = [calls * (length + 1) * states for calls, length, states in plan]
-        parts = sharding.partition_loci(work, world)
+        capacity = [args.root_capacity] + [1.0] * (world - 1) if world > 1 else None
+        parts = sharding.partition_loci(work, world, capacity)
         mine = parts[rank]
         total_calls = int(sum(p[0] for p in plan))
         loads = [float(sum(work[int(k)] for k in p)) for p in parts]
         plan_info = {"loci_per_rank": [int(len(p)) for p in parts],
                      "calls_per_rank": [int(sum(plan[int(k)][0] for k in p)) for p in parts],
                      "load_imbalance_max_over_mean": max(loads) / (sum(loads) / world),
+                     "root_capacity": capacity[0] if capacity else None, "root_load_over_mean": loads[0] / (sum(loads) / world),
                      "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0)}
     if args.dry_run:
         counts = comm.allgather_i64(plan_info["calls_per_rank"][rank] if plan_info else args.reads) if comm else [args.reads]
@@ -569,7 +574,8 @@ def main(argv=None):
             out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
                                                      {"calls": int(n_reads), "loop_ms": elapsed / args.steps * 1e3,
                                                       "kernel_ms": kernel_ms}, flags, max(1, args.steps),
-                                                     planned_work=work if workload == "c4" else None)
+                                                     planned_work=work if workload == "c4" else None,
+                                                     root_capacity=args.root_capacity)
         if workload == "c1" and world == 1 and not args.no_cpu:
             cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
             assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
@@ -660,7 +666,8 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     return rec
 
 
-def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps, planned_work=None):
+def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps, planned_work=None,
+                    root_capacity=0.99):
     """What a 1-GPU lease can say about the north star's "strong scaling to 8 GPUs": the C3 locus set partitioned for
     n_ranks ranks exactly as `--gpus N` partitions it (whole loci, LPT on calls x (n+1) x states, sharding.partition_loci), and
     every rank's share run on THIS GPU as its own resident batch with the launch parameters of the multi-GPU job (the slots
@@ -675,7 +682,7 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
     # planned_work: the per-locus estimates the multi-GPU job partitions by when it cannot know a locus's calls exactly (C4:
     # workloads.c4_plan); otherwise the plan is exact (C3: calls x 151 x states)
     work = list(planned_work) if planned_work is not None else [int(calls[k]) * 151 * int(ms[k]) for k in range(len(dms))]
-    parts = sharding.partition_loci(work, n_ranks)
+    parts = sharding.partition_loci(work, n_ranks, [root_capacity] + [1.0] * (n_ranks - 1))
     loads = [float(sum(work[int(k)] for k in p)) for p in parts]
     cells = np.bincount(which, weights=(lens + 1) * ms[which], minlength=len(dms))       # actual work: trellis cells per locus
     actual = [float(cells[p].sum()) for p in parts]
@@ -710,6 +717,8 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
     return {"projection": True, "ranks": n_ranks, "whole_set": whole, "shares": shares,
             "sum_of_shares_loop_ms": sum(x["loop_ms"] for x in shares), "slowest_share_loop_ms": worst_loop,
             "load_imbalance_max_over_mean": max(loads) / (sum(loads) / n_ranks),
+            "root_capacity": root_capacity, "root_load_over_mean": loads[0] / (sum(loads) / n_ranks),
+            "root_share_loop_ms_over_slowest": shares[0]["loop_ms"] / worst_loop,
             "actual_cells_imbalance_max_over_mean": max(actual) / (sum(actual) / n_ranks),
             "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0),
             "projected_efficiency": whole["loop_ms"] / (n_ranks * worst_loop),
@@ -811,7 +820,8 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
                        "note": "exact sum over the calls of n + (n+1) m + (n+m) + 32 bytes (SURVEY 8d) / HIP-event kernel time"}}
     from advntr_amd import sharding
     c2["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
-                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps)
+                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
+                                            root_capacity=args.root_capacity)
     if not args.no_cpu:
         # per-locus sample against the oracle: log-probabilities bit for bit, repeat-unit counts as hmm_utils derives them
         # from the oracle's path; its single-thread rate on these models prices the whole set for the reference
@@ -947,7 +957,8 @@ def c4_record(_lib, workloads, inp, flags, args):
     plan = workloads.c4_plan(len(loci), seed=20240603)
     rec["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
                                              {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
-                                             planned_work=[c * (ln + 1) * st for c, ln, st in plan])
+                                             planned_work=[c * (ln + 1) * st for c, ln, st in plan],
+                                             root_capacity=args.root_capacity)
     if not args.no_cpu:
         from oracle import oracle as Or
         sample = np.linspace(0, len(loci) - 1, 12).astype(int)

@@ -296,3 +296,41 @@ def test_pacbio_loci_from_whole_reads_equal_the_per_locus_route():
             assert n_called >= (6 if accuracy else 10)
     finally:
         settings.MAX_ERROR_RATE = 0.05
+
+
+@pytest.mark.gpu
+def test_a_read_list_shared_by_many_loci_is_uploaded_once(monkeypatch):
+    """`python -m advntr_amd genotype --pacbio --extract-spanning` hands the SAME read list to every locus (every read is a
+    candidate of every locus): extract_spanning_reads_multi uploads each distinct read once and lets the pairs of every locus
+    index that copy -- same spanning reads per locus as with private copies of the list, and the flank-alignment call sees
+    len(reads) strings, not len(reads) x loci; genotype_pacbio_loci cuts its pieces by the number of alignments."""
+    from advntr_amd import _lib, settings, vntr_finder, workloads
+    loci, read_lists = workloads.make_pacbio_whole_reads(6, seed=78, n_reads=5, min_len=1500, max_len=3000, workers=1)
+    everything = [r for rl in read_lists for r in rl]                  # 30 reads, each a candidate of all 6 loci
+    pairs = [(l[0], l[1]) for l in loci]
+    seen = []
+    real = _lib.flank_align
+
+    def spy(reads, flanks, pair_read, pair_flank):
+        seen.append((len(reads), len(pair_read)))
+        return real(reads, flanks, pair_read, pair_flank)
+    monkeypatch.setattr(_lib, "flank_align", spy)
+    settings.MAX_ERROR_RATE = 0.3
+    try:
+        shared = vntr_finder.extract_spanning_reads_multi(pairs, [everything] * 6)
+        assert seen[-1] == (30, 4 * 30 * 6)
+        private = vntr_finder.extract_spanning_reads_multi(pairs, [[str(s[:1]) + s[1:] for s in everything] for _ in range(6)])
+        assert seen[-1] == (180, 4 * 30 * 6)
+        assert shared == private
+        for i, (sp, lengths) in enumerate(shared):
+            assert sorted(k for _, k, _ in sp) == list(range(5 * i, 5 * i + 5))[:len(sp)] or len(sp) <= 5
+            assert len(sp) >= 3 and len(lengths) == len(sp)
+        # pieces by alignments: 2 loci x 3 000 000 shared "reads" would be 24 M alignments -> at least 6 pieces
+        calls = []
+        monkeypatch.setattr(vntr_finder, "extract_spanning_reads_multi",
+                            lambda fp, rl, size=100: calls.append(len(fp)) or [([], []) for _ in fp])
+        big = [None] * 3000000
+        res = vntr_finder.genotype_pacbio_loci(loci[:2] * 6, [big] * 12, chunks=1)
+        assert len(res) == 12 and len(calls) >= 9 and all(g.copy_numbers is None for g in res)
+    finally:
+        settings.MAX_ERROR_RATE = 0.05

@@ -87,6 +87,24 @@ def test_partition_is_balanced_and_complete():
         assert max(loads) - min(loads) <= int(work.max())
 
 
+def test_partition_capacity_gives_the_gather_root_a_smaller_share():
+    """partition_loci(work, world, capacity): rank 0 at capacity 0.9 ends with ~0.9 of the others' load; every locus once;
+    capacity None == all ones; bad capacities are refused."""
+    import numpy as np
+    from advntr_amd import sharding
+    rng = np.random.default_rng(4)
+    work = rng.integers(1000, 20000, 4000)
+    parts = sharding.partition_loci(work, 8, [0.9] + [1.0] * 7)
+    assert sorted(int(k) for p in parts for k in p) == list(range(4000))
+    loads = np.array([work[p].sum() for p in parts], np.float64)
+    assert abs(loads[0] / loads[1:].mean() - 0.9) < 0.005 and loads[1:].max() / loads[1:].min() < 1.002
+    same = sharding.partition_loci(work, 8, [1.0] * 8)
+    assert all(np.array_equal(a, b) for a, b in zip(same, sharding.partition_loci(work, 8)))
+    for bad in ([1.0] * 7, [0.0] + [1.0] * 7):
+        with pytest.raises(ValueError):
+            sharding.partition_loci(work, 8, bad)
+
+
 def test_gather_world_size_2_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
