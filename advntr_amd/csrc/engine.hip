@@ -922,9 +922,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.rows_slab_bytes = ((((int64_t)C.rows_depth * C.nc_max + 33) * 64 * 4) + 255) & ~int64_t(255);
                 const int64_t rows_bp = C.rows_slab_bytes * ROWS_PEND_SLABS;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
-                // (+ the tail values of all reads of a sweep, which are finished together: rows_finish.h)
-                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64) + COL_MAX_TAIL +
-                                                                 ROWS_FINISH_MAXQ * COL_MAX_TAIL);
+                // (the captured rows of ROWS_PEND_SLABS sweeps + the tail values of the pending reads: rows_finish.h)
+                C.rows_rown_slab = ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64);
+                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_PEND_SLABS * C.rows_rown_slab + COL_MAX_TAIL + ROWS_PEND_READS * COL_MAX_TAIL);
             }
         }
         // useful share of the row-blocked sweeps' lane-steps: a sweep of `depth` reads per lane group costs depth * NC + (rows of

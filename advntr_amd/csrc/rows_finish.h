@@ -6,14 +6,13 @@
 // vector instructions (scripts/budget_finish.sh, profiles/r05_finish_budget.json).  Here the same work is laid out so that
 // the round trips of different reads are in flight together:
 //
-//   rows_tails   the tail states' maxima of all reads in one pass over the tail edges: an edge record is loaded once and
-//                relaxed against every read's captured row; the chain of dependent tail states is walked once, not per read;
-//   rows_finish_lanes   tracebacks and path summaries DEFERRED until the wavefront has swept 64 reads (their back-pointer slabs
-//                stay in HBM meanwhile), then one read per LANE: every lane walks its own path cell by cell -- the plain
-//                serial traceback of hmm.pyx:2107-2136 on the column layout -- and counts what advntr/hmm_utils.py:155-286
-//                derives from the path as it goes (no second pass, no reversed-path buffer unless paths are asked for).  A step
-//                costs the wavefront ~50 vector instructions for 64 reads instead of ~57 for one gather of one read, and the
-//                ~300 dependent round trips of the longest path are paid once per 64 reads instead of ~28 per read.
+//   rows_finish_lanes   everything after the sweep DEFERRED until the wavefront has swept 64 reads (their back-pointer slabs,
+//                captured last rows and fan-in winners stay in HBM meanwhile), then one read per LANE: every lane evaluates its
+//                read's tail states edge by edge (hmm.pyx:2065-2083 for those states) and walks its own path back through the
+//                trellis -- the plain serial traceback of hmm.pyx:2107-2136 on the column layout, ROWS_WALK_K cells of the
+//                current run fetched per round trip -- counting what advntr/hmm_utils.py:155-286 derives from the path as it
+//                goes (no second pass, no cross-lane reduction, no reversed-path buffer unless paths are asked for).  The
+//                dependent round trips of the longest path are paid once per 64 reads instead of ~28 per read.
 //
 // (A first round-5 version kept the wave-cooperative walk and ran 2, 4 or 8 of them in lock step: bit-exact, and no faster --
 // S300 2.64 / 2.71 / 2.74 ms against 2.64: the scalar state of several walks does not fit the scalar registers next to the
@@ -30,109 +29,44 @@
 #define ROWS_PEND_INTS (ROWS_PEND_READS * 8)                  // their descriptors (RowsPend) and
 #define ROWS_TAILLOC_INTS (ROWS_PEND_READS * COL_MAX_TAIL)    // tail winners, at the end of the wavefront's `aux` scratch
 
-__device__ __forceinline__ double wave_max_f64_raw(double v)
-{
-    // wave_max_f64 without fmax()'s canonicalising self-maxima (no NaN reaches the tail: sums of finite values and -inf)
-    auto mx = [](double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
-    v = mx(v, wave_dpp_f64<0xB1>(v));
-    v = mx(v, wave_dpp_f64<0x4E>(v));
-    v = mx(v, wave_dpp_f64<0x141>(v));
-    v = mx(v, wave_dpp_f64<0x140>(v));
-    v = mx(v, wave_dpp_f64<0x142, 0xA>(v));
-    v = mx(v, wave_dpp_f64<0x143, 0xC>(v));
-    const long long b = __double_as_longlong(v);
-    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) |
-                                (unsigned)__builtin_amdgcn_readlane((int)b, 63));
-}
-
-// Tail states at the last row for NQ reads of one model (col_tail for many reads).  roff[q]: where read q's captured row
-// starts, in doubles from `rown`; tailv_all / tailloc_all: NQ x COL_MAX_TAIL scratch of the wave (tail values; the `loc` of the
-// winning in-edge -- what the traceback needs of it).  logp[q] = value of the model's end state.
-template <int NQ>
-__device__ __forceinline__ void rows_tails(const ColFinishTables &F, const double *__restrict__ rown, const unsigned (&roff)[NQ],
-                                           double *__restrict__ tailv_all, int32_t *__restrict__ tailloc_all, const int lane,
-                                           double (&logp)[NQ])
-{
-    const int n_tail = F.n_tail, end_tail = F.end_tail;
-    int e1 = F.tptr[0];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) logp[q] = -INFINITY;
-    for (int i = 0; i < n_tail; ++i) {
-        const int e0 = e1;
-        e1 = F.tptr[i + 1];
-        double best[NQ];
-        int rank[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { best[q] = -INFINITY; rank[q] = 0x7fffffff; }
-        for (int eb = e0; eb < e1; eb += 64) {
-            const int e = eb + lane;
-            const TailEdge ed = F.edges[min(e, e1 - 1)];
-            const bool in = e < e1, isrow = ed.loc >= 0;
-            const unsigned off_row = (unsigned)(ed.loc >> 2) * 3u + (unsigned)(ed.loc & 3), off_tail = (unsigned)(-ed.loc - 1);
-            double v[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                v[q] = isrow ? rown[roff[q] + off_row] : tailv_all[q * COL_MAX_TAIL + off_tail];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const double cand = v[q] + ed.logp;
-                const bool take = in && cand > best[q];
-                best[q] = take ? cand : best[q];
-                rank[q] = take ? e : rank[q];
-            }
-        }
-        double top[NQ];
-        int first[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            top[q] = wave_max_f64_raw(best[q]);
-            first[q] = wave_min_i32(best[q] == top[q] ? rank[q] : 0x7fffffff);
-        }
-        int loc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) loc[q] = F.edges_u[first[q] != 0x7fffffff ? first[q] : e0].loc;      // (scalar loads, all in flight)
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { tailv_all[q * COL_MAX_TAIL + i] = top[q]; tailloc_all[q * COL_MAX_TAIL + i] = loc[q]; }
-        }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        if (i == end_tail) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) logp[q] = top[q];
-        }
-    }
-}
-
-// One read waiting for its traceback: what the sweep knew about it (32 bytes, written by the lane that held it in the sweep).
+// One read waiting for its finish: what the sweep knew about it (32 bytes, written by the lane that held it in the sweep).
 struct RowsPend {
     int32_t r, n, off_lo, off_hi;     // read index, length, offset of its bases
     int32_t model, nc;                // index into BatchArgs::models, columns of that model
     int32_t key;                      // slab | position in its lane group's back-to-back sweep << 4 | lane group << 8 |
-                                      // fan-in winner block << 12 | present << 24 | has a path (log-probability > -inf) << 25
-    int32_t pad;
+                                      // fan-in winner block << 12 | present << 24
+    int32_t row_off;                  // where its captured last row starts, in doubles from the wavefront's row scratch
 };
 static_assert(sizeof(RowsPend) == 32, "RowsPend is stored as two 16-byte words");
 
-typedef __attribute__((address_space(1))) const int GlobalInt;
+#ifndef ROWS_WALK_K
+#define ROWS_WALK_K 1                 // cells of the current run a lane fetches per round trip (measured: 1 -> S300 2.50 ms, 2 -> 2.52, 4 ->
+                                      // 2.58: at the end of a launch every wavefront walks at once and the masks come from HBM a 128-byte line
+                                      // per cell -- fetching ahead along a run only adds lines)
+#endif
 
-// Deferred finish, one read per lane.  Lane p takes pending read p (slot = sweep * NQ + position in the sweep): its tail chain
-// (the winners rows_tails recorded), then cell by cell back through the trellis along the back-pointer masks of its sweep's
-// slab -- M_c(t) <- (t-1, c-1), I_c(t) <- (t-1, c), b_c(t) <- (t, c-1), a fan-in sink <- the winner the sweep recorded --, then
-// the row-0 silent chain.  Every visited state adds to the lane's summary counters through the per-column class words
-// (ColCls: no dependent lookup by state index), with the running base-pair count of hmm_utils.py:171 read off the row: an
-// emitting state visited in row t is the t-th emitting state of the path.  (Models whose class words do not mark exactly the
-// emitting states as emitting never come here: engine.hip routes them to the anti-diagonal kernel.)
+// Deferred finish, one read per lane.  Lane p takes pending read p (slot = sweep * NQ + position in the sweep):
+//   1. its tail states at the last row, in index order, each the first maximum over its in-edges in the reference's order
+//      (strict '>': the serial loop IS that order); values and the winners' `loc`s go to the lane's 16 scratch slots;
+//   2. the path: the tail chain, then cell by cell back through the trellis along the back-pointer masks of its sweep's slab
+//      -- M_c(t) <- (t-1, c-1), I_c(t) <- (t-1, c), b_c(t) <- (t, c-1), a fan-in sink <- the winner the sweep recorded --,
+//      then the row-0 silent chain.  A path is made of runs (match diagonals, insert columns, delete rows), so a lane fetches
+//      the masks of the next ROWS_WALK_K cells ALONG ITS CURRENT RUN in one round trip and uses as many as the pointers
+//      confirm;
+//   3. every visited state adds to the lane's summary counters through the per-column class words (ColCls: no dependent
+//      lookup by state index), with the running base-pair count of hmm_utils.py:171 read off the row: an emitting state visited
+//      in row t is the t-th emitting state of the path.  (Models whose class words do not mark exactly the emitting states as
+//      emitting never come here: engine.hip routes them to the anti-diagonal kernel.)
 template <int R, int G>
 __device__ __forceinline__ void rows_finish_lanes(const ColArgs &g, const uint32_t flags, const int n_slots,
-                                                  const unsigned *__restrict__ bp_wave, const int32_t *__restrict__ aux_wave,
-                                                  int32_t *__restrict__ rev_wave, const int lane)
+                                                  const unsigned *__restrict__ bp_wave, const double *__restrict__ rown_wave,
+                                                  int32_t *__restrict__ aux_wave, int32_t *__restrict__ rev_wave, const int lane)
 {
-    constexpr int W = 64 / G, WORDS = (R + 4) / 5;
+    constexpr int W = 64 / G, WORDS = (R + 4) / 5, K = ROWS_WALK_K;
     const bool want_summary = g.a.out_summary && !(flags & 4u), want_path = g.a.out_path && (flags & 1u);
-    if (!want_summary && !want_path) return;
     const RowsPend *pend = (const RowsPend *)(aux_wave + (g.aux_stride - ROWS_PEND_INTS - ROWS_TAILLOC_INTS));
-    const int32_t *tailloc = aux_wave + (g.aux_stride - ROWS_TAILLOC_INTS) + lane * COL_MAX_TAIL;
+    int32_t *tailloc = aux_wave + (g.aux_stride - ROWS_TAILLOC_INTS) + lane * COL_MAX_TAIL;
+    double *tailv = (double *)rown_wave + (g.rown_stride - ROWS_PEND_READS * COL_MAX_TAIL) + lane * COL_MAX_TAIL;
     if (lane >= n_slots) return;
     const int4 d0 = ((const int4 *)(pend + lane))[0], d1 = ((const int4 *)(pend + lane))[1];
     const int key = d1.z;
@@ -145,11 +79,38 @@ __device__ __forceinline__ void rows_finish_lanes(const ColArgs &g, const uint32
     const uint8_t *cpb = (const uint8_t *)Mp->cols;
     const ColProgram *cp = (const ColProgram *)cpb;
     const int end_tail = cp->end_tail, n_tail = cp->n_tail;
+    const int32_t *tptr = (const int32_t *)(cpb + cp->off_tail_ptr);
     const int32_t *tstate = (const int32_t *)(cpb + cp->off_tail_state);
+    const TailEdge *edges = (const TailEdge *)(cpb + cp->off_tail_edge);
     const int32_t *pred0 = (const int32_t *)(cpb + cp->off_pred0);
     const ColState *state = (const ColState *)(cpb + cp->off_state);
     const uint2 *colcls = (const uint2 *)(cpb + cp->off_colcls);
     const int slab = key & 15, kq = (key >> 4) & 15, gq = (key >> 8) & 15, sinkblock = (key >> 12) & 0xfff;
+    // ---- 1. tail states
+    double logp = -INFINITY;
+    {
+        const double *row = rown_wave + (unsigned)d1.w;
+        int e1 = tptr[0];
+        for (int i = 0; i < n_tail; ++i) {
+            const int e0 = e1;
+            e1 = tptr[i + 1];
+            double best = -INFINITY;
+            int wloc = 0;
+#pragma unroll 4
+            for (int e = e0; e < e1; ++e) {
+                const TailEdge ed = edges[e];
+                const double v = ed.loc >= 0 ? row[(ed.loc >> 2) * 3 + (ed.loc & 3)] : tailv[-ed.loc - 1];
+                const double cand = v + ed.logp;
+                if (cand > best) { best = cand; wloc = ed.loc; }
+            }
+            tailv[i] = best;
+            tailloc[i] = wloc;
+            __threadfence_block();               // (this lane reads both back: later tail states, the tail chain below)
+            if (i == end_tail) logp = best;
+        }
+    }
+    g.a.out_logp[r] = logp;
+    if (!want_summary && !want_path) return;
     const unsigned *bp = bp_wave + (size_t)slab * (size_t)(g.rows_slab_bytes / 4);
     const int32_t *sinks = aux_wave + COL_MAX_TAIL + (int64_t)slab * g.rows_sink_slab + (int64_t)sinkblock * COL_MAX_SINKS * g.sink_stride;
     int32_t *rev = rev_wave + (int64_t)lane * g.a.path_cap;
@@ -175,9 +136,9 @@ __device__ __forceinline__ void rows_finish_lanes(const ColArgs &g, const uint32
         if ((cls & SC_UNIT_END) && cur_bp >= 3) { ++ends; if (last_end < 0) last_end = cur_bp; first_end = cur_bp; }
     };
     bool failed = false;
-    if ((key >> 25) & 1) {
+    if (logp != -INFINITY) {
         const int len_max = n + m;          // the reference's own path buffer (hmm.pyx:1953): a longer path is refused
-        // ---- tail states (row n); the first one is the model's end state, which the summaries leave out
+        // ---- 2a. tail states (row n); the first one is the model's end state, which the summaries leave out
         int c = 0, slot = 0;
         {
             int ti = end_tail;
@@ -194,41 +155,52 @@ __device__ __forceinline__ void rows_finish_lanes(const ColArgs &g, const uint32
                 break;
             }
         }
-        // ---- the trellis
+        // ---- 2b. the trellis
         int t = n, s0 = -1;
         while (!failed && t >= 1) {
             if (len > len_max) { failed = true; break; }
-            const int tr = t - 1, lp = tr / R, kk = tr - lp * R, ln = lane0 + lp;
+            // the next K cells along the run this cell belongs to: M (t - j, c - j), I (t - j, c), b (t, c - j)
+            const int dt = slot != 2 ? 1 : 0, dc = slot != 0 ? 1 : 0;
             const int grp = slot == 1 ? 0 : (slot == 0 ? 1 : 2);           // masks of a cell in relaxation order: M, I, b
-            const unsigned *cell = bp + ((unsigned)(max(c, 0) + kNC + lp) * (unsigned)(64 * WORDS) + (unsigned)(kk * 12 + grp * 4 + (ln >> 5)));
-            // (written with scalar stores, which do not pass through the vector L1: agent-scope loads go around it)
-            const unsigned aw = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned bw = __hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c = max(c, -1);                              // (column -1 is the dummy in front of the tables; no path goes there)
-            const uint2 cc = colcls[c + 1];              // class words of the column's I, M, b states and its flags
-            if (want_path) rev[len] = slot == 1 ? state[c + 1].sM : (slot == 0 ? state[c + 1].sI : state[c + 1].sB);
-            ++len;
-            if (want_summary) visit(slot == 1 ? (cc.x >> 16) : (slot == 0 ? (cc.x & 0xffffu) : (cc.y & 0xffffu)), t);
-            const unsigned fl = cc.y >> 16;
-            if (slot == 2 && (fl & COL_FLAG_SINK)) {
-                // a fan-in sink: its predecessor is the winner the sweep recorded for this row (a feeder's b cell), not a pointer
-                c = sinks[((fl >> 4) & 15) * g.sink_stride + t] - kNC;
-                continue;
+            unsigned aw[K], bw[K];
+            uint2 cw[K];
+            int lnj[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int tj = max(t - j * dt, 1), cj = max(c - j * dc, 0);
+                const int tr = tj - 1, lp = tr / R, kk = tr - lp * R;
+                lnj[j] = lane0 + lp;
+                const unsigned *cell = bp + ((unsigned)(cj + kNC + lp) * (unsigned)(64 * WORDS) + (unsigned)(kk * 12 + grp * 4 + (lnj[j] >> 5)));
+                // (written with scalar stores, which do not pass through the vector L1: agent-scope loads go around it)
+                aw[j] = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bw[j] = __hip_atomic_load(cell + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cw[j] = colcls[cj + 1];          // class words of the column's I, M, b states and its flags
             }
-            const unsigned a = (aw >> (ln & 31)) & 1u, b = (bw >> (ln & 31)) & 1u;      // a: the 2nd candidate won, b: the last one did
-            if (slot == 1) {                         // M_c(t) <- [I, M (row 1: the entry edge), b](t - 1, c - 1)
-                if (t == 1 && !b && a) { s0 = state[c + 1].sX; t = 0; break; }
-                slot = b ? 2 : (int)a;
-                --t; --c;
-            } else if (slot == 0) {                  // I_c(t) <- [I, M, b](t - 1, c)
-                slot = b ? 2 : (int)a;
-                --t;
-            } else {                                 // b_c(t) <- [I, M, b](t, c - 1)
-                slot = b ? 2 : (int)a;
-                --c;
+            bool on_run = true;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (!on_run || t < 1 || c < 0 || len > len_max) break;
+                if (want_path) rev[len] = slot == 1 ? state[c + 1].sM : (slot == 0 ? state[c + 1].sI : state[c + 1].sB);
+                ++len;
+                if (want_summary) visit(slot == 1 ? (cw[j].x >> 16) : (slot == 0 ? (cw[j].x & 0xffffu) : (cw[j].y & 0xffffu)), t);
+                const unsigned fl = cw[j].y >> 16;
+                if (slot == 2 && (fl & COL_FLAG_SINK)) {
+                    // a fan-in sink: its predecessor is the winner the sweep recorded for this row (a feeder's b cell), not a pointer
+                    c = sinks[((fl >> 4) & 15) * g.sink_stride + t] - kNC;
+                    on_run = false;
+                    break;
+                }
+                const unsigned a = (aw[j] >> (lnj[j] & 31)) & 1u, b = (bw[j] >> (lnj[j] & 31)) & 1u;   // a: the 2nd candidate won, b: the last one did
+                const int from = b ? 2 : (int)a;         // the predecessor's kind: 0 I, 1 M, 2 b
+                if (slot == 1 && t == 1 && from == 1) { s0 = state[c + 1].sX; t = 0; on_run = false; break; }     // row 1: the entry edge
+                t -= dt;
+                c -= dc;
+                on_run = from == slot;
+                slot = from;
             }
+            if (c < 0) failed = true;            // (no path leaves the tables to the left)
         }
-        // ---- row 0: the silent chain back to the model's start state (left out of the summaries like the end state)
+        // ---- 2c. row 0: the silent chain back to the model's start state (left out of the summaries like the end state)
         if (!failed) {
             if (s0 < 0) s0 = state[c + 1].sB;
             while (s0 != start_state) {

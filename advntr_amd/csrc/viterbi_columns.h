@@ -68,6 +68,7 @@ struct ColArgs {
     int32_t rows_depth;      // row-blocked kernels: reads per lane group of the deepest tile (back-to-back sweeps, viterbi_rows.h)
     int32_t rows_sink_slab;  // ... ints of fan-in winners per sweep (a wavefront keeps ROWS_PEND_SLABS sweeps until their deferred finish)
     int64_t rows_slab_bytes; // ... bytes of back-pointer masks per sweep (bp_stride = ROWS_PEND_SLABS of them)
+    int64_t rows_rown_slab;  // ... doubles of captured last rows per sweep
     int32_t fwd_tailw_cap;   // forward_rows_kernel: tail-edge weights (exp of the transition log-probabilities) that fit the LDS
                              // behind the row-0 table; 0: none, the weights are exponentiated per read
     int32_t lds_level;       // which tables of the column program are staged in LDS: 2 = all; 1 = all but the traceback's

@@ -402,50 +402,24 @@ __device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ s
     return w | (unsigned)kc << (3 * R);
 }
 
-// Right after a sweep: the tail states of all of its reads (rows_finish.h: rows_tails), their log-probabilities, and one
-// descriptor per read for the deferred traceback (rows_finish_lanes) -- slot `sw * NQ + q` of the wavefront's pending list.
-// `what`: lane k * G + q holds {read index, length, offset of the bases (lo, hi)} of read k of lane group q (what the sweep
-// stashed); depth = reads per lane group in this sweep, of which the tile may leave the last ones of some groups empty.
+// Right after a sweep: one descriptor per read for the deferred finish (rows_finish.h: rows_finish_lanes) -- slot `sw * NQ + q`
+// of the wavefront's pending list.  `what`: lane k * G + q holds {read index, length, offset of the bases (lo, hi)} of read k
+// of lane group q (what the sweep stashed); depth = reads per lane group in this sweep, of which the tile may leave the last
+// ones of some groups empty.
 template <int R, int G>
-__device__ __forceinline__ void rows_after_sweep(const ColArgs &g, const ColProgram *__restrict__ cp, const int model, const int NC,
-                                                 const int dmax, const int depth, const int jw, const int tile_count, const int4 what,
-                                                 double *__restrict__ rown, const int64_t grp_doubles, int32_t *__restrict__ aux,
-                                                 const int sw, const int lane)
+__device__ __forceinline__ void rows_after_sweep(const ColArgs &g, const int model, const int NC, const int dmax, const int depth,
+                                                 const int jw, const int tile_count, const int4 what, const int64_t grp_doubles,
+                                                 int32_t *__restrict__ aux, const int sw, const int lane)
 {
     constexpr int W = 64 / G, NQ = ROWS_DEPTH * G;
-    const ColFinishTables F = col_finish_tables(cp);
-    // read q = k * G + group: present in this sweep?  Absent ones alias the sweep's first read (always present), so that
-    // every address below is a valid one; what is computed for them is dropped
-    unsigned roff[NQ];
-    unsigned present = 0u;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int k = q / G, gi = q % G;
-        const bool act = k < depth && jw + k * COL_WAVES * G + gi < tile_count;
-        present |= act ? 1u << q : 0u;
-        roff[q] = (unsigned)((act ? gi : 0) * grp_doubles + 3 * (W + (int64_t)(act ? k : 0) * NC));
-    }
-    double *tailv_all = rown + (g.rown_stride - ROWS_FINISH_MAXQ * COL_MAX_TAIL);
-    int32_t *tailloc = aux + (g.aux_stride - ROWS_TAILLOC_INTS) + sw * NQ * COL_MAX_TAIL;
-    double logp[NQ];
-    rows_tails<NQ>(F, rown, roff, tailv_all, tailloc, lane, logp);
-    unsigned has_path = 0u;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) has_path |= logp[q] != -INFINITY ? 1u << q : 0u;
     if (lane < NQ) {
-        double mine = logp[0];
-#pragma unroll
-        for (int q = 1; q < NQ; ++q) mine = lane == q ? logp[q] : mine;
         const int k = lane / G, gi = lane % G;
-        const bool act = (present >> lane) & 1u;
-        if (act) g.a.out_logp[what.x] = mine;
+        const bool act = k < depth && jw + k * COL_WAVES * G + gi < tile_count;
         RowsPend *pend = (RowsPend *)(aux + (g.aux_stride - ROWS_PEND_INTS - ROWS_TAILLOC_INTS)) + (sw * NQ + lane);
-        const int key = sw | k << 4 | gi << 8 | (gi * (dmax + 1) + k) << 12 | (act ? 1 << 24 : 0) | (((has_path >> lane) & 1u) ? 1 << 25 : 0);
+        const int key = sw | k << 4 | gi << 8 | (gi * (dmax + 1) + k) << 12 | (act ? 1 << 24 : 0);
         ((int4 *)pend)[0] = what;
-        ((int4 *)pend)[1] = make_int4(model, NC, key, 0);
+        ((int4 *)pend)[1] = make_int4(model, NC, key, (int)((int64_t)sw * g.rows_rown_slab + gi * grp_doubles + 3 * (W + (int64_t)k * NC)));
     }
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
 }
 
 template <int R, int G>
@@ -544,8 +518,8 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
 #pragma unroll
             for (int q = 0; q < G; ++q) nlast = max(nlast, __builtin_amdgcn_readlane(fn, (depth - 1) * G + q));
             if (lane < ROWS_DEPTH * G) stash[lane] = make_int4(fr, fn, (int)fo, (int)(fo >> 32));
-            const unsigned cap_base = (unsigned)(grp * grp_doubles);
             sw = __builtin_amdgcn_readfirstlane(sw);                        // (wave-uniform; said to the compiler: the slab address is scalar)
+            const unsigned cap_base = (unsigned)((int64_t)sw * g.rows_rown_slab + grp * grp_doubles);
             const unsigned sink_base = (unsigned)(COL_MAX_TAIL + sw * g.rows_sink_slab + grp * (dmax + 1) * COL_MAX_SINKS * g.sink_stride);
             const int s_end = depth * NC - 1 + (max(nlast, 1) - 1) / R;
             rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bp_wave + (size_t)sw * (size_t)(g.rows_slab_bytes / 4), rown, cap_base, aux,
@@ -555,21 +529,25 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             __builtin_amdgcn_wave_barrier();
             int4 what = make_int4(0, 0, 0, 0);
             if (lane < ROWS_DEPTH * G) what = stash[lane];
-            // (ADVNTR_BUDGET_*: builds that leave a piece of the finish phase out -- wrong results, made only by
-            // scripts/budget_finish.sh to price the pieces with SQ_INSTS_VALU; never defined in the shipped library)
+            // (ADVNTR_BUDGET_NO_FINISH: a build without the finish phase -- wrong results, made only by scripts/budget_finish.sh
+            // to price it with SQ_INSTS_VALU; never defined in the shipped library)
 #ifndef ADVNTR_BUDGET_NO_FINISH
-            rows_after_sweep<R, G>(g, cp, cur_model, NC, dmax, depth, jw, tile.count, what, rown, grp_doubles, aux, sw, lane);
+            rows_after_sweep<R, G>(g, cur_model, NC, dmax, depth, jw, tile.count, what, grp_doubles, aux, sw, lane);
             if (++sw == NSW) {
-#ifndef ADVNTR_BUDGET_NO_TRACEBACK
-                rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, aux, rev_wave, lane);
-#endif
+                __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+                rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, rown, aux, rev_wave, lane);
                 sw = 0;
             }
 #endif
         }
     }
-#if !defined(ADVNTR_BUDGET_NO_FINISH) && !defined(ADVNTR_BUDGET_NO_TRACEBACK)
-    if (sw) rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, aux, rev_wave, lane);
+#ifndef ADVNTR_BUDGET_NO_FINISH
+    if (sw) {
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, rown, aux, rev_wave, lane);
+    }
 #endif
 }
 
