@@ -45,6 +45,8 @@ SYMBOLS = {
     "advntr_batch_forward_timed": (ctypes.c_int, [_vp, _i32, _vp]),
     "advntr_batch_fetch": (ctypes.c_int, [_vp, _vp, _vp]),
     "advntr_batch_fetch_paths": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "advntr_batch_recruit": (ctypes.c_int, [_vp, _vp, _i32, _vp]),
+    "advntr_batch_fetch_recruited": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "advntr_batch_result_ptrs": (ctypes.c_int, [_vp, _vp, _vp]),
     "advntr_batch_device_bytes": (_i64, [_vp]),
     "advntr_batch_info": (ctypes.c_int, [_vp, _vp, _i32]),
@@ -614,6 +616,23 @@ class DeviceBatch(object):
         summ = None if (self.flags & FLAG_NO_SUMMARY) else np.zeros((self.n_reads, SUMMARY_INTS), np.int32)
         check(load().advntr_batch_fetch(self._h, ptr(logp), ptr(summ)))
         return logp, summ
+
+    def recruit(self, scaled_scores=None, min_repeat_bp=2):
+        """VNTRFinder's keep / discard rule on the device (advntr_batch_recruit: strand choice, recruit_read, repeat_bp >
+        min_repeat_bp) on the results of the last run(); scaled_scores: one per model (NaN / None / 0: no trained score) or
+        None.  Returns (index of the forward read, logp, summary[8], reversed) of the survivors, in read order."""
+        sc = None
+        if scaled_scores is not None:
+            sc = np.array([np.nan if (s is None or s == 0) else float(s) for s in scaled_scores], np.float64)
+            if len(sc) != len(self.models):
+                raise ValueError("recruit: %d scaled scores for %d models" % (len(sc), len(self.models)))
+        n = ctypes.c_int32(0)
+        check(load().advntr_batch_recruit(self._h, ptr(sc), int(min_repeat_bp), ctypes.byref(n)))
+        k = n.value
+        index, logp = np.zeros(k, np.int32), np.zeros(k, np.float64)
+        summ, rev = np.zeros((k, SUMMARY_INTS), np.int32), np.zeros(k, np.uint8)
+        check(load().advntr_batch_fetch_recruited(self._h, ptr(index), ptr(logp), ptr(summ), ptr(rev)))
+        return index, logp, summ, rev.astype(bool)
 
     def device_bytes(self):
         return int(load().advntr_batch_device_bytes(self._h))

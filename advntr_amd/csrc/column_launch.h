@@ -21,9 +21,6 @@ struct ColumnLaunch {
     bool stream = false;                    // all column reads go through the stream kernel (tiles[0])
     int ring = 2;
     int rows_depth = 1;                     // reads per lane group of the deepest row-blocked tile
-    int32_t rows_sink_slab = 0;             // row-blocked kernels: ints of fan-in winners and bytes of back-pointer masks per sweep
-    int64_t rows_slab_bytes = 0;            // (a wavefront keeps ROWS_PEND_SLABS sweeps until their deferred finish: rows_finish.h)
-    int64_t rows_rown_slab = 0;             // ... and doubles of captured last rows per sweep
     double useful_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // per tile list (row-blocked kernels only): trellis cells of the reads,
     double swept_cells[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};    // and cell slots the sweeps' lane-steps offer (advntr_batch_info)
     int reserve_workgroups = 0;             // resident workgroup slots the NEXT pass leaves unclaimed (a multi-GPU run's result
@@ -88,9 +85,6 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.lds_level = cl.lds_level;
     g.sink_stride = cl.sink_stride;
     g.rows_depth = cl.rows_depth;
-    g.rows_sink_slab = cl.rows_sink_slab;
-    g.rows_slab_bytes = cl.rows_slab_bytes;
-    g.rows_rown_slab = cl.rows_rown_slab;
     const int grid = launch_grid(cl, g.n_tiles);
     const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES;
     if (lds > 48 * 1024)

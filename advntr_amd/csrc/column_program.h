@@ -57,11 +57,6 @@ struct ColState {             // 16 B per column: state indices for the tracebac
     int32_t sI, sM, sB, sX;
 };
 
-struct ColCls {               // 8 B per column (index c + 1 like ColInfo / ColState): the ADVNTR_SC_* class words of the column's
-    uint16_t cI, cM, cB;      // insert-like, match-like and backbone state (0 where the column has none) and the column's
-    uint16_t flags;           // ColInfo::flags -- all a lane of the deferred traceback (rows_finish.h) needs per visited cell
-};
-
 struct TailEdge {             // in-edge of a tail state, reference evaluation order
     int32_t loc;              // >= 0: column*4 + slot (0 I, 1 M, 2 b);  < 0: -(tail index)-1
     int32_t src_state;
@@ -72,8 +67,7 @@ struct TailEdge {             // in-edge of a tail state, reference evaluation o
 struct ColProgram {
     int32_t n_cols, n_tclass, n_eclass, n_tail, n_sinks, end_tail, m, P;
     int32_t off_class, off_emis, off_info, off_state, off_pred0, off_tail_ptr, off_tail_state, off_tail_edge;
-    int32_t off_v0, lds_bytes, off_fwd, off_colcls;   // off_fwd: n_cols x {fwd row-0 value of b_c, fwd entry term of M_c}; off_colcls:
-                                                      // ColCls per column (n_cols + 2), the traceback's class words
+    int32_t off_v0, lds_bytes, off_fwd, pad1;     // off_fwd: n_cols x {fwd row-0 value of b_c, fwd entry term of M_c}
     int32_t off_epair, n_epair, off_pair_of_col, pad2;   // emission pair table (LDS-resident, between emis and info) and the
                                                          // pair class of every column (n_cols + 2 x uint16, read at staging)
 };
@@ -93,7 +87,6 @@ struct ColProgramHost {
     int32_t n_epair = 0;
     std::vector<ColInfo> info;             // n_cols + 2
     std::vector<ColState> state;           // n_cols + 2
-    std::vector<ColCls> colcls;            // n_cols + 2 (fill_colcls: needs the model's class words)
     std::vector<int32_t> pred0;            // per silent state: row-0 predecessor state or -1
     std::vector<double> v0;                // per silent state: row-0 value
     std::vector<int32_t> tail_state, tail_ptr;
@@ -109,20 +102,10 @@ struct ColProgramHost {
         why.clear();
         n_cols = n_sinks = m = P = 0;
         classes.clear(); emis.clear(); epair.clear(); pair_of_col.clear(); n_epair = 0;
-        info.clear(); state.clear(); colcls.clear(); pred0.clear(); v0.clear();
+        info.clear(); state.clear(); pred0.clear(); v0.clear();
         tail_state.clear(); tail_ptr.clear(); tail_edges.clear();
         end_tail = -1;
         fwd.clear(); fv0.clear();
-    }
-
-    // class words per column from the model's per-state ones (sclass: m entries or nullptr = no name information)
-    void fill_colcls(const uint16_t *sclass)
-    {
-        colcls.assign(state.size(), ColCls{0, 0, 0, 0});
-        for (size_t i = 0; i < state.size(); ++i) {
-            auto cls = [&](int32_t st) -> uint16_t { return (sclass && st >= 0 && st < m) ? sclass[st] : (uint16_t)0; };
-            colcls[i] = ColCls{cls(state[i].sI), cls(state[i].sM), cls(state[i].sB), i < info.size() ? info[i].flags : (uint16_t)0};
-        }
     }
 
     size_t lds_bytes() const
@@ -166,7 +149,6 @@ struct ColProgramHost {
         h.off_tail_edge = add(tail_edges.data(), tail_edges.size() * sizeof(TailEdge));
         h.off_fwd = add(fwd.data(), fwd.size() * sizeof(double));
         h.off_pair_of_col = add(pair_of_col.data(), pair_of_col.size() * sizeof(uint16_t));
-        h.off_colcls = add(colcls.data(), colcls.size() * sizeof(ColCls));
         memcpy(out.data(), &h, sizeof h);
     }
 };

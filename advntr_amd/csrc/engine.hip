@@ -208,7 +208,6 @@ struct advntr_hmm {
     std::shared_ptr<const mb::Built> built;               // ... or the builder's result they point into
     bool has_class = false;
     ColProgramSummary colprog;    // valid = false when the model is not a recognised read matcher
-    bool rows_classes_ok = true;   // class words usable by the row-blocked kernels' deferred traceback (advntr_hmm_create)
     int32_t col_lds_bytes = 0;     // LDS-resident tables of the column program: classes, emissions, column info, states
     int32_t col_lds_core = 0;      // ... without the state table (only the traceback reads it)
     int32_t col_lds_min = 0;       // ... without the column-info table either (the sweep indexes a padded copy of it)
@@ -399,21 +398,6 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
     // (they end up in the blob), only the summary stays with the model
     static thread_local ColProgramHost prog;
     build_column_program(*H, prog);
-    if (prog.valid) prog.fill_colcls(H->sclass.p);
-    // The deferred traceback of the row-blocked kernels (rows_finish.h) reads the running base-pair count of
-    // hmm_utils.py:171 off the trellis row, which is right when the class words mark exactly the emitting states as emitting
-    // (what advntr's names do) or say nothing at all; any other class words keep the model's reads on the kernels that count
-    // along the path
-    H->rows_classes_ok = true;
-    {
-        bool any = false, consistent = true;
-        for (int i = 0; i < m; ++i) {
-            const uint16_t c = H->sclass.p[i];
-            any = any || c != 0;
-            if (((c & ADVNTR_SC_EMIT) != 0) != (i < silent_start)) consistent = false;
-        }
-        H->rows_classes_ok = !any || consistent;
-    }
     H->colprog.valid = prog.valid;
     H->colprog.n_cols = prog.n_cols;
     H->colprog.why = prog.why;
@@ -588,6 +572,11 @@ struct advntr_batch {
     int64_t *d_path_off = nullptr;
     uint8_t *d_bp_gen = nullptr;
     int32_t *d_pathbuf_gen = nullptr, *d_pathbuf_col = nullptr;
+    // advntr_batch_recruit (abi_recruit.h): per-read choice, per-wavefront counts, the survivors' records
+    uint8_t *d_rec_choice = nullptr, *d_rec_reversed = nullptr;
+    int32_t *d_rec_count = nullptr, *d_rec_index = nullptr, *d_rec_summary = nullptr;
+    double *d_rec_scaled = nullptr, *d_rec_logp = nullptr;
+    int32_t n_recruited = 0;
     int32_t *d_counter = nullptr;       // [0]: generic dequeue head, [3..8]: tile heads of the column kernels' lists
     int32_t path_cap = 0;
     int device = 0;
@@ -733,7 +722,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         const int64_t n = read_off[r + 1] - read_off[r];
         // (the row-blocked sweep reaches class and emission records through 16-bit LDS addresses: a model whose two tables
         // pass 64 KiB keeps its reads on the anti-diagonal kernel, which has a range-checked sweep for that case)
-        if (use_rows && rows_len(n) && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000 && B->models[read_model[r]]->rows_classes_ok) {
+        if (use_rows && rows_len(n) && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) {
             int cfg = 0;
             while (cfg + 1 < ROWS_CONFIGS && n <= rows_configs[cfg + 1].max_read) ++cfg;       // the tightest fit
             return cfg;
@@ -918,13 +907,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 C.rown_stride = std::max<int64_t>(C.rown_stride, 2 * (3 * ((int64_t)C.nc_max + 128) + COL_MAX_TAIL));
             }
             if (rows_groups > 1) {            // row-blocked kernels: G reads per wave side by side, ROWS_DEPTH one behind the other; six 64-bit lane masks per cell of a step (256 B per step at R <= 5)
-                // ... and ROWS_PEND_SLABS sweeps' worth of them per wavefront: tracebacks are deferred until 64 reads have been swept
-                C.rows_slab_bytes = ((((int64_t)C.rows_depth * C.nc_max + 33) * 64 * 4) + 255) & ~int64_t(255);
-                const int64_t rows_bp = C.rows_slab_bytes * ROWS_PEND_SLABS;
+                const int64_t rows_bp = ((int64_t)C.rows_depth * C.nc_max + 33) * 64 * 4;
                 C.bp_stride = (std::max(C.bp_stride, rows_bp) + 255) & ~int64_t(255);
-                // (the captured rows of ROWS_PEND_SLABS sweeps + the tail values of the pending reads: rows_finish.h)
-                C.rows_rown_slab = ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64);
-                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_PEND_SLABS * C.rows_rown_slab + COL_MAX_TAIL + ROWS_PEND_READS * COL_MAX_TAIL);
+                C.rown_stride = std::max<int64_t>(C.rown_stride, ROWS_MAX_GROUPS * 3 * ((int64_t)C.rows_depth * C.nc_max + 64) + COL_MAX_TAIL);
             }
         }
         // useful share of the row-blocked sweeps' lane-steps: a sweep of `depth` reads per lane group costs depth * NC + (rows of
@@ -973,17 +958,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             return fail(ADVNTR_ERR_TOO_LARGE, "batch: the back-pointers of its longest read (%d bases on a %d-column model) take "
                         "%lld B per wavefront, %lld B for one workgroup; %lld B of device memory can be had", n_max_col, C.nc_max,
                         (long long)C.bp_stride, (long long)COL_WAVES * C.bp_stride, (long long)bp_budget);
-        // fan-in winners: one block per read of a sweep (+ a spare one per lane group); the row-blocked kernels keep ROWS_PEND_SLABS
-        // sweeps of them, and at the end of the region the descriptors and tail winners of their pending reads (rows_finish.h)
-        C.rows_sink_slab = rows_groups > 1 ? (int32_t)(rows_groups * (C.rows_depth + 1) * COL_MAX_SINKS * C.sink_stride) : 0;
-        C.aux_stride = rows_groups > 1 ? COL_MAX_TAIL + (int64_t)ROWS_PEND_SLABS * C.rows_sink_slab + ROWS_PEND_INTS + ROWS_TAILLOC_INTS
-                                       : COL_MAX_TAIL + (int64_t)COL_MAX_SINKS * C.sink_stride;
+        C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * (rows_groups > 1 ? C.rows_depth + 1 : 1) * COL_MAX_SINKS * C.sink_stride;
         const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
-        // (the row-blocked kernels finish 64 reads together, one per lane: when paths are asked for, a reversed-path buffer each)
-        if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap * ((rows_groups > 1 && (flags & ADVNTR_FLAG_PATH)) ? ROWS_PEND_READS : 1)))) return rc;
+        if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
         for (int k = 0; k < 9; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
@@ -1371,5 +1351,6 @@ extern "C" int advntr_batch_forward_timed(advntr_batch *B, int32_t iters, float 
 #include "abi_keyword_filter.h"
 #include "abi_model_builder.h"
 #include "abi_flank_align.h"
+#include "abi_recruit.h"
 #include "abi_comm.h"
 #include "abi_genotype.h"

@@ -66,9 +66,6 @@ struct ColArgs {
     int32_t sink_stride;     // ints per fan-in state in the sink back-pointer array (n_max + 1)
     int32_t ring;            // stream kernel: back-pointer slabs per wave (row tiles kept for the traceback)
     int32_t rows_depth;      // row-blocked kernels: reads per lane group of the deepest tile (back-to-back sweeps, viterbi_rows.h)
-    int32_t rows_sink_slab;  // ... ints of fan-in winners per sweep (a wavefront keeps ROWS_PEND_SLABS sweeps until their deferred finish)
-    int64_t rows_slab_bytes; // ... bytes of back-pointer masks per sweep (bp_stride = ROWS_PEND_SLABS of them)
-    int64_t rows_rown_slab;  // ... doubles of captured last rows per sweep
     int32_t fwd_tailw_cap;   // forward_rows_kernel: tail-edge weights (exp of the transition log-probabilities) that fit the LDS
                              // behind the row-0 table; 0: none, the weights are exponentiated per read
     int32_t lds_level;       // which tables of the column program are staged in LDS: 2 = all; 1 = all but the traceback's
@@ -176,8 +173,6 @@ struct LdsTables {
     const double *emis;
     const ColInfo *info0;     // original table, index c + 1 (LDS or, for wide models, the model blob in HBM/L2)
     const ColState *state;
-    unsigned info_lds, state_lds;     // LDS byte addresses of those two tables, 0 when the table stayed in HBM/L2 (lds_level): through
-                                      // the generic pointers every access is a FLAT load, which waits for both memory counters
 };
 
 template <int K>
@@ -735,8 +730,6 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
     L.pinfo = 0;
     L.state = lds_level >= 2 ? (const ColState *)(tables + (cp->off_state - cp->off_class))
                              : (const ColState *)((const uint8_t *)cp + cp->off_state);
-    L.info_lds = lds_level >= 1 ? lds_addr(tables + (cp->off_info - cp->off_class)) : 0u;
-    L.state_lds = lds_level >= 2 ? lds_addr(tables + (cp->off_state - cp->off_class)) : 0u;
     // (the 16-bit address fields need the class and emission tables below 64 KiB of LDS)
     const bool padded = (size_t)staged + (size_t)(cp->n_cols + 128 * K) * sizeof(ColInfo) <= (size_t)lds_tables &&
                         L.epair_base + (unsigned)COL_EPAIR_SYMBOLS * L.epair_sym_stride <= 0x10000u;

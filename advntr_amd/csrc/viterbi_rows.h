@@ -64,8 +64,6 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
                                      // tile runs with as few rows per lane as cover it: viterbi_rows_long_kernel)
 #endif
 
-#include "rows_finish.h"
-
 template <int G>
 __device__ __forceinline__ int rows_shr1(const int old, const int src)
 {
@@ -402,24 +400,41 @@ __device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ s
     return w | (unsigned)kc << (3 * R);
 }
 
-// Right after a sweep: one descriptor per read for the deferred finish (rows_finish.h: rows_finish_lanes) -- slot `sw * NQ + q`
-// of the wavefront's pending list.  `what`: lane k * G + q holds {read index, length, offset of the bases (lo, hi)} of read k
-// of lane group q (what the sweep stashed); depth = reads per lane group in this sweep, of which the tile may leave the last
-// ones of some groups empty.
-template <int R, int G>
-__device__ __forceinline__ void rows_after_sweep(const ColArgs &g, const int model, const int NC, const int dmax, const int depth,
-                                                 const int jw, const int tile_count, const int4 what, const int64_t grp_doubles,
-                                                 int32_t *__restrict__ aux, const int sw, const int lane)
+// tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group; col0 = the steps
+// the read's sweep began after (k * NC for the kth read of a back-to-back sweep)
+template <int R>
+__device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
+                                                 const LdsTables &L, const DevModel &M, const int r,
+                                                 const uint8_t *__restrict__ seq, const int n, double *final_row,
+                                                 double *tailv, const unsigned *__restrict__ bpw, const int lane0,
+                                                 int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
+                                                 int32_t *__restrict__ rev, const int lane, const int col0)
 {
-    constexpr int W = 64 / G, NQ = ROWS_DEPTH * G;
-    if (lane < NQ) {
-        const int k = lane / G, gi = lane % G;
-        const bool act = k < depth && jw + k * COL_WAVES * G + gi < tile_count;
-        RowsPend *pend = (RowsPend *)(aux + (g.aux_stride - ROWS_PEND_INTS - ROWS_TAILLOC_INTS)) + (sw * NQ + lane);
-        const int key = sw | k << 4 | gi << 8 | (gi * (dmax + 1) + k) << 12 | (act ? 1 << 24 : 0);
-        ((int4 *)pend)[0] = what;
-        ((int4 *)pend)[1] = make_int4(model, NC, key, (int)((int64_t)sw * g.rows_rown_slab + gi * grp_doubles + 3 * (W + (int64_t)k * NC)));
+    const int NC = cp->n_cols;
+    // (ADVNTR_BUDGET_*: builds that leave one piece of the finish phase out -- wrong results, made only by scripts/budget_finish.sh
+    // to price the pieces with SQ_INSTS_VALU; never defined in the shipped library)
+#ifdef ADVNTR_BUDGET_NO_TAIL
+    const double logp = final_row[3 * (NC - 1) + 2];
+#else
+    const double logp = col_tail(cp, final_row, tailwin, NC, lane, tailv);
+#endif
+    if (lane == 0) g.a.out_logp[r] = logp;
+    int len = 0;
+#ifndef ADVNTR_BUDGET_NO_TRACEBACK
+    if (logp != -INFINITY) {
+        auto bp_at = [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); };
+        len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
+                                 1 << 30, col0);
+        len = __builtin_amdgcn_readfirstlane(len);
     }
+#endif
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+#ifdef ADVNTR_BUDGET_NO_SUMMARY
+    if (lane == 0 && g.a.out_summary) g.a.out_summary[(int64_t)r * 8 + 7] = len;
+#else
+    col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
+#endif
 }
 
 template <int R, int G>
@@ -427,7 +442,7 @@ __global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
 viterbi_rows_kernel(ColArgs g, uint32_t flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int W = 64 / G;
+    constexpr int W = 64 / G, WORDS = (R + 4) / 5;
     static_assert(3 * (3 * R + 3) <= 64 && ROWS_DEPTH <= 4, "queued reads of a lane: one 64-bit register");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -437,16 +452,12 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
     // behind the tables: what the reads of a wavefront's sweep are (index, length, offset of the bases), kept out of the
     // registers while the sweep runs
     int4 *stash = (int4 *)(lds + 16 + g.lds_tables) + wave * (ROWS_DEPTH * ROWS_MAX_GROUPS);
-    unsigned *bp_wave = (unsigned *)(g.bp + gw * g.bp_stride);          // ROWS_PEND_SLABS slabs of g.rows_slab_bytes
+    unsigned *bpw = (unsigned *)(g.bp + gw * g.bp_stride);
     double *rown = g.rown + gw * g.rown_stride;
     int32_t *aux = g.aux + gw * g.aux_stride;
-    int32_t *rev_wave = g.a.path_scratch + gw * (int64_t)ROWS_PEND_READS * g.a.path_cap;     // (only when paths are asked for)
+    int32_t *tailwin = aux;
+    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
     const int grp = lane / W, lp = lane - grp * W;
-    // Tracebacks are deferred: a sweep leaves its back-pointers in slab `sw` and its reads on the pending list; when the list is
-    // full (64 reads = NSW sweeps) -- or the work has run out -- they are finished together, one read per lane (rows_finish.h)
-    constexpr int NQ = ROWS_DEPTH * G, NSW = ROWS_PEND_READS / NQ;
-    static_assert(NSW <= ROWS_PEND_SLABS && NSW <= 16, "slabs per wavefront");
-    int sw = 0;
     int cur_model = -1;
     bool padded = false;
     LdsTables L{};
@@ -467,9 +478,10 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
         }
         const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
         // per lane group: the row-n values of its reads one behind the other (padded by W columns either side: lanes run
-        // ahead of and past their reads); the tail values of the sweep's reads sit at the end of the wave's row scratch
+        // ahead of and past their reads); the tail values of the read being finished sit behind the groups
         const int dmax = NC >= ROWS_STREAM_MIN_COLS ? g.rows_depth : 1;       // (the deepest tile of the launch: the scratch is laid out for it)
         const int64_t grp_doubles = 3 * ((int64_t)dmax * NC + 2 * W);
+        double *tailv = rown + G * grp_doubles;
         // a round: every wavefront takes up to dmax reads per lane group; read (k, group) of wave w is the tile's read
         // j0 + (k * COL_WAVES + w) * G + group
         for (int j0 = 0; j0 < tile.count; j0 += COL_WAVES * G * dmax) {
@@ -518,39 +530,33 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
 #pragma unroll
             for (int q = 0; q < G; ++q) nlast = max(nlast, __builtin_amdgcn_readlane(fn, (depth - 1) * G + q));
             if (lane < ROWS_DEPTH * G) stash[lane] = make_int4(fr, fn, (int)fo, (int)(fo >> 32));
-            sw = __builtin_amdgcn_readfirstlane(sw);                        // (wave-uniform; said to the compiler: the slab address is scalar)
-            const unsigned cap_base = (unsigned)((int64_t)sw * g.rows_rown_slab + grp * grp_doubles);
-            const unsigned sink_base = (unsigned)(COL_MAX_TAIL + sw * g.rows_sink_slab + grp * (dmax + 1) * COL_MAX_SINKS * g.sink_stride);
+            const unsigned cap_base = (unsigned)(grp * grp_doubles);
+            const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * (dmax + 1) * COL_MAX_SINKS * g.sink_stride);
             const int s_end = depth * NC - 1 + (max(nlast, 1) - 1) / R;
-            rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bp_wave + (size_t)sw * (size_t)(g.rows_slab_bytes / 4), rown, cap_base, aux,
-                             sink_base, g.sink_stride, 0, nullptr, queue, depth);
+            rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride, 0, nullptr,
+                             queue, depth);
             rows_bp_publish();
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
             int4 what = make_int4(0, 0, 0, 0);
             if (lane < ROWS_DEPTH * G) what = stash[lane];
-            // (ADVNTR_BUDGET_NO_FINISH: a build without the finish phase -- wrong results, made only by scripts/budget_finish.sh
-            // to price it with SQ_INSTS_VALU; never defined in the shipped library)
-#ifndef ADVNTR_BUDGET_NO_FINISH
-            rows_after_sweep<R, G>(g, cur_model, NC, dmax, depth, jw, tile.count, what, grp_doubles, aux, sw, lane);
-            if (++sw == NSW) {
-                __threadfence_block();
-                __builtin_amdgcn_wave_barrier();
-                rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, rown, aux, rev_wave, lane);
-                sw = 0;
+#pragma unroll 1
+            for (int k = 0; k < depth; ++k) {
+#pragma unroll 1
+                for (int q = 0; q < G; ++q) {
+                    if (jw + k * COL_WAVES * G + q >= tile.count) break;
+                    const int src = k * G + q;
+                    const int rq = __builtin_amdgcn_readlane(what.x, src), nq = __builtin_amdgcn_readlane(what.y, src);
+                    const uint8_t *sq = g.a.bases + (((long long)__builtin_amdgcn_readlane(what.w, src) << 32) |
+                                                     (unsigned)__builtin_amdgcn_readlane(what.z, src));
+                    rows_finish_read<R>(g, flags, cp, L, M, rq, sq, nq, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv,
+                                        bpw + (int64_t)k * NC * (64 * WORDS), q * W, tailwin,
+                                        aux + COL_MAX_TAIL + (int64_t)(q * (dmax + 1) + k) * COL_MAX_SINKS * g.sink_stride, rev, lane, k * NC);
+                }
             }
-#endif
         }
     }
-#ifndef ADVNTR_BUDGET_NO_FINISH
-    if (sw) {
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        rows_finish_lanes<R, G>(g, flags, sw * NQ, bp_wave, rown, aux, rev_wave, lane);
-    }
-#endif
 }
-
 
 // Reads longer than the single-sweep kernels take (156 bases up to COL_MAX_LONG_READ), one per wavefront, in row tiles of
 // 64 R rows: the last row of a tile ("seam", in the per-wave row buffers, ping-pong) is what the next tile's first lane

@@ -190,6 +190,23 @@ def _score_prepared(models, prep, scaled_scores=None, compute_reverse=True):
                 recruited=recruit_mask(logp, summ, lens, min_scores))
 
 
+def _select_prepared(models, prep, scaled_scores=None, compute_reverse=True, min_repeat_bp=2):
+    """_score_prepared followed by the selection of process_unmapped_read (vntr_finder.py:246-254: recruit_read, then more
+    than min_repeat_bp repeat bases), with strand choice, recruit rule and selection applied ON THE DEVICE
+    (advntr_batch_recruit): only the selected reads' records come back, in read order.  Returns (position in the prepared
+    read list, locus, summary[8], reversed) of the selected reads -- what _score_prepared + recruit_mask select."""
+    if prep is None:
+        return (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, _lib.SUMMARY_INTS), np.int32), np.zeros(0, bool))
+    batch = _lib.DeviceBatch(device_models(models), prep["bases"], prep["off"], prep["locus"],
+                             flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
+    try:
+        batch.run()
+        index, _, summ, rev = batch.recruit(scaled_scores, min_repeat_bp)
+    finally:
+        batch.close()
+    return index, prep["locus"][index], summ, rev
+
+
 def score_reads_arrays(models, read_lists, scaled_scores=None, compute_reverse=True):
     """score_reads_multi without a Python object per read, for genome-scale runs: returns a dict of arrays over all
     kept reads (reads holding 'N' are dropped): locus, index (position in read_lists[locus]), logp, summary,
@@ -219,69 +236,127 @@ def genotype_loci(models, read_lists, scaled_scores=None, accuracy_filter=False,
     return _genotypes_from_scores(res, len(models), accuracy_filter, is_haploid, threads)
 
 
+class _Stage(object):
+    """One stage of a host pipeline: a thread that takes one item from each input queue per piece, applies fn and puts the
+    result on its output queue (bounded: a stage runs at most two pieces ahead of its consumer).  A failure travels downstream
+    as the exception object and ends every stage it passes; `abort` (set by the consumer when it gives up) ends the rest."""
+
+    def __init__(self, name, fn, n_pieces, inputs, abort, timer=None):
+        import queue
+        import threading
+        self.out = queue.Queue(maxsize=2)
+        self._fn, self._n, self._inputs, self._abort, self._timer = fn, n_pieces, inputs, abort, timer
+        self.thread = threading.Thread(target=self._run, name=name)
+        self.thread.start()
+
+    def _get(self, q):
+        import queue
+        while not self._abort.is_set():
+            try:
+                return q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        raise _Aborted()
+
+    def _put(self, item):
+        import queue
+        while not self._abort.is_set():
+            try:
+                return self.out.put(item, timeout=0.05)
+            except queue.Full:
+                pass
+        raise _Aborted()
+
+    def _run(self):
+        import time
+        try:
+            for k in range(self._n):
+                args = [self._get(q.out) for q in self._inputs]
+                for a in args:
+                    if isinstance(a, BaseException):
+                        self._put(a)
+                        return
+                t = time.perf_counter()
+                res = self._fn(k, *args)
+                if self._timer is not None:
+                    self._timer[0][self._timer[1]] += time.perf_counter() - t
+                self._put(res)
+        except _Aborted:
+            pass
+        except BaseException as e:                  # handed to the consumer: a failure must not leave it waiting
+            try:
+                self._put(e)
+            except _Aborted:
+                pass
+
+
+class _Aborted(Exception):
+    pass
+
+
 def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False,
                             compute_reverse=True, chunks=8, threads=0, timings=None):
     """genotype_loci from the locus DESCRIPTIONS -- loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...], what
     the reference turns into a model per locus inside its serial loop (genome_analyzer.py:280-297 -> vntr_finder.py:117-138) --
-    with the host stages overlapped with the device's: the locus set is cut into `chunks` pieces; a preparation thread builds
-    the models of piece k + 1 (native builder, host threads), uploads them and encodes the piece's reads while the calling
-    thread has piece k scored (both strands, one engine batch) and applies the strand choice and the recruit rule.  The
-    per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results as
-    genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage."""
-    import queue
+    with the host stages overlapped with the device's.  The locus set is cut into `chunks` pieces that flow through a
+    pipeline of host threads: build the models of a piece (native builder, host threads) -> upload them; encode the piece's
+    reads; -> bind reads and models into a device batch (routing, tile lists, upload); the calling thread only launches a
+    piece's kernels (both strands, reverse complements made on the device) and has the reads selected on the device (strand
+    choice, recruit rule, more than two repeat bases: advntr_batch_recruit), so that only the selected reads' records come
+    back.  The per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results
+    as genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage."""
     import threading
     import time
     from . import hmm_utils
     n_loci = len(loci)
     chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
-    ready = queue.Queue(maxsize=2)               # (piece, models, prepared reads) waiting for the device
-    T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, score_recruit=0.0, aggregate_genotype=0.0)
+    T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, bind_batch=0.0, score_recruit=0.0, aggregate_genotype=0.0)
+    abort = threading.Event()
 
-    def prepare():
-        try:
-            for k in range(chunks):
-                lo, hi = cuts[k], cuts[k + 1]
-                t = time.perf_counter()
-                models = hmm_utils.build_read_matcher_models(loci[lo:hi], threads=threads)
-                T["build_models"] += time.perf_counter() - t
-                t = time.perf_counter()
-                device_models(models)
-                T["upload_models"] += time.perf_counter() - t
-                t = time.perf_counter()
-                prep = _prepare_reads(read_lists[lo:hi])
-                T["encode_reads"] += time.perf_counter() - t
-                ready.put((k, models, prep))
-        except BaseException as e:                  # handed to the consumer: a failure must not leave it waiting
-            ready.put(e)
+    def upload(k, models):
+        device_models(models)
+        return models
+
+    def bind(k, models, prep):
+        if prep is None:
+            return models, None, None
+        return models, prep, _lib.DeviceBatch(device_models(models), prep["bases"], prep["off"], prep["locus"],
+                                              flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
 
     t0 = time.perf_counter()
-    worker = threading.Thread(target=prepare, name="advntr-prepare")
-    worker.start()
+    built = _Stage("advntr-build", lambda k: hmm_utils.build_read_matcher_models(loci[cuts[k]:cuts[k + 1]], threads=threads),
+                   chunks, [], abort, (T, "build_models"))
+    uploaded = _Stage("advntr-upload", upload, chunks, [built], abort, (T, "upload_models"))
+    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]]),), chunks, [], abort, (T, "encode_reads"))
+    bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
+    stages = [built, uploaded, encoded, bound]
     parts = []
     try:
-        for _ in range(chunks):
-            item = ready.get()
+        for k in range(chunks):
+            item = bound.out.get()
             if isinstance(item, BaseException):
                 raise item
-            k, models, prep = item
+            models, prep, batch = item
             t = time.perf_counter()
-            res = _score_prepared(models, prep, None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]],
-                                  compute_reverse)
-            keep = res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)
-            parts.append((res["locus"][keep].astype(np.int64) + cuts[k], res["summary"][keep]))
+            if batch is not None:
+                try:
+                    batch.run()
+                    index, _, summ, _ = batch.recruit(None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]], 2)
+                finally:
+                    batch.close()
+                parts.append((prep["locus"][index].astype(np.int64) + cuts[k], summ))
             T["score_recruit"] += time.perf_counter() - t
-            del models, prep, res                   # the piece's models leave the device with their last reference
-    except BaseException:
-        # the preparation thread would block on the full queue once nobody takes from it: drain until it is through
-        while worker.is_alive():
-            try:
-                ready.get(timeout=0.05)
-            except queue.Empty:
-                pass
-        raise
+            del models, prep, batch, item           # the piece's models leave the device with their last reference
     finally:
-        worker.join()
+        abort.set()                                 # (no stage is left waiting on a queue nobody serves any more)
+        for st in stages:
+            st.thread.join()
+        # batches bound but never run (a failure upstream of them): release their device memory now
+        while not bound.out.empty():
+            left = bound.out.get_nowait()
+            if isinstance(left, tuple) and left[2] is not None:
+                left[2].close()
     t = time.perf_counter()
     locus = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
     summ = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, _lib.SUMMARY_INTS), np.int32)

@@ -143,6 +143,17 @@ int advntr_batch_forward_timed(advntr_batch *batch, int32_t iters, float *ms_per
 int advntr_batch_fetch(advntr_batch *batch, double *out_logp, int32_t *out_summary);
 int advntr_batch_fetch_paths(advntr_batch *batch, int32_t *out_path, const int64_t *out_path_off,
                              int32_t *out_path_len);
+/* The callers' keep / discard rule on the results as they are in HBM after advntr_batch_run -- what VNTRFinder does with
+ * every scored read (vntr_finder.py): the strand with the larger log-probability (process_unmapped_read :242-246: the reverse
+ * one iff logp < rev_logp; only with ADVNTR_FLAG_BOTH_STRANDS), recruit_read (:179-190: flank match rate >= 0.9, then
+ * logp > scaled_score[model] * read_length for a locus with a trained score -- scaled_score NULL, NaN or 0: none,
+ * get_min_score_to_select_a_read :174-177 -- else matches >= 0.9 * read_length and logp > -read_length), and
+ * repeat_bp > min_repeat_bp (:251).  n_keep = survivors; fetch_recruited returns them IN READ ORDER: index of the (forward)
+ * read, log-probability and summary record of the chosen strand, 1 where that strand is the reverse one (any output may be
+ * NULL).  Only the survivors' records cross PCIe.                                                                          */
+int advntr_batch_recruit(advntr_batch *batch, const double *scaled_score, int32_t min_repeat_bp, int32_t *n_keep);
+int advntr_batch_fetch_recruited(advntr_batch *batch, int32_t *out_index, double *out_logp, int32_t *out_summary,
+                                 uint8_t *out_reversed);
 /* device addresses of the result arrays (fp64 logp[n_reads], int32 summary[n_reads][8]) so that a
  * multi-GPU driver can hand them to RCCL without a host round trip; valid until batch_destroy.      */
 int advntr_batch_result_ptrs(advntr_batch *batch, void **d_logp, void **d_summary);

@@ -367,3 +367,66 @@ def test_resident_log_probability_equals_one_shot_and_oracle():
     again, _ = B.fetch()
     assert np.array_equal(again, v_logp)
     B.close()
+
+
+def test_device_recruit_equals_the_rule_applied_on_the_host():
+    """advntr_batch_recruit (strand choice, recruit_read, more than two repeat bases -- vntr_finder.py:179-190, 242-254 -- applied
+    to the records in HBM, survivors compacted in read order) against the same rule in numpy on the downloaded records
+    (recruit_mask, which the golden verdicts pin): loci with and without a trained score, both strands and forward only, reads
+    of several lengths, a batch whose last wavefront is partial, a batch nobody survives."""
+    from advntr_amd import _lib, vntr_finder, workloads
+    from advntr_amd.pomegranate import device_models
+    rng = np.random.default_rng(4242)
+    loci = [workloads.make_locus(rng, 150, int(L), vntr_finder.get_copies_for_hmm(150, int(L))) for L in (9, 14, 33, 57)]
+    workloads.build_models(loci)
+    dms = device_models([l.model for l in loci])
+    reads, which = [], []
+    for k, loc in enumerate(loci):
+        for n, cnt in ((150, 230), (149, 17), (100, 40), (60, 9)):
+            rs = workloads.make_reads(rng, loc, cnt, n, locus_fraction=0.7)
+            reads += [r if rng.random() < 0.5 else vntr_finder.reverse_complement(r) for r in rs]
+            which += [k] * cnt
+    which = np.asarray(which, np.int32)
+    bases, off = _lib.encode_reads(reads)
+    lens = np.diff(off)
+    nf = len(reads)
+    assert nf % 64 != 0
+    for scaled in (None, [-1.0, None, -0.9, 0], [-0.5, -0.5, -0.5, -0.5]):
+        for both in (True, False):
+            B = _lib.DeviceBatch(dms, bases, off, which, flags=_lib.FLAG_BOTH_STRANDS if both else 0)
+            B.run()
+            logp, summ = B.fetch()
+            idx, lp, sm, rev = B.recruit(scaled, 2)
+            B.close()
+            if both:
+                use_rev = logp[:nf] < logp[nf:]
+                c_lp, c_sm = np.where(use_rev, logp[nf:], logp[:nf]), np.where(use_rev[:, None], summ[nf:], summ[:nf])
+            else:
+                use_rev, c_lp, c_sm = np.zeros(nf, bool), logp, summ
+            sc = np.array([np.nan if (s is None or s == 0) else s for s in (scaled or [None] * 4)], np.float64)
+            want = vntr_finder.recruit_mask(c_lp, c_sm, lens, sc[which] * lens) & (c_sm[:, _lib.SUM_REPEAT_BP] > 2)
+            keep = np.flatnonzero(want)
+            assert np.array_equal(idx, keep), (scaled, both, len(idx), len(keep))
+            assert np.array_equal(lp, c_lp[keep]) and np.array_equal(sm, c_sm[keep]) and np.array_equal(rev, use_rev[keep])
+            if scaled is None and both:
+                assert 50 < len(keep) < nf and rev.any() and not rev.all()
+    # nobody survives / an empty batch
+    junk = [workloads.rand_seq(rng, 150) for _ in range(70)]
+    jb, jo = _lib.encode_reads(junk)
+    B = _lib.DeviceBatch(dms[:1], jb, jo, np.zeros(70, np.int32), flags=_lib.FLAG_BOTH_STRANDS)
+    B.run()
+    idx, lp, sm, rev = B.recruit(None, 2)
+    assert len(idx) == len(lp) == len(sm) == len(rev) == 0
+    with pytest.raises(ValueError):
+        B.recruit([1.0, 2.0], 2)
+    B.close()
+    # the selection the pipelined genotyper makes == score_reads_arrays + recruit_mask
+    models = [l.model for l in loci]
+    lists = [[r for r, w in zip(reads, which) if w == k] for k in range(4)]
+    lists[2] = lists[2][:5] + ["ACGTN" * 30] + lists[2][5:]
+    prep = vntr_finder._prepare_reads(lists)
+    res = vntr_finder._score_prepared(models, prep, [-1.0, None, -0.9, None])
+    pos, locus, sm, rev = vntr_finder._select_prepared(models, prep, [-1.0, None, -0.9, None])
+    keep = np.flatnonzero(res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2))
+    assert np.array_equal(pos, keep) and np.array_equal(locus, res["locus"][keep])
+    assert np.array_equal(sm, res["summary"][keep]) and np.array_equal(rev, res["reversed"][keep])
