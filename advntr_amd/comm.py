@@ -317,7 +317,7 @@ def init_from_env(backend=None, set_device=True):
         err = str(e).encode("utf-8", "replace")
     except Exception as e:          # noqa: BLE001 -- past the agreed stage: no collective fallback, no waiting for the others
         raise RuntimeError("rank %d: RCCL communicator could not be created after every rank had agreed to (%s); the other "
-                           "ranks are inside ncclCommInitRank and end with the job" % (rank, e))
+                           "ranks are inside ncclCommInitRank and end with the job" % (rank, e)) from e
     failures = [x for x in rdzv.allgather(err) if x]
     if not failures:
         return c

@@ -370,6 +370,9 @@ __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_kernel(KwfArgs a)
 #define KWF_QCAP 384                         // queue entries per wavefront (a word of 64 reads has 220 survivors on average, 1 024
                                              // at most: a fuller queue is drained in passes)
 #define KWF_SHORT_LDS_BYTES (KWF_BITSET_BITS / 8 + (KWF_BLOCK / 64) * KWF_QCAP * 5)
+// (dynamic LDS of keyword_filter_short_kernel: the first-level filter + the wavefronts' survivor queues -- KWF_QCAP entries of 5
+// bytes each -- must fit the 160 KiB of a compute unit, or the launch fails at run time)
+static_assert(KWF_SHORT_LDS_BYTES <= 160 * 1024, "keyword_filter_short_kernel: first-level filter + queues exceed the LDS of a CU");
 template <bool ASCII, bool WIDE>
 __global__ void __launch_bounds__(KWF_BLOCK) keyword_filter_short_kernel(KwfArgs a)
 {

@@ -28,7 +28,7 @@
 //   <4, 2>:  65-124 bases, 4 rows per lane, 2 reads per wavefront
 //   <4, 4>:   1-64  bases, 4 rows per lane, 4 reads per wavefront (a DPP row of 16 lanes each: `row_shr:1` never crosses
 //             groups and lanes 0/16/32/48 keep the `old` operand = the row-0 boundary, so no fix-up at all)
-// Measured on the bench workload (100 k reads of 150 bases, 453-column model; kernel ms per launch; the anti-diagonal
+// Measured on the bench workload (100 k reads of 150 bases, the 488-column REF150 model; kernel ms per launch; the anti-diagonal
 // kernel: 16.5):  <5, 2> at 3 waves/SIMD 11.3 (no spill inside the sweep loop); at 4 waves/SIMD (128 VGPRs) 12.6:
 // the loop then reloads spilled values, and on gfx9 a vector-memory load waits behind the back-pointer stores in the
 // same counter;  <10, 4> needs 256 VGPRs (2 waves/SIMD) 13.2, with 3 waves it spills 22.3.
@@ -45,7 +45,7 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 // Back-to-back sweeps: a wavefront's lane groups take up to ROWS_DEPTH reads each, one behind the other ALONG THE STEP AXIS.
 // When a lane has done the last column of its group's kth read it starts column 0 of read k + 1 on the next step -- the
 // neighbouring lanes follow one step later each, exactly as at the start of a sweep -- so the W - 1 steps a sweep spends
-// filling and draining its pipeline are paid once per ROWS_DEPTH reads instead of once per read (REF150, 453 columns: 6 %
+// filling and draining its pipeline are paid once per ROWS_DEPTH reads instead of once per read (REF150, 488 columns: 6 %
 // of the steps; the 99 columns of the metric's ~300-state shape: 23 %).  A lane's rows of the queued reads wait packed in
 // one 64-bit register (3 bits per row + 3 bits for the slot of the read's last row): nothing else is carried.
 #ifndef ROWS_DEPTH

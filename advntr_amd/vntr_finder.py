@@ -647,20 +647,19 @@ def find_hmm_score_of_simulated_reads(model, reads):
 
 
 def find_recruitment_score_threshold(true_scores, false_scores):
-    """vntr_finder.py:1007-1021: logistic regression on the scores, threshold = the first integer below 0 the
-    classifier calls "false" (max(true) if none within -1..-299)."""
+    """The score that separates a locus's own reads from the false positives of its keyword filter: a one-feature logistic
+    classifier on the Viterbi scores, asked about every integer score -1, -2, ... -299 at once; the first one it calls
+    "false" is the threshold, the best true score when it calls none (vntr_finder.py:1007-1021)."""
     from sklearn.linear_model import LogisticRegression
-    true_scores, false_scores = list(true_scores), list(false_scores)
-    if len(false_scores) == 0:
-        false_scores = [min(true_scores) - 2]
+    pos = np.asarray(list(true_scores), np.float64)
+    neg = np.asarray(list(false_scores), np.float64)
+    if neg.size == 0:
+        neg = np.array([pos.min() - 2])
     clf = LogisticRegression()
-    clf.fit([[s] for s in true_scores + false_scores], [1] * len(true_scores) + [0] * len(false_scores))
-    recruitment_score = max(true_scores)
-    for i in range(-1, -300, -1):
-        if int(clf.predict([[i]])[0]) == 0:
-            recruitment_score = i
-            break
-    return recruitment_score
+    clf.fit(np.concatenate([pos, neg]).reshape(-1, 1), np.concatenate([np.ones(pos.size, int), np.zeros(neg.size, int)]))
+    grid = np.arange(-1, -300, -1)
+    rejected = np.flatnonzero(clf.predict(grid.reshape(-1, 1).astype(np.float64)) == 0)
+    return int(grid[rejected[0]]) if rejected.size else float(pos.max())
 
 
 def train_classifier_threshold(reference_vntr, sequences, read_length=150):
@@ -680,52 +679,53 @@ def train_classifier_threshold(reference_vntr, sequences, read_length=150):
 # Frameshift identification from Viterbi paths (vntr_finder.py:256-309) -- a consumer of the engine's PATH output
 # ------------------------------------------------------------------------------------------------
 def identify_frameshift(location_coverage, observed_indel_transitions, expected_indels, error_rate=0.01):
-    """vntr_finder.py:256-263: binomial likelihood ratio of "sequencing error" against "frameshift"."""
+    """Is an indel seen `observed_indel_transitions` times at a position covered `location_coverage` times a frameshift or a
+    sequencing error?  Binomial likelihood of the count under either rate; a frameshift when the error explanation is a
+    hundred times less likely (vntr_finder.py:256-263; the coverage may be fractional, as there)."""
     if observed_indel_transitions >= location_coverage:
         return True
     from scipy.stats import binom
-    sequencing_error_prob = binom.pmf(observed_indel_transitions, location_coverage, error_rate)
-    frameshift_prob = binom.pmf(observed_indel_transitions, location_coverage, expected_indels)
-    return bool(sequencing_error_prob / frameshift_prob < 0.01)
+    as_error, as_frameshift = binom.pmf(observed_indel_transitions, location_coverage, [error_rate, expected_indels])
+    return bool(as_error / as_frameshift < 0.01)
+
+
+def _off_length_unit_indels(sequence, visited_states, pattern_length):
+    """The insert / delete states a read's path takes inside repeat units whose length is one or two bases off the pattern's
+    (an insert state labelled with the base it emitted, e.g. 'I3A'), in path order."""
+    from .hmm_utils import get_emitted_basepair_from_visited_states, get_repeating_pattern_lengths
+    unit_lengths = get_repeating_pattern_lengths(visited_states)
+    unit = -1
+    for name in visited_states:
+        if name.startswith('unit_start'):
+            unit += 1
+            continue
+        if unit < 0 or unit >= len(unit_lengths) or name[0] not in 'ID' or name.endswith('fix'):
+            continue
+        off = abs(unit_lengths[unit] - pattern_length)
+        if off == 0 or off > 2:
+            continue
+        label = name.split('_')[0]
+        yield label + get_emitted_basepair_from_visited_states(name, visited_states, sequence) if label[0] == 'I' else label
 
 
 def find_frameshift_from_selected_reads(pattern_length, vntr_length, selected_reads):
-    """vntr_finder.py:265-309.  selected_reads = [(sequence, visited_state_names)] with the names of vpath[1:-1].
-    Counts, per insert/delete state, the repeat units whose length is off by one or two bases from the pattern, and
-    tests the most frequent one against the per-base coverage.  Returns the state label (an insert state carries the
-    inserted base, e.g. 'I3A') or None."""
-    from .hmm_utils import get_emitted_basepair_from_visited_states, get_repeating_pattern_lengths, state_class_from_name
-    mutations = {}
-    repeating_bps_in_data = 0
+    """vntr_finder.py:265-309.  selected_reads = [(sequence, visited_state_names)] with the names of vpath[1:-1].  Tallies the
+    indel states of off-length repeat units over the reads, takes the most frequent one (of equally frequent ones the one
+    first seen last) and tests its count against the per-base coverage of the repeat region.  Returns the state label or None."""
+    from .hmm_utils import state_class_from_name
+    tally = {}
+    repeat_bases = 0
     for sequence, visited_states in selected_reads:
-        repeats_lengths = get_repeating_pattern_lengths(visited_states)
-        current_repeat = None
-        for name in visited_states:                       # emitting states outside the flanks = repeat bases
-            c = state_class_from_name(name)
-            if (c & _lib.SC_EMIT) and not (c & _lib.SC_FIX):
-                repeating_bps_in_data += 1
-        for name in visited_states:
-            if name.endswith('fix') or name.startswith('M'):
-                continue
-            if name.startswith('unit_start'):
-                current_repeat = 0 if current_repeat is None else current_repeat + 1
-            if current_repeat is None or current_repeat >= len(repeats_lengths):
-                continue
-            if not name.startswith('I') and not name.startswith('D'):
-                continue
-            if repeats_lengths[current_repeat] == pattern_length:
-                continue
-            state = name.split('_')[0]
-            if state.startswith('I'):
-                state += get_emitted_basepair_from_visited_states(name, visited_states, sequence)
-            if abs(repeats_lengths[current_repeat] - pattern_length) <= 2:
-                mutations[state] = mutations.get(state, 0) + 1
-    ranked = sorted(mutations.items(), key=lambda kv: kv[1])           # stable: ties keep first-seen order
-    candidate = ranked[-1] if ranked else (None, 0)
-    avg_bp_coverage = float(repeating_bps_in_data) / vntr_length / 2
-    if identify_frameshift(avg_bp_coverage, candidate[1], 1 / avg_bp_coverage):
-        return candidate[0]
-    return None
+        classes = np.fromiter((state_class_from_name(name) for name in visited_states), dtype=np.int64, count=len(visited_states))
+        repeat_bases += int(np.count_nonzero((classes & _lib.SC_EMIT != 0) & (classes & _lib.SC_FIX == 0)))
+        for label in _off_length_unit_indels(sequence, visited_states, pattern_length):
+            tally[label] = tally.get(label, 0) + 1
+    best, best_count = None, 0
+    for label, count in tally.items():              # first-seen order; '>=' keeps the last of equally frequent labels
+        if count >= best_count:
+            best, best_count = label, count
+    coverage = float(repeat_bases) / vntr_length / 2
+    return best if identify_frameshift(coverage, best_count, 1 / coverage) else None
 
 
 def find_frameshift(model, pattern_length, vntr_length, sequences, scaled_score=None):

@@ -154,8 +154,10 @@ def spawn_ranks(args, argv):
         sys.stdout.flush()
     finally:
         # also when the launcher itself is interrupted: no rank, pool worker, output file or rendezvous directory stays behind
+        # (only ranks that have not been reaped: their process-group id is still theirs.  The id of a rank that has exited and
+        # been waited for may have been recycled for somebody else's group)
         for p in procs:
-            if p.poll() is None or why is not None:
+            if p.returncode is None and p.poll() is None:
                 end_rank(p)
         for p in procs:
             try:
