@@ -29,6 +29,7 @@ SYMBOLS = {
     "advntr_last_error": (ctypes.c_char_p, []),
     "advntr_version": (ctypes.c_char_p, []),
     "advntr_trim": (None, []),
+    "advntr_host_threads": (ctypes.c_int, []),
     "advntr_hmm_create": (_vp, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "advntr_hmm_destroy": (None, [_vp]),
     "advntr_hmm_has_column_program": (ctypes.c_int, [_vp]),

@@ -14,7 +14,7 @@ extern "C" int advntr_genotype_illumina(const int32_t *summaries, const int64_t 
         if (locus_off[i + 1] < locus_off[i]) return fail(ADVNTR_ERR_ARG, "advntr_genotype_illumina: locus_off not monotone at %d", i);
     if (locus_off[n_loci] > locus_off[0] && !summaries) return fail(ADVNTR_ERR_ARG, "advntr_genotype_illumina: null summaries");
     const bool accuracy = (flags & ADVNTR_GENOTYPE_ACCURACY_FILTER) != 0, haploid = (flags & ADVNTR_GENOTYPE_HAPLOID) != 0;
-    if (n_threads <= 0) n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads <= 0) n_threads = std::min(16, host_cpu_limit());
     n_threads = std::min(n_threads, std::max(1, n_loci / 64));
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -52,7 +52,7 @@ extern "C" int advntr_genotype_observed(const int32_t *ru_counts, const int64_t 
         if (locus_off[i + 1] < locus_off[i]) return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: locus_off not monotone at %d", i);
     if (locus_off[n_loci] > locus_off[0] && !ru_counts) return fail(ADVNTR_ERR_ARG, "advntr_genotype_observed: null ru_counts");
     const bool accuracy = (flags & ADVNTR_GENOTYPE_ACCURACY_FILTER) != 0, haploid = (flags & ADVNTR_GENOTYPE_HAPLOID) != 0;
-    if (n_threads <= 0) n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads <= 0) n_threads = std::min(16, host_cpu_limit());
     n_threads = std::min(n_threads, std::max(1, n_loci / 64));
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -81,7 +81,7 @@ extern "C" int advntr_genotype_observed(const int32_t *ru_counts, const int64_t 
 // 2 M reads around the prefilter kernel): line index of a FASTA text and ASCII -> base codes, on host threads.
 static int host_text_threads(int n_threads, int64_t units, int64_t per_thread)
 {
-    if (n_threads <= 0) n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_threads <= 0) n_threads = std::min(16, host_cpu_limit());
     return (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (units + per_thread - 1) / per_thread));
 }
 

@@ -14,16 +14,9 @@ struct advntr_built {
 // Host threads for the per-locus jobs (model build, table preparation).  These jobs are allocation-heavy (thousands of
 // small vectors and strings per locus); measured on a 256-thread host, 6 719 loci: 32 threads 0.31-0.37 s for the
 // build and 0.30 s for the upload preparation, 256 threads 0.65 s and 1.3 s (allocator contention) -- hence the cap.
-// host threads of the bulk calls when the caller says 0: up to 32 (measured on the 256-thread host of the GPU box, with the
-// stages of a pipelined run beside each other: 64 or 128 threads per call are no faster); ADVNTR_HOST_THREADS overrides
-static int default_host_threads()
-{
-    if (const char *e = getenv("ADVNTR_HOST_THREADS")) {
-        const int v = atoi(e);
-        if (v > 0) return std::min<int>(v, 1024);
-    }
-    return (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-}
+// host threads of the bulk calls when the caller says 0: up to 32 (measured on the host of the GPU box: 64 or 128 threads per
+// call are no faster), never more than the CPUs this process may use (host_cpu_limit); ADVNTR_HOST_THREADS overrides
+static int default_host_threads() { return std::min(32, host_cpu_limit()); }
 
 extern "C" int advntr_build_read_matchers(int32_t n_loci, const char *const *left_flank, const char *const *right_flank,
                                           const char *const *repeats, const int32_t *repeat_off, const int32_t *copies,

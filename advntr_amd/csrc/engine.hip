@@ -1348,6 +1348,38 @@ extern "C" int advntr_batch_forward_timed(advntr_batch *B, int32_t iters, float 
     return ADVNTR_OK;
 }
 
+// CPUs this process may really use: the hardware threads, cut down to the CPU-time quota of its control group (a container on
+// a 256-thread host is typically given a few cores: 16 on the GPU boxes of this pool).  A bulk call that starts more worker
+// threads than that has its whole group stopped by the scheduler for the rest of every accounting period -- seen as pauses of
+// tens of milliseconds in ALL threads of a pipelined run (scripts/e2e_timeline.py).  ADVNTR_HOST_THREADS overrides.
+static int host_cpu_limit()
+{
+    static const int limit = [] {
+        if (const char *e = getenv("ADVNTR_HOST_THREADS")) {
+            const int v = atoi(e);
+            if (v > 0) return std::min(v, 1024);
+        }
+        int n = (int)std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(h, "%lld", &period) != 1) period = 100000;
+                fclose(h);
+            }
+        }
+        if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+        return n;
+    }();
+    return limit;
+}
+extern "C" int advntr_host_threads(void) { return host_cpu_limit(); }
+
 #include "abi_keyword_filter.h"
 #include "abi_model_builder.h"
 #include "abi_flank_align.h"

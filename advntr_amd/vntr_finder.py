@@ -138,7 +138,7 @@ def _empty_scores():
                 recruited=np.zeros(0, bool), length=np.zeros(0, np.int64))
 
 
-def _prepare_reads(read_lists):
+def _prepare_reads(read_lists, threads=0):
     """The host half of score_reads_arrays: one code buffer for every read of every locus (case folding, encoding and the
     test for symbols outside ACGT on host threads in the library, advntr_encode_ascii).  Reads holding 'N' are dropped as
     the reference does (vntr_finder.py:237); any other foreign symbol raises, as the reference's viterbi does
@@ -150,7 +150,7 @@ def _prepare_reads(read_lists):
     n_all = len(flat)
     if n_all == 0:
         return None
-    codes, all_off, bad = _lib.encode_ascii(flat)
+    codes, all_off, bad = _lib.encode_ascii(flat, threads)
     if np.any(bad == 2):
         raise ValueError("Symbol is not defined in a distribution (read %d holds a symbol outside ACGTN)" % int(np.argmax(bad == 2)))
     all_len = np.diff(all_off)
@@ -280,6 +280,8 @@ class _Stage(object):
                 res = self._fn(k, *args)
                 if self._timer is not None:
                     self._timer[0][self._timer[1]] += time.perf_counter() - t
+                    if "trace" in self._timer[0]:
+                        self._timer[0]["trace"].append((self._timer[1], k, t, time.perf_counter()))
                 self._put(res)
         except _Aborted:
             pass
@@ -312,10 +314,12 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
     T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, bind_batch=0.0, score_recruit=0.0, aggregate_genotype=0.0)
+    if timings is not None and "trace" in timings:
+        T["trace"] = []                             # (stage, piece, start, end) of every stage call: scripts/host_profile.py
     abort = threading.Event()
 
     def upload(k, models):
-        device_models(models)
+        device_models(models, threads=t_other)
         return models
 
     def bind(k, models, prep):
@@ -324,11 +328,20 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
         return models, prep, _lib.DeviceBatch(device_models(models), prep["bases"], prep["off"], prep["locus"],
                                               flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
 
+    # every stage may use the CPUs this process may use (advntr_host_threads: the hardware threads cut down to the control
+    # group's quota -- 16 on the GPU boxes of this pool, where 32 or more threads per stage have the whole process stopped by
+    # the scheduler for the rest of every accounting period: 0.41 s at 16 threads per stage, 0.47 s at 32, 0.50 s at 64 or 128;
+    # splitting the quota between the stages -- 10 + 4 + 4 -- starves the table preparation of the upload: 0.55 s).  The host
+    # work of this run is ~8 core-seconds (model building 5, table preparation 1.5-2, read encoding 1): a quota of 16 cores
+    # bounds the run at ~0.4-0.5 s whatever the device does in its 0.17 s
+    cpus = int(threads) if threads and threads > 0 else int(_lib.load().advntr_host_threads())
+    t_build = t_other = max(1, cpus)
     t0 = time.perf_counter()
-    built = _Stage("advntr-build", lambda k: hmm_utils.build_read_matcher_models(loci[cuts[k]:cuts[k + 1]], threads=threads),
+    built = _Stage("advntr-build", lambda k: hmm_utils.build_read_matcher_models(loci[cuts[k]:cuts[k + 1]], threads=t_build),
                    chunks, [], abort, (T, "build_models"))
     uploaded = _Stage("advntr-upload", upload, chunks, [built], abort, (T, "upload_models"))
-    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]]),), chunks, [], abort, (T, "encode_reads"))
+    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_other),), chunks, [], abort,
+                     (T, "encode_reads"))
     bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
     stages = [built, uploaded, encoded, bound]
     parts = []
@@ -347,6 +360,8 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
                     batch.close()
                 parts.append((prep["locus"][index].astype(np.int64) + cuts[k], summ))
             T["score_recruit"] += time.perf_counter() - t
+            if "trace" in T:
+                T["trace"].append(("score_recruit", k, t, time.perf_counter()))
             del models, prep, batch, item           # the piece's models leave the device with their last reference
     finally:
         abort.set()                                 # (no stage is left waiting on a queue nobody serves any more)

@@ -81,6 +81,8 @@ int advntr_device_count(void);
 int advntr_set_device(int device);           /* per process: one process per GPU                        */
 const char *advntr_last_error(void);         /* thread-local message of the last failing call           */
 const char *advntr_version(void);
+int advntr_host_threads(void);               /* CPUs the bulk host-side calls may use: hardware threads cut down to the CPU quota of
+                                              * the process's control group; ADVNTR_HOST_THREADS overrides                       */
 void advntr_trim(void);                      /* release the cached device buffers (batches reuse them between calls) */
 
 /* ---- model (replaces the malloc'd CSR owned by a baked HiddenMarkovModel, hmm.pyx:935-1023) ---
