@@ -208,7 +208,6 @@ struct advntr_hmm {
     std::shared_ptr<const mb::Built> built;               // ... or the builder's result they point into
     bool has_class = false;
     ColProgramSummary colprog;    // valid = false when the model is not a recognised read matcher
-    bool rows_classes_ok = true;   // class words usable by the row-blocked kernels' summaries gathered along the walk (advntr_hmm_create)
     int32_t col_lds_bytes = 0;     // LDS-resident tables of the column program: classes, emissions, column info, states
     int32_t col_lds_core = 0;      // ... without the state table (only the traceback reads it)
     int32_t col_lds_min = 0;       // ... without the column-info table either (the sweep indexes a padded copy of it)
@@ -399,19 +398,6 @@ static advntr_hmm *hmm_prepare(int32_t m, int32_t silent_start, int32_t start_in
     // (they end up in the blob), only the summary stays with the model
     static thread_local ColProgramHost prog;
     build_column_program(*H, prog);
-    // The row-blocked kernels gather the path summary along the traceback and read the running base-pair count of
-    // hmm_utils.py:171 off the trellis row (path_summary.h: PathSummaryAcc), which is right when the class words mark exactly
-    // the emitting states as emitting (what advntr's names do) or say nothing at all; any other class words keep the model's
-    // reads on the kernels that count along the reversed path
-    {
-        bool any = false, consistent = true;
-        for (int i = 0; i < m; ++i) {
-            const uint16_t c = H->sclass.p[i];
-            any = any || c != 0;
-            if (((c & ADVNTR_SC_EMIT) != 0) != (i < silent_start)) consistent = false;
-        }
-        H->rows_classes_ok = !any || consistent;
-    }
     H->colprog.valid = prog.valid;
     H->colprog.n_cols = prog.n_cols;
     H->colprog.why = prog.why;
@@ -736,15 +722,12 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         const int64_t n = read_off[r + 1] - read_off[r];
         // (the row-blocked sweep reaches class and emission records through 16-bit LDS addresses: a model whose two tables
         // pass 64 KiB keeps its reads on the anti-diagonal kernel, which has a range-checked sweep for that case)
-        const advntr_hmm *Hr = B->models[read_model[r]];
-        // (... and their short-read summaries count path states in 16-bit fields, their walks need class words that mark exactly
-        // the emitting states as emitting: path_summary.h)
-        if (use_rows && rows_len(n) && Hr->col_lds_min + 64 <= 0x10000 && Hr->rows_classes_ok && Hr->m + ROWS_MAX_READ < 65536) {
+        if (use_rows && rows_len(n) && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) {
             int cfg = 0;
             while (cfg + 1 < ROWS_CONFIGS && n <= rows_configs[cfg + 1].max_read) ++cfg;       // the tightest fit
             return cfg;
         }
-        if (use_rows_long && n > ROWS_MAX_READ && Hr->col_lds_min + 64 <= 0x10000 && Hr->rows_classes_ok) return 3;
+        if (use_rows_long && n > ROWS_MAX_READ && B->models[read_model[r]]->col_lds_min + 64 <= 0x10000) return 3;
         return 3 + (int)std::min<int64_t>(5, (n + 63) / 64);
     };
     {   // order: bucket, then model, then longest first, then read index.  A counting sort over (bucket, model) -- both

@@ -18,7 +18,6 @@
 // fan-in from every match state) are evaluated once, wave-parallel, after the sweep.  The wave then walks the
 // pointers back cooperatively (col_traceback) and summarises the path (path_summary.h).
 #pragma once
-#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <vector>
@@ -581,26 +580,20 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 // and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
 // bp_at(t, c, st) -> back-pointer byte of cell (t, c), of which the walk uses the two bits of state st (0 = I, 1 = M, 2 = b):
 // the layout of the back-pointer store belongs to the sweep that wrote it
-// acc: what gathers the path summary along the walk (path_summary.h: PathSummaryAcc; `fused` = it does, and the walk knows every
-// visited state's row) -- with it, and want_rev false, the walk writes no reversed path at all
-template <class BpAt, class Acc = NoPathSummaryAcc>
+template <class BpAt>
 __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                                   const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
                                                   const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
                                                   int32_t *__restrict__ rev, const int cap, const int lane,
-                                                  const int U0, const int W, const int sink_col0 = 0, Acc *acc = nullptr,
-                                                  const bool want_rev = true)
+                                                  const int U0, const int W, const int sink_col0 = 0)
 {
-    constexpr bool fused = !std::is_same<Acc, NoPathSummaryAcc>::value;
     const ColFinishTables F = col_finish_tables(cp);
     int len = 0;
     int ti = F.end_tail, t = n, c = 0, slot = 0;
-    // tail states (all in row n; the first one is the model's end state, which the summaries leave out)
+    // tail states (all in row n)
     for (;;) {
         if (len >= cap - 2) return -2;
-        const int st = F.tstate[ti];
-        if (want_rev && lane == 0) rev[len] = st;
-        if (fused && len > 0) acc->visit(lane == 0, st, n, false);
+        if (lane == 0) rev[len] = F.tstate[ti];
         ++len;
         const int loc = F.edges_u[__builtin_amdgcn_readfirstlane(tailwin[ti])].loc;
         if (loc < 0) { ti = -loc - 1; continue; }
@@ -616,17 +609,12 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             const int tt = t - lane, cc = c - lane;
             const bool valid = tt >= 1 && cc >= 1;
             const int byte = valid ? bp_at(tt, cc, 1) : 0xff;
-            if (fused) acc->flush(byte);
             const unsigned long long mm = __ballot(valid && tt > 1 && bp_ptr_M(byte) == 1);      // row 1: 1 = entry edge
             // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
             const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
             const int cells = min(run + 1, 64);                       // M cells visited, lanes 0..cells-1
-            if (want_rev || fused) {
-                const int st = lane < cells ? L.state[cc + 1].sM : 0;
-                if (want_rev && lane < cells) rev[len + lane] = st;
-                if (fused) acc->issue(lane < cells, st, tt, true);
-            }
+            if (lane < cells) rev[len + lane] = L.state[cc + 1].sM;
             len += cells;
             if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
@@ -648,12 +636,10 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             const int tt = t - lane;
             const bool valid = tt >= 1;
             const int byte = valid ? bp_at(tt, c, 0) : 0xff;
-            if (fused) acc->flush(byte);
             const unsigned long long ii = __ballot(valid && bp_ptr_I(byte) == 0);
             const int run = (~ii == 0ull) ? 64 : (__ffsll((long long)~ii) - 1);
             const int cells = min(run + 1, 64);
-            if (want_rev && lane < cells) rev[len + lane] = cs.sI;
-            if (fused) acc->issue(lane < cells, cs.sI, tt, true);
+            if (lane < cells) rev[len + lane] = cs.sI;
             len += cells;
             if (run >= 64) { t -= 64; continue; }
             slot = bp_ptr_I(__builtin_amdgcn_readlane(byte, run));      // 1 -> M, 2 -> b of the same column
@@ -671,15 +657,10 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             const unsigned fl = valid ? L.info0[cc + 1].flags : 0u;
             const bool sink = (fl & COL_FLAG_SINK) != 0;
             const int byte = (valid && !sink) ? bp_at(t, cc, 2) : 0xff;
-            if (fused) acc->flush(byte);
             const unsigned long long bb = __ballot(valid && !sink && bp_ptr_B(byte) == 2) | (~0ull << COL_B_RUN);
             const int run = (~bb == 0ull) ? COL_B_RUN : (__ffsll((long long)~bb) - 1);
             const int cells = min(run + 1, COL_B_RUN);
-            if (want_rev || fused) {
-                const int st = lane < cells ? L.state[max(cc, 0) + 1].sB : 0;
-                if (want_rev && lane < cells) rev[len + lane] = st;
-                if (fused) acc->issue(lane < cells, st, t, false);
-            }
+            if (lane < cells) rev[len + lane] = L.state[max(cc, 0) + 1].sB;
             len += cells;
             if (run >= COL_B_RUN) { c -= COL_B_RUN; continue; }
             const unsigned flr = (unsigned)__builtin_amdgcn_readlane((int)fl, run);
@@ -692,14 +673,13 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
         }
     }
     if (s0 < 0) s0 = L.state[c + 1].sB;                    // arrived in row 0 on the backbone
-    while (s0 != start_state) {                            // (the start state itself is left out of the summaries like the end state)
+    while (s0 != start_state) {
         if (len >= cap - 2 || s0 < P) return -2;
-        if (want_rev && lane == 0) rev[len] = s0;
-        if (fused) acc->visit(lane == 0, s0, 0, false);
+        if (lane == 0) rev[len] = s0;
         ++len;
         s0 = F.pred0[s0 - P];
     }
-    if (want_rev && lane == 0) rev[len] = start_state;
+    if (lane == 0) rev[len] = start_state;
     ++len;
     return len;
 }

@@ -400,50 +400,6 @@ __device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ s
     return w | (unsigned)kc << (3 * R);
 }
 
-// Traceback, path summary and outputs of one read whose log-probability (tail states done) is `logp`.  The summary is gathered
-// along the walk (path_summary.h: PathSummaryAcc -- the row-blocked kernels' walks know the row of every state they visit), so
-// the reversed path is only written when the caller asked for paths.
-template <bool WIDE, class BpAt>
-__device__ __forceinline__ void rows_walk_and_emit(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
-                                                   const LdsTables &L, const DevModel &M, const int r,
-                                                   const uint8_t *__restrict__ seq, const int n, const double logp,
-                                                   const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                                   int32_t *__restrict__ rev, const int lane, const int col0, const BpAt &bp_at)
-{
-    const bool want_summary = g.a.out_summary && !(flags & 4u), want_path = g.a.out_path && (flags & 1u);
-    PathSummaryAcc<WIDE> acc(M.sclass, seq, n);
-    int len = 0;
-#ifndef ADVNTR_BUDGET_NO_TRACEBACK
-    if (logp != -INFINITY && (want_summary || want_path)) {
-        len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0, 1 << 30,
-                                 col0, &acc, want_path);
-        len = __builtin_amdgcn_readfirstlane(len);
-    }
-#endif
-    // the reference's path buffer holds n + m entries (hmm.pyx:1953, written without a bound check): a longer path is
-    // refused here, the same way by every kernel
-    if (len > n + M.m) len = -2;
-#ifndef ADVNTR_BUDGET_NO_SUMMARY
-    if (want_summary) {
-        int32_t *out = g.a.out_summary + (int64_t)r * 8;
-        if (len > 0) acc.write(out, len, lane);
-        else if (lane < 8) out[lane] = (lane == 7) ? len : 0;
-    }
-#endif
-    if (want_path) {
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        const int64_t o0 = g.a.out_path_off[r];
-        const int cap = (int)(g.a.out_path_off[r + 1] - o0);
-        int olen = len;
-        if (len > cap) olen = -2;
-        if (olen > 0)
-            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
-        if (lane == 0) g.a.out_path_len[r] = olen;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
 // tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group; col0 = the steps
 // the read's sweep began after (k * NC for the kth read of a back-to-back sweep)
 template <int R>
@@ -463,8 +419,22 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
     const double logp = col_tail(cp, final_row, tailwin, NC, lane, tailv);
 #endif
     if (lane == 0) g.a.out_logp[r] = logp;
-    rows_walk_and_emit<false>(g, flags, cp, L, M, r, seq, n, logp, tailwin, sinkbp, rev, lane, col0,
-                       [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); });
+    int len = 0;
+#ifndef ADVNTR_BUDGET_NO_TRACEBACK
+    if (logp != -INFINITY) {
+        auto bp_at = [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); };
+        len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
+                                 1 << 30, col0);
+        len = __builtin_amdgcn_readfirstlane(len);
+    }
+#endif
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+#ifdef ADVNTR_BUDGET_NO_SUMMARY
+    if (lane == 0 && g.a.out_summary) g.a.out_summary[(int64_t)r * 8 + 7] = len;
+#else
+    col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
+#endif
 }
 
 template <int R, int G>
@@ -658,17 +628,23 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
             double *final_row = rown + (n_tiles & 1) * row_doubles + 3 * W;
             const double logp = col_tail(cp, final_row, tailwin, NC, lane);
             if (lane == 0) g.a.out_logp[r] = logp;
-            {
+            int len = 0;
+            if (logp != -INFINITY) {
                 // x / rl for x < 400 as a multiply and a shift (rl = 1 .. 5)
                 const unsigned rl_magic = rl == 1 ? 65536u : (rl == 2 ? 32768u : (rl == 3 ? 21846u : (rl == 4 ? 16384u : 13108u)));
-                rows_walk_and_emit<true>(g, flags, cp, L, M, r, seq, n, logp, tailwin, aux + COL_MAX_TAIL, rev, lane, 0,
-                                   [&](int tt, int cc, int st) -> int {
-                                       const int tl = (tt - 1) / RT;
-                                       if (tl + 1 < n_tiles) return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc, st);
-                                       const int x = tt - tl * RT - 1, lp = (int)(((unsigned)x * rl_magic) >> 16);
-                                       return rows_bp_at_split(bpw + tl * slab, lp, x - lp * rl, cc, st);
-                                   });
+                auto bp_at = [&](int tt, int cc, int st) -> int {
+                    const int tl = (tt - 1) / RT;
+                    if (tl + 1 < n_tiles) return rows_bp_at<R>(bpw + tl * slab, 0, tt - tl * RT, cc, st);
+                    const int x = tt - tl * RT - 1, lp = (int)(((unsigned)x * rl_magic) >> 16);
+                    return rows_bp_at_split(bpw + tl * slab, lp, x - lp * rl, cc, st);
+                };
+                len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, aux + COL_MAX_TAIL, rev,
+                                         g.a.path_cap, lane, 0, 1 << 30);
+                len = __builtin_amdgcn_readfirstlane(len);
             }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            col_emit_outputs(g, flags, M, r, seq, n, rev, len, lane);
         }
     }
 }
