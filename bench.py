@@ -238,7 +238,7 @@ def measured_clock_ghz():
 def pmc_section(workload, n_calls, kernel):
     """Counters per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench);
     None when no committed profile describes this workload / kernel / size."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         pmc = load_json("profiles", name)
         if not pmc:
             continue
@@ -573,6 +573,7 @@ def main(argv=None):
                 out["flank_align"] = flank_align_record(_lib, upstream_input, args)
                 out["prefilter"] = prefilter_record(_lib, upstream_input, args)
         if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3", "c4"):
+            batch.close()                                   # (a rank has its GPU to itself: see c4_record)
             out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
                                                      {"calls": int(n_reads), "loop_ms": elapsed / args.steps * 1e3,
                                                       "kernel_ms": kernel_ms}, flags, max(1, args.steps),
@@ -957,6 +958,9 @@ def c4_record(_lib, workloads, inp, flags, args):
                                            "source": pmc.get("file")}
     from advntr_amd import sharding
     plan = workloads.c4_plan(len(loci), seed=20240603)
+    # (a rank of the multi-GPU job has its GPU to itself: the whole set's batch -- 100 GB of long-read scratch -- gives its memory
+    # back before the shares are laid out, or their launches would be sized for what is left)
+    batch.close()
     rec["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
                                              {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
                                              planned_work=[c * (ln + 1) * st for c, ln, st in plan],

@@ -1,0 +1,53 @@
+#!/bin/bash
+# Run on the GPU box: everything profiles/r05_* is made of.  scripts/profile_round5.sh gpurun_out/r05_prof
+# (every profiler pass under its own timeout: a pass that hangs must not eat the call)
+out=$1; root=$(pwd); mkdir -p $root/$out
+B="--no-cpu --no-s300 --no-c2"
+for w in c1 s300 c2 c4; do timeout 200 python3 bench.py --workload $w $B --steps 2 > $out/${w}_quick.json 2> $out/${w}_quick.err; done
+cd /tmp && export TMPDIR=/tmp
+declare -A passes=([c1]="--steps 20 --warmup 5" [s300]="--steps 20 --warmup 5" [c2]="--steps 10 --warmup 3" [c4]="--steps 5 --warmup 2")
+for w in c1 s300 c2 c4; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_$w -- python3 $root/bench.py --workload $w $B ${passes[$w]} > $root/$out/trace_$w.log 2>&1 < /dev/null
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_${w}_$c -- python3 $root/bench.py --workload $w $B --steps 1 --warmup 0 > $root/$out/pmc_${w}_$c.log 2>&1 < /dev/null
+  done
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU_ADD_F64 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $root/$out/pmc_${w}_sq -- python3 $root/bench.py --workload $w $B --steps 1 --warmup 0 > $root/$out/pmc_${w}_sq.log 2>&1 < /dev/null
+done
+# the end-to-end run (builder, recruit kernels, genotype caller) under the kernel trace: what the device does in it
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_e2e -- python3 $root/bench.py --no-upstream --no-cpu --steps 2 > $root/$out/trace_e2e.log 2>&1 < /dev/null
+cd $root
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections, json
+out = sys.argv[1]
+sections = []
+for w in ("c1", "s300", "c2", "c4"):
+    try:
+        bench = json.load(open("%s/%s_quick.json" % (out, w)))
+    except Exception as e:
+        print("no quick line for", w, e); continue
+    kernel = bench["config"]["kernel"]
+    tot = collections.defaultdict(float); n = collections.defaultdict(int)
+    for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row.get("Kernel_Name", "")
+            if not name.startswith("void " + kernel.split("<")[0]) or kernel not in name: continue
+            tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
+    c = {k: tot[k] / n[k] for k in tot}
+    sec = {"workload": w, "calls": bench["config"]["calls_this_rank"], "kernel": kernel, "counters_per_launch": c,
+           "launches_averaged": dict(n)}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB here; FETCH_SIZE counts half of the bytes of wide reads on
+        # gfx950 (MI355X_MICROARCH.md, HBM section): x2
+        sec["hbm_bytes_per_launch_fetch_x2"] = (c["WRITE_SIZE"] + 2 * c["FETCH_SIZE"]) * 1024
+    if "SQ_INSTS_VALU" in c:
+        sec["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+    sections.append(sec)
+    for f in glob.glob("%s/trace_%s/**/*kernel_stats.csv" % (out, w), recursive=True):
+        open("%s/%s_kernel_stats.csv" % (out, w), "w").write(open(f).read())
+for f in glob.glob("%s/trace_e2e/**/*kernel_stats.csv" % out, recursive=True):
+    open("%s/e2e_kernel_stats.csv" % out, "w").write(open(f).read())
+json.dump({"note": "per-launch counters of the dominant kernel of `python bench.py --workload W` (rocprofv3 --pmc, separate "
+                   "passes); FETCH_SIZE/WRITE_SIZE in KiB as reported, hbm_bytes = (WRITE + 2 x FETCH) x 1024",
+           "sections": sections}, open(out + "/pmc_summary.json", "w"), indent=1)
+print(json.dumps(sections, indent=1)[:1800])
+PY
