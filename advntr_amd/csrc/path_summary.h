@@ -33,9 +33,33 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Where a traceback leaves the path it walks (reversed: entry 0 = the model's end state): plain device memory, or -- the
+// row-blocked short-read kernel -- the wavefront's own piece of LDS for the first REV_LDS_ENTRIES states (16 bits each: engine.hip
+// sends a model there only when its state indices fit) with device memory behind it.  A store to device memory counts in the same
+// counter as the traceback's back-pointer gathers, so every round of the walk also waited for the previous round's stores to
+// reach memory (a build without the stores: REF150 launch 8.62 -> 8.38 ms, S300 2.64 -> 2.54 ms); an LDS store does not, and the
+// summary pass that follows reads the path back from LDS as well.
+#define REV_LDS_ENTRIES 512
+struct RevLds {
+    __attribute__((address_space(3))) unsigned short *lds;
+    int32_t *mem;
+};
+__device__ __forceinline__ void rev_put(int32_t *rev, const int pos, const int val) { rev[pos] = val; }
+__device__ __forceinline__ int rev_get(const int32_t *rev, const int pos) { return rev[pos]; }
+__device__ __forceinline__ void rev_put(const RevLds &rev, const int pos, const int val)
+{
+    if (pos < REV_LDS_ENTRIES) rev.lds[pos] = (unsigned short)val;
+    else rev.mem[pos] = val;
+}
+__device__ __forceinline__ int rev_get(const RevLds &rev, const int pos)
+{
+    return pos < REV_LDS_ENTRIES ? (int)rev.lds[pos] : rev.mem[pos];
+}
+
 // rev[0..len) holds the path reversed (rev[0] = model end ... rev[len-1] = model start).
 // Forward position i (0..len-1) is rev[len-1-i]; the reference drops positions 0 and len-1.
-__device__ inline void summarize_path(const int32_t *rev, int len, const uint16_t *__restrict__ sclass,
+template <class Rev>
+__device__ inline void summarize_path(const Rev &rev, int len, const uint16_t *__restrict__ sclass,
                                       const uint8_t *__restrict__ seq, int n, int32_t *out, int lane)
 {
     int cb = 0;                       // emitting states seen so far (reference: current_bp / seq_index)
@@ -47,7 +71,7 @@ __device__ inline void summarize_path(const int32_t *rev, int len, const uint16_
     for (int b = 1; b < len - 1; b += 64) {
         const int i = b + lane;
         const bool valid = i < len - 1;
-        const int st = valid ? rev[len - 1 - i] : 0;
+        const int st = valid ? rev_get(rev, len - 1 - i) : 0;
         const unsigned cls = (valid && sclass) ? sclass[st] : 0u;
         const bool emit = (cls & SC_EMIT) != 0;
         const unsigned long long bal = __ballot(emit);

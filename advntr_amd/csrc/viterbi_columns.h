@@ -580,11 +580,11 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 // and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
 // bp_at(t, c, st) -> back-pointer byte of cell (t, c), of which the walk uses the two bits of state st (0 = I, 1 = M, 2 = b):
 // the layout of the back-pointer store belongs to the sweep that wrote it
-template <class BpAt>
+template <class BpAt, class Rev>
 __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                                   const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
                                                   const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                                  int32_t *__restrict__ rev, const int cap, const int lane,
+                                                  const Rev &rev, const int cap, const int lane,
                                                   const int U0, const int W, const int sink_col0 = 0)
 {
     const ColFinishTables F = col_finish_tables(cp);
@@ -593,7 +593,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
     // tail states (all in row n)
     for (;;) {
         if (len >= cap - 2) return -2;
-        if (lane == 0) rev[len] = F.tstate[ti];
+        if (lane == 0) rev_put(rev, len, F.tstate[ti]);
         ++len;
         const int loc = F.edges_u[__builtin_amdgcn_readfirstlane(tailwin[ti])].loc;
         if (loc < 0) { ti = -loc - 1; continue; }
@@ -614,7 +614,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
             const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
             const int cells = min(run + 1, 64);                       // M cells visited, lanes 0..cells-1
-            if (lane < cells) rev[len + lane] = L.state[cc + 1].sM;
+            if (lane < cells) rev_put(rev, len + lane, L.state[cc + 1].sM);
             len += cells;
             if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
@@ -639,7 +639,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             const unsigned long long ii = __ballot(valid && bp_ptr_I(byte) == 0);
             const int run = (~ii == 0ull) ? 64 : (__ffsll((long long)~ii) - 1);
             const int cells = min(run + 1, 64);
-            if (lane < cells) rev[len + lane] = cs.sI;
+            if (lane < cells) rev_put(rev, len + lane, cs.sI);
             len += cells;
             if (run >= 64) { t -= 64; continue; }
             slot = bp_ptr_I(__builtin_amdgcn_readlane(byte, run));      // 1 -> M, 2 -> b of the same column
@@ -660,7 +660,7 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
             const unsigned long long bb = __ballot(valid && !sink && bp_ptr_B(byte) == 2) | (~0ull << COL_B_RUN);
             const int run = (~bb == 0ull) ? COL_B_RUN : (__ffsll((long long)~bb) - 1);
             const int cells = min(run + 1, COL_B_RUN);
-            if (lane < cells) rev[len + lane] = L.state[max(cc, 0) + 1].sB;
+            if (lane < cells) rev_put(rev, len + lane, L.state[max(cc, 0) + 1].sB);
             len += cells;
             if (run >= COL_B_RUN) { c -= COL_B_RUN; continue; }
             const unsigned flr = (unsigned)__builtin_amdgcn_readlane((int)fl, run);
@@ -675,11 +675,11 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
     if (s0 < 0) s0 = L.state[c + 1].sB;                    // arrived in row 0 on the backbone
     while (s0 != start_state) {
         if (len >= cap - 2 || s0 < P) return -2;
-        if (lane == 0) rev[len] = s0;
+        if (lane == 0) rev_put(rev, len, s0);
         ++len;
         s0 = F.pred0[s0 - P];
     }
-    if (lane == 0) rev[len] = start_state;
+    if (lane == 0) rev_put(rev, len, start_state);
     ++len;
     return len;
 }
@@ -768,8 +768,9 @@ __device__ __forceinline__ bool stage_model(const ColProgram *__restrict__ cp, u
 }
 
 // summary record and (optionally) the path of one read, from the reversed path in `rev`
+template <class Rev>
 __device__ __forceinline__ void col_emit_outputs(const ColArgs &g, const uint32_t flags, const DevModel &M, const int r,
-                                                 const uint8_t *__restrict__ seq, const int n, const int32_t *__restrict__ rev,
+                                                 const uint8_t *__restrict__ seq, const int n, const Rev &rev,
                                                  const int len_walked, const int lane)
 {
     // the reference's path buffer holds n + m entries (hmm.pyx:1953, written without a bound check): a longer path is
@@ -786,7 +787,7 @@ __device__ __forceinline__ void col_emit_outputs(const ColArgs &g, const uint32_
         int olen = len;
         if (len > cap) olen = -2;
         if (olen > 0)
-            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev[len - 1 - i];
+            for (int i = lane; i < len; i += 64) g.a.out_path[o0 + i] = rev_get(rev, len - 1 - i);
         if (lane == 0) g.a.out_path_len[r] = olen;
     }
     __builtin_amdgcn_wave_barrier();

@@ -42,6 +42,7 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 #define ROWS_MAX_READ 155           // longest read any configuration takes
 #define ROWS_MAX_GROUPS 4
 #define ROWS_STASH_BYTES (COL_WAVES * ROWS_DEPTH * ROWS_MAX_GROUPS * 16)     // LDS behind the tables (viterbi_rows_kernel)
+#define ROWS_REV_BYTES (COL_WAVES * REV_LDS_ENTRIES * 2)                    // ... and behind that the wavefronts' reversed paths (path_summary.h: RevLds)
 // Back-to-back sweeps: a wavefront's lane groups take up to ROWS_DEPTH reads each, one behind the other ALONG THE STEP AXIS.
 // When a lane has done the last column of its group's kth read it starts column 0 of read k + 1 on the next step -- the
 // neighbouring lanes follow one step later each, exactly as at the start of a sweep -- so the W - 1 steps a sweep spends
@@ -402,13 +403,13 @@ __device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ s
 
 // tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group; col0 = the steps
 // the read's sweep began after (k * NC for the kth read of a back-to-back sweep)
-template <int R>
+template <int R, class Rev>
 __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
                                                  const LdsTables &L, const DevModel &M, const int r,
                                                  const uint8_t *__restrict__ seq, const int n, double *final_row,
                                                  double *tailv, const unsigned *__restrict__ bpw, const int lane0,
                                                  int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
-                                                 int32_t *__restrict__ rev, const int lane, const int col0)
+                                                 const Rev &rev, const int lane, const int col0)
 {
     const int NC = cp->n_cols;
     // (ADVNTR_BUDGET_*: builds that leave one piece of the finish phase out -- wrong results, made only by scripts/budget_finish.sh
@@ -456,7 +457,11 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
     double *rown = g.rown + gw * g.rown_stride;
     int32_t *aux = g.aux + gw * g.aux_stride;
     int32_t *tailwin = aux;
-    int32_t *rev = g.a.path_scratch + gw * g.a.path_cap;
+    // the reversed path of the read being finished: its first REV_LDS_ENTRIES states in this wavefront's piece of LDS (behind the
+    // stash), the rest -- longer paths are rare -- in the wavefront's path scratch
+    const RevLds rev{(__attribute__((address_space(3))) unsigned short *)(size_t)lds_addr(lds + 16 + g.lds_tables + ROWS_STASH_BYTES) +
+                         wave * REV_LDS_ENTRIES,
+                     g.a.path_scratch + gw * g.a.path_cap};
     const int grp = lane / W, lp = lane - grp * W;
     int cur_model = -1;
     bool padded = false;
