@@ -86,7 +86,7 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     g.sink_stride = cl.sink_stride;
     g.rows_depth = cl.rows_depth;
     const int grid = launch_grid(cl, g.n_tiles);
-    const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES + ROWS_REV_BYTES;
+    const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);

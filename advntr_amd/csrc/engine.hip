@@ -819,14 +819,14 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
         // workgroups per CU are bounded by LDS (4 waves each; 1 workgroup per CU = 1 wave per SIMD): wide models (PacBio:
         // > 1000 columns) leave the traceback's state table, then the unpadded column-info table, in HBM/L2 when
         // that buys another resident workgroup
-        auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES) + 1024))); };
+        auto wgs = [](size_t lds) { return (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / (lds + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES) + 1024))); };
         C.lds_core_bytes = lds_core; C.lds_min_bytes = lds_min;
         if (wgs(lds_core) > wgs(C.lds_bytes)) { C.lds_bytes = lds_core; C.lds_level = 1; }
         if (wgs(lds_min) > wgs(C.lds_bytes)) { C.lds_bytes = lds_min; C.lds_level = 0; }
         // (one workgroup per CU either way: still take the level that fits at all)
-        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES) > 160 * 1024 && C.lds_level > 1 && lds_core + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES) <= 160 * 1024) { C.lds_bytes = lds_core; C.lds_level = 1; }
-        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES) > 160 * 1024 && C.lds_level > 0) { C.lds_bytes = lds_min; C.lds_level = 0; }
-        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES) > 160 * 1024)
+        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES) > 160 * 1024 && C.lds_level > 1 && lds_core + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES) <= 160 * 1024) { C.lds_bytes = lds_core; C.lds_level = 1; }
+        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES) > 160 * 1024 && C.lds_level > 0) { C.lds_bytes = lds_min; C.lds_level = 0; }
+        if (C.lds_bytes + 16 + (ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES) > 160 * 1024)
             return fail(ADVNTR_ERR_TOO_LARGE, "batch: the class / emission tables of a %d-column model take %zu B of LDS "
                         "(> 160 KiB per CU)", C.nc_max, C.lds_bytes + 16);
         int per_cu = wgs(C.lds_bytes);

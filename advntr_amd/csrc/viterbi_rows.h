@@ -43,6 +43,7 @@ static const RowsConfig rows_configs[ROWS_CONFIGS] = {{5, 2, 5 * 31}, {4, 2, 4 *
 #define ROWS_MAX_GROUPS 4
 #define ROWS_STASH_BYTES (COL_WAVES * ROWS_DEPTH * ROWS_MAX_GROUPS * 16)     // LDS behind the tables (viterbi_rows_kernel)
 #define ROWS_REV_BYTES (COL_WAVES * REV_LDS_ENTRIES * 2)                    // ... and behind that the wavefronts' reversed paths (path_summary.h: RevLds)
+#define ROWS_TAIL_LDS_BYTES (COL_WAVES * COL_MAX_TAIL * 12)                 // ... and the tail states' values and winners of the read being finished
 // Back-to-back sweeps: a wavefront's lane groups take up to ROWS_DEPTH reads each, one behind the other ALONG THE STEP AXIS.
 // When a lane has done the last column of its group's kth read it starts column 0 of read k + 1 on the next step -- the
 // neighbouring lanes follow one step later each, exactly as at the start of a sweep -- so the W - 1 steps a sweep spends
@@ -456,7 +457,10 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
     unsigned *bpw = (unsigned *)(g.bp + gw * g.bp_stride);
     double *rown = g.rown + gw * g.rown_stride;
     int32_t *aux = g.aux + gw * g.aux_stride;
-    int32_t *tailwin = aux;
+    // the tail states' values and winning in-edges of the read being finished: in LDS as well (col_tail writes one of each per tail
+    // state and waits for it -- a round trip to HBM per tail state and read when they sat in the wavefront's scratch there)
+    double *tailv = (double *)(lds + 16 + g.lds_tables + ROWS_STASH_BYTES + ROWS_REV_BYTES) + wave * COL_MAX_TAIL;
+    int32_t *tailwin = (int32_t *)(lds + 16 + g.lds_tables + ROWS_STASH_BYTES + ROWS_REV_BYTES + COL_WAVES * COL_MAX_TAIL * 8) + wave * COL_MAX_TAIL;
     // the reversed path of the read being finished: its first REV_LDS_ENTRIES states in this wavefront's piece of LDS (behind the
     // stash), the rest -- longer paths are rare -- in the wavefront's path scratch
     const RevLds rev{(__attribute__((address_space(3))) unsigned short *)(size_t)lds_addr(lds + 16 + g.lds_tables + ROWS_STASH_BYTES) +
@@ -486,7 +490,6 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
         // ahead of and past their reads); the tail values of the read being finished sit behind the groups
         const int dmax = NC >= ROWS_STREAM_MIN_COLS ? g.rows_depth : 1;       // (the deepest tile of the launch: the scratch is laid out for it)
         const int64_t grp_doubles = 3 * ((int64_t)dmax * NC + 2 * W);
-        double *tailv = rown + G * grp_doubles;
         // a round: every wavefront takes up to dmax reads per lane group; read (k, group) of wave w is the tile's read
         // j0 + (k * COL_WAVES + w) * G + group
         for (int j0 = 0; j0 < tile.count; j0 += COL_WAVES * G * dmax) {
