@@ -39,7 +39,9 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 // counter as the traceback's back-pointer gathers, so every round of the walk also waited for the previous round's stores to
 // reach memory (a build without the stores: REF150 launch 8.62 -> 8.38 ms, S300 2.64 -> 2.54 ms); an LDS store does not, and the
 // summary pass that follows reads the path back from LDS as well.
-#define REV_LDS_ENTRIES 512
+#ifndef REV_LDS_ENTRIES
+#define REV_LDS_ENTRIES 512       // (a build with 64 runs the parity suite through the spill-over into device memory)
+#endif
 struct RevLds {
     __attribute__((address_space(3))) unsigned short *lds;
     int32_t *mem;
