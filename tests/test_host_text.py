@@ -87,3 +87,33 @@ def test_builder_exp_routes_agree():
     assert all(np.array_equal(a, b) for a, b in zip(by["numpy"], by["numpy-callback"]))
     worst = max(float(np.max(np.abs(a - b)[np.isfinite(a)] / np.spacing(np.abs(b[np.isfinite(a)])))) for a, b in zip(by["libm"], by["numpy"]))
     assert worst <= 4
+
+
+def test_host_threads_follow_the_cpu_quota_and_the_override():
+    """advntr_host_threads: what the bulk host-side calls use when asked for 0 threads -- the hardware threads cut down to the
+    control group's CPU quota (a container on a big host is given a few cores; more worker threads than that have the whole
+    process stopped by the scheduler for the rest of every accounting period), ADVNTR_HOST_THREADS overriding."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as e; e.build()\n"
+            "from advntr_amd import _lib\nprint('threads', _lib.load().advntr_host_threads())\n" % ROOT)
+
+    def ask(env):
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, check=True, timeout=600).stdout.decode()
+        return int(out.split("threads")[-1])
+    plain = {k: v for k, v in os.environ.items() if k != "ADVNTR_HOST_THREADS"}
+    n = ask(plain)
+    assert 1 <= n <= (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = -(-int(q) // int(period))
+    except (OSError, ValueError):
+        pass
+    if quota:
+        assert n <= quota
+    assert ask(dict(plain, ADVNTR_HOST_THREADS="5")) == 5
+    assert ask(dict(plain, ADVNTR_HOST_THREADS="junk")) == n
