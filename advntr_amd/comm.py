@@ -160,6 +160,48 @@ class HostComm(object):
         self.rdzv.close()
 
 
+class InitWatchdog(object):
+    """Stands beside a rank while it is inside ncclCommInitRank -- a collective that returns when ALL ranks have entered it
+    and cannot be called back.  Ends the PROCESS (exit status 70) when the call has not returned after `timeout` seconds, and
+    at once (status 71) when a peer has left an abort marker in the rendezvous directory: a rank whose own ncclCommInitRank
+    failed (init_from_env writes `abort.<rank>`) -- its peers would otherwise sit in the collective until their timeouts.
+    `on_end(status, message)` replaces the exit in tests."""
+
+    def __init__(self, directory, rank, timeout, on_end=None, poll=0.25):
+        import threading
+        self._dir, self._rank, self._timeout, self._poll = directory, rank, float(timeout), float(poll)
+        self._on_end = on_end or self._exit
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, name="advntr-init-watchdog", daemon=True)
+        self._thread.start()
+
+    @staticmethod
+    def _exit(status, message):
+        import sys
+        sys.stderr.write(message + "\n")
+        sys.stderr.flush()
+        os._exit(status)
+
+    def _run(self):
+        t0 = time.monotonic()
+        while not self._stop.wait(self._poll):
+            try:
+                gone = sorted(f for f in os.listdir(self._dir) if f.startswith("abort."))
+            except OSError:
+                gone = []
+            if gone:
+                self._on_end(71, "advntr_amd.comm: rank %d: a peer could not create its communicator (%s); ending this process"
+                             % (self._rank, ", ".join(gone)))
+                return
+            if time.monotonic() - t0 > self._timeout:
+                self._on_end(70, "advntr_amd.comm: rank %d: ncclCommInitRank did not return within %.0f s (a peer is gone?); "
+                             "ending this process" % (self._rank, self._timeout))
+                return
+
+    def cancel(self):
+        self._stop.set()
+
+
 class CommSetupError(RuntimeError):
     """RCCL cannot be used by this job; raised on every rank alike, before any of them entered a collective."""
 
@@ -198,17 +240,7 @@ class RcclComm(HostComm):
             raise CommSetupError(reason)
         if init_timeout is None:
             init_timeout = float(os.environ.get("ADVNTR_COMM_INIT_TIMEOUT", "180"))
-        import sys
-        import threading
-
-        def give_up():
-            sys.stderr.write("advntr_amd.comm: rank %d: ncclCommInitRank did not return within %.0f s (a peer is gone?); "
-                             "ending this process\n" % (self.rank, init_timeout))
-            sys.stderr.flush()
-            os._exit(70)
-        watchdog = threading.Timer(init_timeout, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        watchdog = InitWatchdog(rdzv.dir, self.rank, init_timeout)
         try:
             self._h = L.advntr_comm_create(self.rank, self.world, blob)
         finally:
@@ -316,6 +348,10 @@ def init_from_env(backend=None, set_device=True):
     except CommSetupError as e:     # raised on every rank alike: nobody is inside a collective
         err = str(e).encode("utf-8", "replace")
     except Exception as e:          # noqa: BLE001 -- past the agreed stage: no collective fallback, no waiting for the others
+        try:
+            rdzv.put("abort.%d" % rank, str(e).encode("utf-8", "replace"))      # the peers' watchdogs end them at once
+        except OSError:
+            pass
         raise RuntimeError("rank %d: RCCL communicator could not be created after every rank had agreed to (%s); the other "
                            "ranks are inside ncclCommInitRank and end with the job" % (rank, e)) from e
     failures = [x for x in rdzv.allgather(err) if x]

@@ -346,3 +346,35 @@ def test_host_gather_results_with_a_rank_that_holds_no_reads(tmp_path):
 def test_run_sharded_carries_rows_as_json_not_pickle():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "advntr_amd", "sharding.py")).read()
     assert "pickle" not in src
+
+
+def test_init_watchdog_ends_a_rank_whose_peer_left_an_abort_marker(tmp_path):
+    """A rank inside ncclCommInitRank cannot be called back: its watchdog ends the process when the call outlives its timeout
+    (status 70) and -- at once -- when a peer whose own communicator failed has left `abort.<rank>` in the rendezvous directory
+    (status 71), instead of after the timeout."""
+    import time
+    from advntr_amd import comm
+    d = tmp_path / "rdzv"
+    d.mkdir(mode=0o700)
+    got = []
+    w = comm.InitWatchdog(str(d), 1, timeout=30.0, on_end=lambda status, msg: got.append((status, msg)), poll=0.02)
+    time.sleep(0.1)
+    assert got == []                                            # nothing wrong yet
+    comm.FileRendezvous(0, 2, str(d)).put("abort.0", b"hipErrorInvalidDevice")
+    t0 = time.monotonic()
+    while not got and time.monotonic() - t0 < 5:
+        time.sleep(0.01)
+    w.cancel()
+    assert got and got[0][0] == 71 and "abort.0" in got[0][1] and time.monotonic() - t0 < 2
+    got2 = []
+    d2 = tmp_path / "rdzv2"
+    d2.mkdir(mode=0o700)
+    w2 = comm.InitWatchdog(str(d2), 0, timeout=0.1, on_end=lambda status, msg: got2.append(status), poll=0.02)
+    time.sleep(0.5)
+    w2.cancel()
+    assert got2 == [70]
+    quiet = []
+    w3 = comm.InitWatchdog(str(d2), 0, timeout=30.0, on_end=lambda status, msg: quiet.append(status), poll=0.02)
+    w3.cancel()                                                 # the call returned in time: nobody is ended
+    time.sleep(0.1)
+    assert quiet == []
