@@ -860,6 +860,9 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                 // long reads: fewer reads per tile so that a modest batch still spreads over all CUs
                 const int64_t nlen = read_off[r0 + 1] - read_off[r0];
                 if (nlen > 192) cap = std::max<int>(COL_WAVES, std::min<int64_t>(cap, COL_TILE_READS * 192 / nlen));
+                // (the tiled row-blocked kernel: one read per wavefront and tile -- a tile of ten 300-base reads is three reads in a
+                // row for two of its wavefronts, and with the cheapest tiles going out last those were the 2 ms at the end of a launch)
+                if (bucket == 3) cap = COL_WAVES;
                 if (bucket < 3) {
                     // G reads per wavefront side by side and up to ROWS_DEPTH one behind the other (back-to-back sweeps,
                     // viterbi_rows.h): full-depth tiles while most of the batch is still ahead, then half depth, then
@@ -884,14 +887,25 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             // long reads, one per wavefront: the tiles of a launch differ by an order of magnitude in work (columns x rows of
             // their longest read, which is the first one) -- heaviest first, so that what the dynamic dequeue hands out last is
             // small (in model order the launch ended on whatever came last: 4 ms of 200 on BASELINE config 4)
+            // The order is by what a tile COSTS, not by its trellis cells: a read is swept in row tiles of 64 x 5 rows, each of
+            // NC + 63 steps whatever it holds, the last one with as few rows per lane as cover it; a step costs a fixed part (about
+            // 0.7 of a row's) plus its rows.  By cells a 321-row read ranks next to a 320-row one and takes a third longer.
+            // (Round 5, per-workgroup clocks of a 22 400-call share: with tiles of up to ten short reads its workgroups ended over
+            // 2 ms, mean idle 4.4 % of the launch; one read per wavefront and tile + this order: over 0.6 ms, 1.3 %.  The short
+            // reads' sweep tiles stay in model order: a set's models are all within 450-550 columns, and the sorted order measured
+            // 2.5 % slower -- neighbouring tiles no longer share a model in L2.)
+            auto tile_cost = [&](const ColTile &t, const int slot) -> double {
+                const int r = col_reads[(size_t)t.first];
+                const int64_t n = read_off[r + 1] - read_off[r];
+                const double nc = (double)B->models[t.model]->colprog.n_cols;
+                if (slot != 8) return nc * (double)n;
+                const int64_t RT = 64 * ROWS_LONG_R, full = (n - 1) / RT, last_rows = n - full * RT;
+                const double rl_last = (double)((last_rows + 63) / 64);
+                return (nc + 63.0) * ((double)full * (0.7 + ROWS_LONG_R) + 0.7 + rl_last) + 0.02 * (double)n * 64.0;      // (+ the traceback: ~ n rounds)
+            };
             for (int k : {4, 8})
-                std::stable_sort(C.tiles[k].begin(), C.tiles[k].end(), [&](const ColTile &x, const ColTile &y) {
-                    auto work = [&](const ColTile &t) {
-                        const int r = col_reads[(size_t)t.first];
-                        return (int64_t)B->models[t.model]->colprog.n_cols * (read_off[r + 1] - read_off[r]);
-                    };
-                    return work(x) > work(y);
-                });
+                std::stable_sort(C.tiles[k].begin(), C.tiles[k].end(),
+                                 [&](const ColTile &x, const ColTile &y) { return tile_cost(x, k) > tile_cost(y, k); });
             const int kmax = std::min(4, (n_max_col + 63) / 64);
             const int TL = 64 * COL_LONG_K;
             // (the anti-diagonal kernel's row-tiled slabs only when some read really goes there: by default longer reads take
