@@ -1154,6 +1154,18 @@ extern "C" int advntr_batch_reserve_next(advntr_batch *B, int32_t n_workgroups)
     return ADVNTR_OK;
 }
 
+#ifdef ADVNTR_WG_CLOCKS
+// measurement build only (viterbi_rows.h, WG_CLOCKS_*): the four clocks of every workgroup of the last row-blocked launch
+extern "C" int advntr_debug_wg_clocks(advntr_batch *B, unsigned long long *out, int cap)
+{
+    HIP_TRY(hipStreamSynchronize(B->stream));
+    const int n = std::min(cap, B->col.grid);
+    for (int w = 0; w < n; ++w)
+        HIP_TRY(hipMemcpy(out + 4 * w, B->col.d_rown + (int64_t)w * COL_WAVES * B->col.rown_stride, 32, hipMemcpyDeviceToHost));
+    return n;
+}
+#endif
+
 extern "C" int advntr_batch_sync(advntr_batch *B)
 {
     if (!B) return fail(ADVNTR_ERR_ARG, "advntr_batch_sync: null batch");

@@ -439,6 +439,26 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
 #endif
 }
 
+// Measurement build only (scripts/build_variant.sh wgclocks -DADVNTR_WG_CLOCKS, scripts/wg_clocks.py): every workgroup leaves when
+// it started, when it took its last tile, when it ended and how many tiles it ran at the head of its first wavefront's row
+// scratch (s_memrealtime, 100 MHz) -- how evenly the dynamic dequeue ends a launch.  The shipped build compiles none of it.
+#ifdef ADVNTR_WG_CLOCKS
+#define WG_CLOCKS_BEGIN()                                                                                                          \
+    const unsigned long long wgc_t0 = __builtin_amdgcn_s_memrealtime();                                                            \
+    unsigned long long wgc_last = wgc_t0;                                                                                          \
+    int wgc_tiles = 0
+#define WG_CLOCKS_TILE() (++wgc_tiles, wgc_last = __builtin_amdgcn_s_memrealtime())
+#define WG_CLOCKS_END(g, tid)                                                                                                      \
+    if ((tid) == 0) {                                                                                                              \
+        unsigned long long *wgc = (unsigned long long *)((g).rown + (int64_t)blockIdx.x * COL_WAVES * (g).rown_stride);            \
+        wgc[0] = wgc_t0, wgc[1] = __builtin_amdgcn_s_memrealtime(), wgc[2] = wgc_last, wgc[3] = (unsigned long long)wgc_tiles;     \
+    }
+#else
+#define WG_CLOCKS_BEGIN() ((void)0)
+#define WG_CLOCKS_TILE() ((void)0)
+#define WG_CLOCKS_END(g, tid) ((void)0)
+#endif
+
 template <int R, int G>
 __global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
 viterbi_rows_kernel(ColArgs g, uint32_t flags)
@@ -472,12 +492,17 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
     LdsTables L{};
     const ColProgram *cp = nullptr;
     DevModel M{};
+    WG_CLOCKS_BEGIN();
     for (;;) {
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);
-        if (ti >= g.n_tiles) break;
+        if (ti >= g.n_tiles) {
+            WG_CLOCKS_END(g, tid);
+            break;
+        }
+        WG_CLOCKS_TILE();
         const ColTile tile = g.tiles[ti];
         if (tile.model != cur_model) {
             cur_model = tile.model;
@@ -590,12 +615,17 @@ viterbi_rows_long_kernel(ColArgs g, uint32_t flags)
     LdsTables L{};
     const ColProgram *cp = nullptr;
     DevModel M{};
+    WG_CLOCKS_BEGIN();
     for (;;) {
         __syncthreads();
         if (tid == 0) *tile_slot = atomicAdd(g.tile_counter, 1);
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(*tile_slot);
-        if (ti >= g.n_tiles) break;
+        if (ti >= g.n_tiles) {
+            WG_CLOCKS_END(g, tid);
+            break;
+        }
+        WG_CLOCKS_TILE();
         const ColTile tile = g.tiles[ti];
         if (tile.model != cur_model) {
             cur_model = tile.model;
