@@ -164,6 +164,30 @@ struct Key32 {
     bool operator<(const Key32 &o) const { return memcmp(w, o.w, sizeof w) < 0; }
 };
 
+// The compiler's temporaries, kept per thread across models (a bulk upload compiles thousands of them: from the general
+// allocator these were ~3 000 small allocations per model -- the successor lists alone one per state).
+struct Scratch {
+    std::vector<int> outdeg, out_ptr, out_dst, pos, backbone, colI, colM, colOf, slotOf, feed_sink, ks, tail_idx;
+    std::vector<char> selfloop, live, dead, tail;
+    std::vector<ColClass> percol;
+    std::vector<ColState> st;
+    std::vector<uint16_t> flags;
+    std::vector<double> fwd_mx;
+    std::vector<int32_t> chash, ehash, phash;            // open addressing: index of the class / emission row / pair, -1 = empty
+    std::vector<std::pair<int, int>> pairs;
+};
+
+static inline uint64_t hash_words(const void *p, int n_words)
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull, w;
+    for (int i = 0; i < n_words; ++i) {
+        memcpy(&w, (const char *)p + 8 * i, 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
 }  // namespace colprog_detail
 
 // Model view the builder needs (engine.hip's advntr_hmm satisfies it; tests can pass their own).
@@ -183,9 +207,13 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     if (S < 2 || P < 1) return fail("too few states");
     if (m > 65000) return fail("too many states");
 
+    static thread_local Scratch scratch;
+    Scratch &W = scratch;
     // out-degree, self loops
-    std::vector<int> outdeg(m, 0);
-    std::vector<char> selfloop(m, 0);
+    std::vector<int> &outdeg = W.outdeg;
+    std::vector<char> &selfloop = W.selfloop;
+    outdeg.assign(m, 0);
+    selfloop.assign(m, 0);
     for (int l = 0; l < m; ++l)
         for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) {
             outdeg[in_src[k]]++;
@@ -247,31 +275,46 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     }
 
     // ---- reachable from an emitting state (=> may be alive in rows >= 1)
-    std::vector<char> live(m, 0);
+    std::vector<char> &live = W.live;
+    live.assign(m, 0);
     for (int l = 0; l < P; ++l) live[l] = 1;
     for (int l = P; l < m; ++l)
         for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k)
             if (live[in_src[k]]) live[l] = 1;
 
     // ---- dead ends and tail: silent states whose every out-edge leads to the end through silent states only
-    std::vector<std::vector<int>> outs(m);
-    for (int l = 0; l < m; ++l)
-        for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) outs[in_src[k]].push_back(l);
-    std::vector<char> dead(m, 0), tail(m, 0);
+    // (successor lists as one CSR: out_dst[out_ptr[l] .. out_ptr[l + 1]) in increasing destination order)
+    std::vector<int> &out_ptr = W.out_ptr, &out_dst = W.out_dst;
+    out_ptr.assign(m + 1, 0);
+    for (int l = 0; l < m; ++l) out_ptr[l + 1] = out_ptr[l] + outdeg[l];
+    out_dst.resize((size_t)out_ptr[m]);
+    {
+        std::vector<int> &fill = W.ks;
+        fill.assign(out_ptr.begin(), out_ptr.end() - 1);
+        for (int l = 0; l < m; ++l)
+            for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) out_dst[(size_t)fill[in_src[k]]++] = l;
+    }
+    std::vector<char> &dead = W.dead, &tail = W.tail;
+    dead.assign(m, 0);
+    tail.assign(m, 0);
     tail[H.end] = 1;
     if (H.end < P) return fail("end state is emitting");
     for (int l = m - 1; l >= P; --l) {
         if (l == H.end) continue;
         if (outdeg[l] == 0) { dead[l] = 1; continue; }
         bool all = true;
-        for (int d : outs[l])
+        for (int q = out_ptr[l]; q < out_ptr[l + 1]; ++q) {
+            const int d = out_dst[(size_t)q];
             if (!(d >= P && (tail[d] || dead[d]))) all = false;
+        }
         if (all) tail[l] = 1;
     }
     if (outdeg[H.end] != 0) return fail("end state has out-edges");
 
     // ---- backbone columns
-    std::vector<int> pos(m, -1), backbone;
+    std::vector<int> &pos = W.pos, &backbone = W.backbone;
+    pos.assign(m, -1);
+    backbone.clear();
     for (int l = P; l < m; ++l)
         if (!dead[l] && !tail[l]) { pos[l] = (int)backbone.size(); backbone.push_back(l); }
     const int NC = (int)backbone.size();
@@ -282,7 +325,11 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
             for (int k = in_ptr[l]; k < in_ptr[l + 1]; ++k) (void)k;   // edges into dead ends are ignored
 
     // ---- emitting states -> (column, slot)
-    std::vector<int> colI(NC, -1), colM(NC, -1), colOf(m, -1), slotOf(m, -1);
+    std::vector<int> &colI = W.colI, &colM = W.colM, &colOf = W.colOf, &slotOf = W.slotOf;
+    colI.assign(NC, -1);
+    colM.assign(NC, -1);
+    colOf.assign(m, -1);
+    slotOf.assign(m, -1);
     for (int u = 0; u < P; ++u) {
         int bmax = -1;
         for (int k = in_ptr[u]; k < in_ptr[u + 1]; ++k) {
@@ -309,11 +356,17 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     for (int c = 0; c < NC; ++c) { colOf[backbone[c]] = c; slotOf[backbone[c]] = 2; }
 
     // ---- per column parameters, validating every in-edge against the stencil order
-    std::vector<ColClass> percol(NC);
-    std::vector<ColState> st(NC);
-    std::vector<uint16_t> flags(NC, 0);
-    std::vector<int> feed_sink(NC, -1);
-    std::vector<double> fwd_mx(NC, NINF);
+    std::vector<ColClass> &percol = W.percol;
+    std::vector<ColState> &st = W.st;
+    std::vector<uint16_t> &flags = W.flags;
+    std::vector<int> &feed_sink = W.feed_sink;
+    std::vector<double> &fwd_mx = W.fwd_mx;
+    percol.assign(NC, ColClass{});
+    st.assign(NC, ColState{});
+    flags.assign(NC, 0);
+    feed_sink.assign(NC, -1);
+    fwd_mx.assign(NC, NINF);
+    std::vector<int> &ks = W.ks;
     int n_sinks = 0;
     for (int c = 0; c < NC; ++c) {
         ColClass &T = percol[c];
@@ -362,7 +415,6 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
         // backbone state
         {
             const int l = backbone[c];
-            std::vector<int> ks;
             rlist(l, ks);
             bool stencil = true;
             int stage = -1;
@@ -432,13 +484,13 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     // the sink takes ONLY the accumulator, so check sinks have no stencil edges (true by construction).
 
     // ---- tail states (evaluated at the last row only), index order
-    std::map<int, int> tail_idx;
+    std::vector<int> &tail_idx = W.tail_idx;             // per state: its index among the tail states
+    tail_idx.assign(m, 0);
     out.tail_ptr.push_back(0);
     for (int l = P; l < m; ++l) {
         if (!tail[l]) continue;
         tail_idx[l] = (int)out.tail_state.size();
         out.tail_state.push_back(l);
-        std::vector<int> ks;
         rlist(l, ks);
         for (int k : ks) {
             const int s = in_src[k];
@@ -455,27 +507,36 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     out.end_tail = tail_idx[H.end];
 
     // ---- class tables (bit-exact de-duplication)
-    std::map<Key96, int> cmap;
-    std::map<Key32, int> emap;
+    // (ids in order of first appearance; open addressing on the bit patterns, at most 2 (NC + 2) + 2 entries per table)
+    size_t hsize = 64;
+    while (hsize < 4 * ((size_t)NC + 4)) hsize *= 2;
+    const size_t hmask = hsize - 1;
+    W.chash.assign(hsize, -1);
+    W.ehash.assign(hsize, -1);
+    static_assert(sizeof(Key96) == 88 && sizeof(Key96) <= sizeof(ColClass), "class key: the first 88 bytes of a ColClass");
     auto class_of = [&](const ColClass &T) {
-        Key96 key;
-        memcpy(key.w, &T, sizeof key.w);
-        auto it = cmap.find(key);
-        if (it != cmap.end()) return it->second;
+        size_t h = (size_t)hash_words(&T, 11) & hmask;
+        for (;; h = (h + 1) & hmask) {
+            const int32_t id = W.chash[h];
+            if (id < 0) break;
+            if (memcmp(&out.classes[(size_t)id], &T, sizeof(Key96)) == 0) return (int)id;
+        }
         const int id = (int)out.classes.size();
         out.classes.push_back(T);
-        cmap[key] = id;
+        W.chash[h] = id;
         return id;
     };
     auto eclass_of = [&](const double *e4) {
-        Key32 key;
-        memcpy(key.w, e4, sizeof key.w);
-        auto it = emap.find(key);
-        if (it != emap.end()) return it->second;
+        size_t h = (size_t)hash_words(e4, 4) & hmask;
+        for (;; h = (h + 1) & hmask) {
+            const int32_t id = W.ehash[h];
+            if (id < 0) break;
+            if (memcmp(&out.emis[(size_t)id * COL_EMIS_STRIDE], e4, 32) == 0) return (int)id;
+        }
         const int id = (int)(out.emis.size() / COL_EMIS_STRIDE);
         out.emis.insert(out.emis.end(), e4, e4 + 4);
         out.emis.push_back(NINF);        // 5th slot: the emission of a padding row (viterbi_rows.h)
-        emap[key] = id;
+        W.ehash[h] = id;
         return id;
     };
     ColClass none{};
@@ -503,14 +564,21 @@ static inline bool build_column_program(const Model &H, ColProgramHost &out)
     }
     if (out.classes.size() > 60000 || out.emis.size() / COL_EMIS_STRIDE > 60000) return fail("class table overflow");
     {   // emission pair classes: distinct (emM, emI) combinations of the columns
-        std::map<std::pair<int, int>, int> pmap;
-        std::vector<std::pair<int, int>> pairs;
+        std::vector<std::pair<int, int>> &pairs = W.pairs;
+        pairs.clear();
+        W.phash.assign(hsize, -1);
         out.pair_of_col.resize(NC + 2);
         for (int cc = 0; cc < NC + 2; ++cc) {
             const std::pair<int, int> key(out.info[cc].emM, out.info[cc].emI);
-            auto it = pmap.find(key);
-            if (it == pmap.end()) { it = pmap.emplace(key, (int)pairs.size()).first; pairs.push_back(key); }
-            out.pair_of_col[cc] = (uint16_t)it->second;
+            size_t h = (size_t)(((uint64_t)key.first << 16 | (uint64_t)key.second) * 0x9e3779b97f4a7c15ull >> 40) & hmask;
+            int found = -1;
+            for (;; h = (h + 1) & hmask) {
+                const int32_t id = W.phash[h];
+                if (id < 0) break;
+                if (pairs[(size_t)id] == key) { found = id; break; }
+            }
+            if (found < 0) { found = (int)pairs.size(); pairs.push_back(key); W.phash[h] = found; }
+            out.pair_of_col[cc] = (uint16_t)found;
         }
         out.n_epair = (int32_t)pairs.size();
         out.epair.assign((size_t)COL_EPAIR_SYMBOLS * pairs.size() * 2, NINF);
