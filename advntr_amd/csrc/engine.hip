@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -82,10 +83,18 @@ struct DeviceCaches {
             }
         }
         void *p = nullptr;
+#ifdef ADVNTR_TRACE_ALLOC
+        const auto t_alloc = std::chrono::steady_clock::now();
+#endif
         if (hipMalloc(&p, bytes) != hipSuccess) {
             trim(dev);                                  // cached blocks may be what is missing
             if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         }
+#ifdef ADVNTR_TRACE_ALLOC
+        fprintf(stderr, "[alloc] hipMalloc %zu B: %.2f ms (at %.1f ms)\n", bytes,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count(),
+                std::chrono::duration<double, std::milli>(t_alloc.time_since_epoch()).count());
+#endif
         *got = bytes;
         return p;
     }

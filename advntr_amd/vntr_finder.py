@@ -297,7 +297,7 @@ class _Aborted(Exception):
 
 
 def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False,
-                            compute_reverse=True, chunks=8, threads=0, timings=None):
+                            compute_reverse=True, chunks=16, threads=0, timings=None, stage_threads=None, ramp=4):
     """genotype_loci from the locus DESCRIPTIONS -- loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...], what
     the reference turns into a model per locus inside its serial loop (genome_analyzer.py:280-297 -> vntr_finder.py:117-138) --
     with the host stages overlapped with the device's.  The locus set is cut into `chunks` pieces that flow through a
@@ -306,13 +306,19 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     piece's kernels (both strands, reverse complements made on the device) and has the reads selected on the device (strand
     choice, recruit rule, more than two repeat bases: advntr_batch_recruit), so that only the selected reads' records come
     back.  The per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results
-    as genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage."""
+    as genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage.
+    ramp: the first piece goes in `ramp` parts, so that the device starts after a small piece's host work instead of a full
+    one's; stage_threads = (build, upload, encode) host threads of the three threaded stages."""
     import threading
     import time
     from . import hmm_utils
     n_loci = len(loci)
     chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
+    if ramp and ramp > 1 and chunks > 1 and cuts[1] >= ramp:
+        # the first piece in `ramp` parts: the device starts on a small piece while the host is still building the rest
+        cuts = [cuts[1] * i // ramp for i in range(ramp)] + cuts[1:]
+        chunks = len(cuts) - 1
     T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, bind_batch=0.0, score_recruit=0.0, aggregate_genotype=0.0)
     if timings is not None and "trace" in timings:
         T["trace"] = []                             # (stage, piece, start, end) of every stage call: scripts/host_profile.py
@@ -328,41 +334,68 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
         return models, prep, _lib.DeviceBatch(device_models(models), prep["bases"], prep["off"], prep["locus"],
                                               flags=_lib.FLAG_BOTH_STRANDS if compute_reverse else 0)
 
-    # every stage may use the CPUs this process may use (advntr_host_threads: the hardware threads cut down to the control
-    # group's quota -- 16 on the GPU boxes of this pool, where 32 or more threads per stage have the whole process stopped by
-    # the scheduler for the rest of every accounting period: 0.41 s at 16 threads per stage, 0.47 s at 32, 0.50 s at 64 or 128;
-    # splitting the quota between the stages -- 10 + 4 + 4 -- starves the table preparation of the upload: 0.55 s).  The host
-    # work of this run is ~8 core-seconds (model building 5, table preparation 1.5-2, read encoding 1): a quota of 16 cores
-    # bounds the run at ~0.4-0.5 s whatever the device does in its 0.17 s
+    # Host threads: the model builder may use the CPUs this process may use (advntr_host_threads: the hardware threads cut
+    # down to the control group's quota -- 16 on the GPU boxes of this pool), the upload's table preparation half and the read
+    # encoding (mostly the interpreter's own work on a million strings) a quarter of them.  The run burns ~2.3 core-seconds
+    # (round 5: model building 1.4, table preparation 0.45, encoding 0.17, the device thread 0.15), in bursts that exhaust the
+    # quota of a 100 ms accounting period early: the scheduler then stops EVERY thread of the process, the one that launches
+    # kernels included, until the period ends (scripts/e2e_timeline.py shows such a run: a piece's kernels "take" 35 ms instead
+    # of 9).  More threads per stage make that worse (32 per stage: +60 ms, round 4), fewer starve a stage.
     cpus = int(threads) if threads and threads > 0 else int(_lib.load().advntr_host_threads())
-    t_build = t_other = max(1, cpus)
+    t_build, t_other, t_enc = max(1, cpus), max(1, cpus // 2), max(1, cpus // 4)
+    if stage_threads:
+        t_build, t_other, t_enc = [max(1, int(x)) for x in stage_threads]
     t0 = time.perf_counter()
     built = _Stage("advntr-build", lambda k: hmm_utils.build_read_matcher_models(loci[cuts[k]:cuts[k + 1]], threads=t_build),
                    chunks, [], abort, (T, "build_models"))
     uploaded = _Stage("advntr-upload", upload, chunks, [built], abort, (T, "upload_models"))
-    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_other),), chunks, [], abort,
+    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_enc),), chunks, [], abort,
                      (T, "encode_reads"))
     bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
     stages = [built, uploaded, encoded, bound]
+    # what a scored piece leaves behind (its models' handles, the batch, the encoded reads) is dropped on a thread of its own:
+    # 840 models are 840 destructor calls, 3-20 ms that the calling thread would spend between two pieces' kernels
+    import queue
+    spent = queue.Queue()
+
+    def reap():
+        while spent.get() is not None:
+            pass
+
+    reaper = threading.Thread(target=reap, name="advntr-release", daemon=True)
+    reaper.start()
     parts = []
     try:
         for k in range(chunks):
+            tw = time.perf_counter()
             item = bound.out.get()
             if isinstance(item, BaseException):
                 raise item
             models, prep, batch = item
             t = time.perf_counter()
+            marks = [("wait", tw, t)]
             if batch is not None:
                 try:
                     batch.run()
+                    batch.sync()
+                    marks.append(("run", t, time.perf_counter()))
+                    t1 = time.perf_counter()
                     index, _, summ, _ = batch.recruit(None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]], 2)
+                    marks.append(("recruit", t1, time.perf_counter()))
                 finally:
+                    t1 = time.perf_counter()
                     batch.close()
+                    marks.append(("close", t1, time.perf_counter()))
                 parts.append((prep["locus"][index].astype(np.int64) + cuts[k], summ))
             T["score_recruit"] += time.perf_counter() - t
             if "trace" in T:
                 T["trace"].append(("score_recruit", k, t, time.perf_counter()))
-            del models, prep, batch, item           # the piece's models leave the device with their last reference
+            t1 = time.perf_counter()
+            spent.put((models, prep, batch, item))  # the piece's models leave the device with their last reference
+            del models, prep, batch, item
+            if "trace" in T:
+                marks.append(("release", t1, time.perf_counter()))
+                T["trace"] += [("  dev:" + nm, k, a, b) for nm, a, b in marks]
     finally:
         abort.set()                                 # (no stage is left waiting on a queue nobody serves any more)
         for st in stages:
@@ -372,12 +405,14 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
             left = bound.out.get_nowait()
             if isinstance(left, tuple) and left[2] is not None:
                 left[2].close()
+        spent.put(None)
     t = time.perf_counter()
     locus = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
     summ = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, _lib.SUMMARY_INTS), np.int32)
     bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
     out = find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
     T["aggregate_genotype"] = time.perf_counter() - t
+    reaper.join()
     T["total"] = time.perf_counter() - t0
     if timings is not None:
         timings.update(T)

@@ -1,5 +1,5 @@
 """Timeline of vntr_finder.genotype_loci_pipelined on the C2 set: when every stage call of every piece started and ended
-(ms from the start of the run), for 1, 4, 8 and 16 pieces.   python scripts/e2e_timeline.py [n_loci]"""
+(ms from the start of the run), for several piece plans.   python scripts/e2e_timeline.py [n_loci]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,11 +15,12 @@ import gc
 gc.collect(); gc.freeze()
 _lib.require_gpu()
 vntr_finder.genotype_loci_pipelined(desc[:64], cand[:64], chunks=2)
-for chunks in (8, 8, 4, 16):
+plans = [dict(chunks=8), dict(chunks=16, ramp=4), dict(chunks=16, ramp=4), dict(chunks=4), dict(chunks=16)]
+for i, plan in enumerate(plans):
     T = {"trace": None}
     t0 = time.perf_counter()
-    vntr_finder.genotype_loci_pipelined(desc, cand, chunks=chunks, timings=T)
-    print("chunks %d total %.3f s  %s" % (chunks, T["total"], {k: round(v, 3) for k, v in T.items() if k not in ("trace", "total")}))
-    if chunks == 8:
+    vntr_finder.genotype_loci_pipelined(desc, cand, timings=T, **plan)
+    print("%s total %.3f s  %s" % (plan, T["total"], {k: round(v, 3) for k, v in T.items() if k not in ("trace", "total")}))
+    if i in (0, 2):
         for st, k, a, b in sorted(T["trace"], key=lambda x: x[2]):
             print("   %-14s piece %2d  %7.1f -> %7.1f ms  (%.1f)" % (st, k, (a - t0) * 1e3, (b - t0) * 1e3, (b - a) * 1e3))

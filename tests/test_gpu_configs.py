@@ -321,9 +321,9 @@ def test_pipelined_genotyping_equals_stage_by_stage():
     cand[7] = cand[7][:3] + ["ACGTN" * 30] + cand[7][3:]   # dropped before scoring (vntr_finder.py:237)
     models = hmm_utils.build_read_matcher_models(desc)
     plain = vntr_finder.genotype_loci(models, cand)
-    for chunks in (1, 4, 64):
+    for chunks, extra in ((1, {}), (4, {}), (64, {}), (4, dict(ramp=0, stage_threads=(2, 1, 1))), (3, dict(ramp=9))):
         T = {}
-        piped = vntr_finder.genotype_loci_pipelined(desc, cand, chunks=chunks, timings=T)
+        piped = vntr_finder.genotype_loci_pipelined(desc, cand, chunks=chunks, timings=T, **extra)
         assert len(piped) == len(plain) == 37
         for a, b in zip(plain, piped):
             assert a.copy_numbers == b.copy_numbers
