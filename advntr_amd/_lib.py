@@ -67,6 +67,7 @@ SYMBOLS = {
     "advntr_encode_ascii": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "advntr_encode_texts": (ctypes.c_int, [_vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
+    "advntr_cut_pieces": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "advntr_genotype_observed": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _vp, _vp]),
@@ -702,15 +703,32 @@ def genotype_observed(ru_counts, locus_off, accuracy_filter=False, is_haploid=Fa
     return geno, prob
 
 
-def flank_align(reads, flanks, pair_read, pair_flank):
+def cut_pieces(codes, read_off, piece_read, begin, end, reverse, threads=0):
+    """advntr_cut_pieces: pieces [begin, end) of encoded reads (reverse-complemented where reverse is set) as reads of their
+    own -> (codes uint8, off int64)."""
+    n = len(piece_read)
+    pr = np.ascontiguousarray(piece_read, np.int32)
+    b = np.ascontiguousarray(begin, np.int64)
+    e = np.ascontiguousarray(end, np.int64)
+    rv = np.ascontiguousarray(reverse, np.uint8)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(e - b, out=off[1:])
+    out = np.empty(int(off[n]), np.uint8)
+    check(load().advntr_cut_pieces(ptr(codes), ptr(read_off), len(read_off) - 1, ptr(pr), ptr(b), ptr(e), ptr(rv), n,
+                                   int(threads), ptr(off), ptr(out)))
+    return out, off
+
+
+def flank_align(reads, flanks, pair_read, pair_flank, encoded=None):
     """advntr_flank_align: local alignment (1, -1, -1, -1) of flanks[pair_flank[p]] to reads[pair_read[p]]; a pair_read of
     len(reads) + r stands for the reverse complement of read r (made on the device).  Returns (score, begin, end) int32
-    arrays and the kernel time in ms.  Symbols outside ACGT match nothing."""
+    arrays and the kernel time in ms.  Symbols outside ACGT match nothing.  encoded = (codes, read_off) of `reads` as
+    encode_ascii gives them, when the caller has (or wants to keep) them."""
     L = load()
     require_gpu()
     # reads: case folding + encoding on host threads (N -> 254, other symbols -> 255; the library clamps them to "matches
     # nothing"); flanks are a few hundred bytes
-    rb, roff, _ = encode_ascii(list(reads))
+    rb, roff = encoded if encoded is not None else encode_ascii(list(reads))[:2]
     code = _CODE.copy()
     code[code == 255] = 4
     flanks = list(flanks)

@@ -210,6 +210,50 @@ extern "C" int advntr_encode_texts(const char *const *texts, int32_t n_reads, ui
     }, n_reads, flags, n_threads, out_off, out_codes, out_bad);
 }
 
+extern "C" int advntr_cut_pieces(const uint8_t *codes, const int64_t *read_off, int32_t n_reads, const int32_t *piece_read,
+                                 const int64_t *begin, const int64_t *end, const uint8_t *reverse, int64_t n_pieces,
+                                 int32_t n_threads, const int64_t *out_off, uint8_t *out_codes)
+{
+    if (n_reads < 0 || n_pieces < 0 || (n_pieces && (!read_off || !piece_read || !begin || !end || !out_off)))
+        return fail(ADVNTR_ERR_ARG, "advntr_cut_pieces: bad argument");
+    if (n_pieces == 0) return ADVNTR_OK;
+    for (int64_t p = 0; p < n_pieces; ++p) {
+        const int32_t r = piece_read[p];
+        if (r < 0 || r >= n_reads) return fail(ADVNTR_ERR_ARG, "advntr_cut_pieces: piece %lld names read %d of %d", (long long)p, r, n_reads);
+        const int64_t n = read_off[r + 1] - read_off[r];
+        if (begin[p] < 0 || end[p] < begin[p] || end[p] > n || out_off[p + 1] - out_off[p] != end[p] - begin[p])
+            return fail(ADVNTR_ERR_ARG, "advntr_cut_pieces: piece %lld = [%lld, %lld) of a read of %lld bases into a slot of %lld",
+                        (long long)p, (long long)begin[p], (long long)end[p], (long long)n, (long long)(out_off[p + 1] - out_off[p]));
+    }
+    if ((!codes || !out_codes) && out_off[n_pieces] > out_off[0]) return fail(ADVNTR_ERR_ARG, "advntr_cut_pieces: null buffer");
+    const int64_t chunk = 256;
+    const int T = host_text_threads(n_threads, n_pieces, chunk);
+    std::atomic<int64_t> next(0);
+    host_parallel(T, [&](int) {
+        for (;;) {
+            const int64_t p0 = next.fetch_add(chunk);
+            if (p0 >= n_pieces) return;
+            for (int64_t p = p0; p < std::min(n_pieces, p0 + chunk); ++p) {
+                const uint8_t *src = codes + read_off[piece_read[p]];
+                uint8_t *dst = out_codes + out_off[p];
+                const int64_t b = begin[p], n = end[p] - b;
+                if (reverse && reverse[p]) {
+                    for (int64_t i = 0; i < n; ++i) {
+                        const uint8_t c = src[b + n - 1 - i];
+                        dst[i] = c < 4 ? (uint8_t)(3 - c) : (uint8_t)255;
+                    }
+                } else {
+                    for (int64_t i = 0; i < n; ++i) {
+                        const uint8_t c = src[b + i];
+                        dst[i] = c < 4 ? c : (uint8_t)255;
+                    }
+                }
+            }
+        }
+    });
+    return ADVNTR_OK;
+}
+
 extern "C" int advntr_encode_ascii(const char *ascii, const int64_t *read_off, int32_t n_reads, int32_t n_threads,
                                    uint8_t *out_codes, uint8_t *out_bad)
 {

@@ -830,54 +830,85 @@ def _spanning_piece(read, begin, end, reverse):
     return read[max(n - end, 0):max(n - begin, 0)].upper().translate(_COMP_STR)[::-1]
 
 
+def _spanning_hits(flank_pairs, read_lists, flanking_region_size=100):
+    """The alignment half of extract_spanning_reads_multi: which (locus, read) uses span, on which strand and where.  Returns
+    None when there are no reads, else a dict: reads (every distinct read once), codes / read_off (their encoding), uses (read of
+    every (locus, read) use), use_locus, first (uses of locus i = first[i] .. first[i+1]), and per hit -- ordered by use, forward
+    strand before reverse -- use, reverse, left_begin, right_begin."""
+    import itertools
+    from . import settings
+    n_loci = len(flank_pairs)
+    flanks = []
+    for lf, rf in flank_pairs:
+        flanks += [lf[-flanking_region_size:], rf[:flanking_region_size]]
+    first = np.zeros(n_loci + 1, np.int64)
+    np.cumsum(np.fromiter(map(len, read_lists), dtype=np.int64, count=n_loci), out=first[1:])
+    flat = list(itertools.chain.from_iterable(read_lists))
+    n_uses = len(flat)
+    if n_uses == 0:
+        return None
+    # a read that is a candidate of several loci (the same object in several lists, or one list handed over for every locus)
+    # is encoded and uploaded ONCE; the pairs of every locus index that copy
+    ids = np.fromiter(map(id, flat), dtype=np.int64, count=n_uses)
+    _, where, uses = np.unique(ids, return_index=True, return_inverse=True)
+    if len(where) == n_uses:
+        reads, uses = flat, np.arange(n_uses, dtype=np.int32)
+    else:
+        reads, uses = [flat[i] for i in where.tolist()], uses.astype(np.int32)
+    if not all(type(s) is str for s in reads):
+        reads = [s if isinstance(s, str) else str(s) for s in reads]
+    n = len(reads)
+    codes, read_off, _ = _lib.encode_ascii(reads)
+    total_bases = int(read_off[n])
+    if 4 * n_uses >= 2 ** 31 or total_bases >= 2 ** 31:
+        raise ValueError("extract_spanning_reads_multi: %d alignments over %d read bases in one call exceed the 32-bit indices of "
+                         "advntr_flank_align; hand the loci over in pieces (genotype_pacbio_loci does)" % (4 * n_uses, total_bases))
+    use_locus = np.repeat(np.arange(n_loci, dtype=np.int32), np.diff(first))
+    # per (locus, read) use: forward strand then reverse strand (read index + n), each against the left then the right flank
+    strand_read = np.repeat(uses, 2) + np.tile(np.array([0, n], np.int32), n_uses)
+    pair_read = np.repeat(strand_read, 2)
+    pair_flank = (2 * np.repeat(use_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n_uses)).astype(np.int32)
+    score, begin, _, _ = _lib.flank_align(reads, flanks, pair_read, pair_flank, encoded=(codes, read_off))
+    flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
+    need = flen * (1 - settings.MAX_ERROR_RATE)
+    ok = ((score[0::2] > 0) & (score[0::2] >= need[pair_flank[0::2]]) & (score[1::2] > 0) &
+          (score[1::2] >= need[pair_flank[1::2]]) & (begin[1::2] >= begin[0::2]))
+    hits = np.flatnonzero(ok)                        # index = 2 * use + strand
+    return dict(reads=reads, codes=codes, read_off=read_off, uses=uses, use_locus=use_locus, first=first, use=hits >> 1,
+                reverse=(hits & 1).astype(np.uint8), left_begin=begin[2 * hits].astype(np.int64),
+                right_begin=begin[2 * hits + 1].astype(np.int64))
+
+
+def _spanning_pieces_encoded(H, flanking_region_size=100, threads=0):
+    """The trimmed pieces of _spanning_hits' hits as ENCODED reads -- str(read).upper()[left_begin : right_begin + flank size] of
+    the strand that spans, cut (and, for the reverse strand, reverse-complemented) out of the codes the alignment was fed with
+    (advntr_cut_pieces): (codes, off, locus of every piece)."""
+    rd = H["uses"][H["use"]]
+    n = (H["read_off"][1:] - H["read_off"][:-1])[rd]
+    begin, end = np.minimum(H["left_begin"], n), np.minimum(H["right_begin"] + flanking_region_size, n)
+    end = np.maximum(end, begin)
+    rev = H["reverse"] != 0
+    # the piece [begin, end) of the reverse complement is the reverse complement of [n - end, n - begin) of the read as stored
+    src_b, src_e = np.where(rev, n - end, begin), np.where(rev, n - begin, end)
+    codes, off = _lib.cut_pieces(H["codes"], H["read_off"], rd, src_b, src_e, H["reverse"], threads)
+    return codes, off, H["use_locus"][H["use"]]
+
+
 def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=100):
     """extract_spanning_reads for many loci in ONE advntr_flank_align call: flank_pairs[i] = (left_flanking_region,
     right_flanking_region) of locus i, read_lists[i] = its candidate long reads.  Returns one (spanning, length_distribution)
     pair per locus, each as extract_spanning_reads returns it (reads in input order, forward strand before reverse).  The
     reads go to the device as they are (the encoder folds case); only the trimmed piece of a spanning read -- a few hundred
     bases of its 5-15 kb -- is upper-cased and, for the reverse strand, reverse-complemented on the host."""
-    from . import settings
-    n_loci = len(flank_pairs)
-    # a read that is a candidate of several loci (the same str object in several lists, or one list handed over for every
-    # locus) is encoded and uploaded ONCE; the pairs of every locus index that copy
-    flanks, reads, slot_of, uses, first = [], [], {}, [], np.zeros(n_loci + 1, np.int64)
-    for i, ((lf, rf), rl) in enumerate(zip(flank_pairs, read_lists)):
-        flanks += [lf[-flanking_region_size:], rf[:flanking_region_size]]
-        for s in rl:
-            u = slot_of.get(id(s))
-            if u is None:
-                u = slot_of[id(s)] = len(reads)
-                reads.append(s if isinstance(s, str) else str(s))
-            uses.append(u)
-        first[i + 1] = len(uses)
-    out = [([], []) for _ in range(n_loci)]
-    n_uses, n = len(uses), len(reads)
-    if n_uses == 0:
+    out = [([], []) for _ in range(len(flank_pairs))]
+    H = _spanning_hits(flank_pairs, read_lists, flanking_region_size)
+    if H is None:
         return out
-    total_bases = sum(map(len, reads))
-    if 4 * n_uses >= 2 ** 31 or total_bases >= 2 ** 31:
-        raise ValueError("extract_spanning_reads_multi: %d alignments over %d read bases in one call exceed the 32-bit indices of "
-                         "advntr_flank_align; hand the loci over in pieces (genotype_pacbio_loci does)" % (4 * n_uses, total_bases))
-    uses = np.asarray(uses, np.int32)
-    use_locus = np.repeat(np.arange(n_loci, dtype=np.int32), np.diff(first))
-    # per (locus, read) use: forward strand then reverse strand (read index + n), each against the left then the right flank
-    strand_read = np.repeat(uses, 2) + np.tile(np.array([0, n], np.int32), n_uses)
-    pair_read = np.repeat(strand_read, 2)
-    pair_flank = (2 * np.repeat(use_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n_uses)).astype(np.int32)
-    score, begin, _, _ = _lib.flank_align(reads, flanks, pair_read, pair_flank)
-    flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
-    need = flen * (1 - settings.MAX_ERROR_RATE)
-    ok = ((score[0::2] > 0) & (score[0::2] >= need[pair_flank[0::2]]) & (score[1::2] > 0) &
-          (score[1::2] >= need[pair_flank[1::2]]) & (begin[1::2] >= begin[0::2]))
-    hits = np.flatnonzero(ok)
-    lbs, rbs = begin[2 * hits].tolist(), begin[2 * hits + 1].tolist()
-    for k, lb, rb in zip(hits.tolist(), lbs, rbs):
-        r = k >> 1                                   # the (locus, read) use; k & 1 = strand
-        s = reads[int(uses[r])]
-        piece = _spanning_piece(s, lb, rb + flanking_region_size, bool(k & 1))
-        i = int(use_locus[r])
+    reads, first = H["reads"], H["first"]
+    use, rd, loc = H["use"].tolist(), H["uses"][H["use"]].tolist(), H["use_locus"][H["use"]].tolist()
+    for r, u, i, rev, lb, rb in zip(use, rd, loc, H["reverse"].tolist(), H["left_begin"].tolist(), H["right_begin"].tolist()):
         spanning, lengths = out[i]
-        spanning.append((piece, r - int(first[i]), bool(k & 1)))
+        spanning.append((_spanning_piece(reads[u], lb, rb + flanking_region_size, bool(rev)), r - int(first[i]), bool(rev)))
         lengths.append(rb - (lb + flanking_region_size))
     return out
 
@@ -889,8 +920,9 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     read_lists[i] = the candidate reads of locus i (what the keyword filter hands over).  Per piece of the locus set:
     spanning-read extraction (both strands x two flanks of every read in one advntr_flank_align call, :324-371), one model
     per locus sized for its longest trimmed read (:538-549, native builder), every trimmed read scored on the forward strand
-    in one engine batch (:550-555); a preparation thread extracts, builds, uploads and encodes piece k + 1 while the calling
-    thread has piece k scored, as genotype_loci_pipelined does.  The >= 3-reads support filter and the maximum-likelihood
+    in one engine batch (:550-555); the stages of a piece run on host threads of their own, a piece behind each other
+    (extraction -> models -> upload and encoding), while the calling thread has the piece before scored, as
+    genotype_loci_pipelined does.  The >= 3-reads support filter and the maximum-likelihood
     call (:568-580) run once at the end on host threads (advntr_genotype_observed).  settings.MAX_ERROR_RATE is the
     caller's (0.3 for PacBio, advntr_commands.py).  Returns one GenotypeResult per locus, as the reference builds it
     (:665): GenotypeResult(copy_numbers, n_spanning, n_spanning, 0, max_prob).  timings (a dict) receives wall seconds per
@@ -907,63 +939,70 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     chunks = max(int(chunks), -(-n_pairs // (1 << 22)))
     chunks = max(1, min(chunks, n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
-    ready = queue.Queue(maxsize=2)
     T = dict(extract_spanning=0.0, build_models=0.0, upload_models=0.0, encode_reads=0.0, score=0.0, genotype=0.0)
+    if timings is not None and "trace" in timings:
+        T["trace"] = []
+    abort = threading.Event()
 
-    def prepare():
-        try:
-            for k in range(chunks):
-                lo, hi = cuts[k], cuts[k + 1]
-                t = time.perf_counter()
-                ext = extract_spanning_reads_multi([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
-                T["extract_spanning"] += time.perf_counter() - t
-                t = time.perf_counter()
-                have = [i for i in range(hi - lo) if ext[i][0]]
-                desc = []
-                for i in have:
-                    left, right, segments, pattern = loci[lo + i]
-                    copies = pacbio_max_copies([len(s[0]) for s in ext[i][0]], len(pattern))
-                    desc.append((left[-flanking_region_size:], right[:flanking_region_size], segments, copies))
-                models = hmm_utils.build_read_matcher_models(desc, threads=threads) if desc else []
-                T["build_models"] += time.perf_counter() - t
-                t = time.perf_counter()
-                device_models(models)
-                T["upload_models"] += time.perf_counter() - t
-                t = time.perf_counter()
-                trimmed = [s[0] for i in have for s in ext[i][0]]
-                which = np.repeat(np.arange(len(have), dtype=np.int32), [len(ext[i][0]) for i in have])
-                enc = _lib.encode_reads(trimmed) if trimmed else None
-                T["encode_reads"] += time.perf_counter() - t
-                ready.put((k, have, models, enc, which))
-        except BaseException as e:
-            ready.put(e)
+    def extract(k):
+        # (locus, read) uses that span -> the trimmed pieces as encoded reads, grouped by locus (hits come ordered by use)
+        lo, hi = cuts[k], cuts[k + 1]
+        H = _spanning_hits([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
+        if H is None or len(H["use"]) == 0:
+            return None
+        return _spanning_pieces_encoded(H, flanking_region_size, threads)
 
+    def build(k, ext):
+        if ext is None:
+            return None
+        lo = cuts[k]
+        codes, off, piece_locus = ext
+        have, start = np.unique(piece_locus, return_index=True)            # loci with a spanning read, ascending
+        longest = np.maximum.reduceat(np.diff(off), start)
+        desc = []
+        for i, n_max in zip(have.tolist(), longest.tolist()):
+            left, right, segments, pattern = loci[lo + i]
+            desc.append((left[-flanking_region_size:], right[:flanking_region_size], segments, pacbio_max_copies([n_max], len(pattern))))
+        models = hmm_utils.build_read_matcher_models(desc, threads=threads)
+        which = np.searchsorted(have, piece_locus).astype(np.int32)
+        return have, models, (codes, off), which
+
+    def upload_encode(k, item):
+        if item is None:
+            return None
+        t = time.perf_counter()
+        device_models(item[1])
+        T["upload_models"] += time.perf_counter() - t
+        return item
+
+    # the stages of a piece run on threads of their own, a piece behind each other: extraction (the flank alignment kernel, the
+    # encoding of the whole reads before it and the cutting of the spanning pieces out of those codes after it) -> models ->
+    # upload -> scoring (the calling thread)
     t0 = time.perf_counter()
-    worker = threading.Thread(target=prepare, name="advntr-prepare-pacbio")
-    worker.start()
+    extracted = _Stage("advntr-pacbio-extract", extract, chunks, [], abort, (T, "extract_spanning"))
+    built = _Stage("advntr-pacbio-build", build, chunks, [extracted], abort, (T, "build_models"))
+    ready = _Stage("advntr-pacbio-upload", upload_encode, chunks, [built], abort, None)
     ru_parts, count = [], np.zeros(n_loci, np.int64)
     try:
-        for _ in range(chunks):
-            item = ready.get()
+        for k in range(chunks):
+            item = ready.out.get()
             if isinstance(item, BaseException):
                 raise item
-            k, have, models, enc, which = item
             t = time.perf_counter()
-            if enc is not None:
+            if item is not None:
+                have, models, enc, which = item
                 _, summ, _ = _lib.viterbi_batch(device_models(models), enc[0], enc[1], which, want_paths=False, want_summary=True)
                 ru_parts.append(summ[:, _lib.SUM_RU].astype(np.int32))
-                np.add.at(count, cuts[k] + np.asarray(have, np.int64)[which], 1)
+                np.add.at(count, cuts[k] + have.astype(np.int64)[which], 1)
+                del have, models, enc, which
             T["score"] += time.perf_counter() - t
-            del models, enc
-    except BaseException:
-        while worker.is_alive():
-            try:
-                ready.get(timeout=0.05)
-            except queue.Empty:
-                pass
-        raise
+            if "trace" in T:
+                T["trace"].append(("score", k, t, time.perf_counter()))
+            del item
     finally:
-        worker.join()
+        abort.set()
+        for st in (extracted, built, ready):
+            st.thread.join()
     t = time.perf_counter()
     off = np.zeros(n_loci + 1, np.int64)
     np.cumsum(count, out=off[1:])

@@ -270,6 +270,16 @@ int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_threads, int6
 int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flags, int32_t n_threads,
                         const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
 
+/* Pieces of encoded reads, as reads of their own: piece p = codes[read_off[r] + begin[p] .. read_off[r] + end[p]) of read
+ * r = piece_read[p] (0 <= begin <= end <= length of the read), reverse-complemented when reverse[p] != 0, written to
+ * out_codes[out_off[p] .. out_off[p+1]) -- the trimming of spanning long reads (read[left_begin : right_begin + flank size] of
+ * the strand that spans, /root/reference/advntr/vntr_finder.py:338-356) done on the codes the flank alignment was fed with,
+ * instead of slicing, upper-casing, complementing and re-encoding strings in the host language.  Codes above 3 (N, other
+ * symbols) come out as 255, what the scoring calls reject.  Host threads, no GPU.                                        */
+int advntr_cut_pieces(const uint8_t *codes, const int64_t *read_off, int32_t n_reads, const int32_t *piece_read,
+                      const int64_t *begin, const int64_t *end, const uint8_t *reverse, int64_t n_pieces, int32_t n_threads,
+                      const int64_t *out_off, uint8_t *out_codes);
+
 /* ---- genotype caller on the summary records (the step downstream of scoring; host threads, no GPU) -----------
  * Replaces, for many loci at once, the Illumina aggregation of VNTRFinder.find_repeat_count_from_alignment_file after
  * read selection (/root/reference/advntr/vntr_finder.py:807-887: spanning / flanking split by

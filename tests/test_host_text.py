@@ -117,3 +117,33 @@ def test_host_threads_follow_the_cpu_quota_and_the_override():
         assert n <= quota
     assert ask(dict(plain, ADVNTR_HOST_THREADS="5")) == 5
     assert ask(dict(plain, ADVNTR_HOST_THREADS="junk")) == n
+
+
+def test_cut_pieces_equals_slicing_strings():
+    """advntr_cut_pieces on the codes of whole reads == encoding what vntr_finder._spanning_piece cuts out of the strings (upper
+    case, reverse complement of the reverse strand, N and foreign symbols -> 255), incl. empty pieces, pieces running to the
+    end of a read and lower-case reads; bad pieces are refused."""
+    from advntr_amd import vntr_finder
+    rng = np.random.default_rng(5)
+    reads = ["".join(rng.choice(list("ACGTacgtNnX"), p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .01, .01], size=int(n)))
+             for n in rng.integers(1, 400, 60)]
+    codes, off, _ = _lib.encode_ascii(reads)
+    n_pieces = 500
+    rd = rng.integers(0, len(reads), n_pieces).astype(np.int32)
+    lens = np.diff(off)[rd]
+    lb = (rng.random(n_pieces) * (lens + 20)).astype(np.int64)
+    rb_end = lb + (rng.random(n_pieces) * 150).astype(np.int64)
+    lb[:5], rb_end[:5] = 0, 0                                            # empty pieces
+    rev = rng.integers(0, 2, n_pieces).astype(np.uint8)
+    want = [vntr_finder._spanning_piece(reads[r], int(b), int(e), bool(v)) for r, b, e, v in zip(rd, lb, rb_end, rev)]
+    n = lens
+    begin, end = np.minimum(lb, n), np.maximum(np.minimum(rb_end, n), np.minimum(lb, n))
+    src_b, src_e = np.where(rev != 0, n - end, begin), np.where(rev != 0, n - begin, end)
+    got, goff = _lib.cut_pieces(codes, off, rd, src_b, src_e, rev, threads=3)
+    wc, woff = _lib.encode_reads(want)
+    assert np.array_equal(goff, woff) and np.array_equal(got, wc)
+    assert len(got) > 10000 and (got == 255).any() and (rev != 0).sum() > 100
+    with pytest.raises(_lib.EngineError):
+        _lib.cut_pieces(codes, off, np.array([0], np.int32), np.array([0]), np.array([int(lens.max()) + 500]), np.array([0], np.uint8))
+    with pytest.raises(_lib.EngineError):
+        _lib.cut_pieces(codes, off, np.array([len(reads)], np.int32), np.array([0]), np.array([1]), np.array([0], np.uint8))
