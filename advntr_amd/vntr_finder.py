@@ -835,8 +835,12 @@ def _spanning_hits(flank_pairs, read_lists, flanking_region_size=100):
     None when there are no reads, else a dict: reads (every distinct read once), codes / read_off (their encoding), uses (read of
     every (locus, read) use), use_locus, first (uses of locus i = first[i] .. first[i+1]), and per hit -- ordered by use, forward
     strand before reverse -- use, reverse, left_begin, right_begin."""
+    return _spanning_align(_spanning_prepare(flank_pairs, read_lists, flanking_region_size))
+
+
+def _spanning_prepare(flank_pairs, read_lists, flanking_region_size=100):
+    """_spanning_hits up to the device call: the distinct reads, encoded, and the (read, flank) pairs to align (host only)."""
     import itertools
-    from . import settings
     n_loci = len(flank_pairs)
     flanks = []
     for lf, rf in flank_pairs:
@@ -868,15 +872,25 @@ def _spanning_hits(flank_pairs, read_lists, flanking_region_size=100):
     strand_read = np.repeat(uses, 2) + np.tile(np.array([0, n], np.int32), n_uses)
     pair_read = np.repeat(strand_read, 2)
     pair_flank = (2 * np.repeat(use_locus, 4) + np.tile(np.array([0, 1], np.int32), 2 * n_uses)).astype(np.int32)
-    score, begin, _, _ = _lib.flank_align(reads, flanks, pair_read, pair_flank, encoded=(codes, read_off))
+    return dict(reads=reads, codes=codes, read_off=read_off, uses=uses, use_locus=use_locus, first=first, flanks=flanks,
+                pair_read=pair_read, pair_flank=pair_flank)
+
+
+def _spanning_align(H):
+    """_spanning_hits from the device call on: the flank alignments and the spanning rule."""
+    from . import settings
+    if H is None:
+        return None
+    flanks, pair_flank = H.pop("flanks"), H.pop("pair_flank")
+    score, begin, _, _ = _lib.flank_align(H["reads"], flanks, H.pop("pair_read"), pair_flank, encoded=(H["codes"], H["read_off"]))
     flen = np.fromiter(map(len, flanks), dtype=np.int64, count=len(flanks))
     need = flen * (1 - settings.MAX_ERROR_RATE)
     ok = ((score[0::2] > 0) & (score[0::2] >= need[pair_flank[0::2]]) & (score[1::2] > 0) &
           (score[1::2] >= need[pair_flank[1::2]]) & (begin[1::2] >= begin[0::2]))
     hits = np.flatnonzero(ok)                        # index = 2 * use + strand
-    return dict(reads=reads, codes=codes, read_off=read_off, uses=uses, use_locus=use_locus, first=first, use=hits >> 1,
-                reverse=(hits & 1).astype(np.uint8), left_begin=begin[2 * hits].astype(np.int64),
-                right_begin=begin[2 * hits + 1].astype(np.int64))
+    H.update(use=hits >> 1, reverse=(hits & 1).astype(np.uint8), left_begin=begin[2 * hits].astype(np.int64),
+             right_begin=begin[2 * hits + 1].astype(np.int64))
+    return H
 
 
 def _spanning_pieces_encoded(H, flanking_region_size=100, threads=0):
@@ -913,7 +927,7 @@ def extract_spanning_reads_multi(flank_pairs, read_lists, flanking_region_size=1
     return out
 
 
-def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=False, chunks=8, threads=0, timings=None,
+def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=False, chunks=16, threads=0, timings=None,
                          flanking_region_size=100):
     """VNTRFinder.find_repeat_count_from_pacbio_reads (vntr_finder.py:652-665) for many loci at once, from the WHOLE long
     reads to the RU-count genotypes: loci = [(left_flanking_region, right_flanking_region, repeat_segments, pattern), ...],
@@ -944,10 +958,13 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
         T["trace"] = []
     abort = threading.Event()
 
-    def extract(k):
-        # (locus, read) uses that span -> the trimmed pieces as encoded reads, grouped by locus (hits come ordered by use)
+    def encode_whole(k):
         lo, hi = cuts[k], cuts[k + 1]
-        H = _spanning_hits([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
+        return _spanning_prepare([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
+
+    def extract(k, prep):
+        # (locus, read) uses that span -> the trimmed pieces as encoded reads, grouped by locus (hits come ordered by use)
+        H = _spanning_align(prep)
         if H is None or len(H["use"]) == 0:
             return None
         return _spanning_pieces_encoded(H, flanking_region_size, threads)
@@ -970,16 +987,19 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     def upload_encode(k, item):
         if item is None:
             return None
+        have, models, enc, which = item
         t = time.perf_counter()
-        device_models(item[1])
+        dms = device_models(models)
         T["upload_models"] += time.perf_counter() - t
-        return item
+        # reads and models bound into a device batch here (routing, tile lists, upload): the calling thread only launches
+        return have, models, _lib.DeviceBatch(dms, enc[0], enc[1], which), which
 
-    # the stages of a piece run on threads of their own, a piece behind each other: extraction (the flank alignment kernel, the
-    # encoding of the whole reads before it and the cutting of the spanning pieces out of those codes after it) -> models ->
-    # upload -> scoring (the calling thread)
+    # the stages of a piece run on threads of their own, a piece behind each other: encoding of the whole reads -> extraction
+    # (the flank alignment kernel and the cutting of the spanning pieces out of those codes) -> models -> upload -> scoring (the
+    # calling thread)
     t0 = time.perf_counter()
-    extracted = _Stage("advntr-pacbio-extract", extract, chunks, [], abort, (T, "extract_spanning"))
+    whole = _Stage("advntr-pacbio-encode", encode_whole, chunks, [], abort, (T, "encode_reads"))
+    extracted = _Stage("advntr-pacbio-extract", extract, chunks, [whole], abort, (T, "extract_spanning"))
     built = _Stage("advntr-pacbio-build", build, chunks, [extracted], abort, (T, "build_models"))
     ready = _Stage("advntr-pacbio-upload", upload_encode, chunks, [built], abort, None)
     ru_parts, count = [], np.zeros(n_loci, np.int64)
@@ -990,19 +1010,27 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
                 raise item
             t = time.perf_counter()
             if item is not None:
-                have, models, enc, which = item
-                _, summ, _ = _lib.viterbi_batch(device_models(models), enc[0], enc[1], which, want_paths=False, want_summary=True)
+                have, models, batch, which = item
+                try:
+                    batch.run()
+                    _, summ = batch.fetch()
+                finally:
+                    batch.close()
                 ru_parts.append(summ[:, _lib.SUM_RU].astype(np.int32))
                 np.add.at(count, cuts[k] + have.astype(np.int64)[which], 1)
-                del have, models, enc, which
+                del have, models, batch, which
             T["score"] += time.perf_counter() - t
             if "trace" in T:
                 T["trace"].append(("score", k, t, time.perf_counter()))
             del item
     finally:
         abort.set()
-        for st in (extracted, built, ready):
+        for st in (whole, extracted, built, ready):
             st.thread.join()
+        while not ready.out.empty():                # batches bound but never run (a failure upstream of them)
+            left = ready.out.get_nowait()
+            if isinstance(left, tuple):
+                left[2].close()
     t = time.perf_counter()
     off = np.zeros(n_loci + 1, np.int64)
     np.cumsum(count, out=off[1:])

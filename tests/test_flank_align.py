@@ -327,7 +327,7 @@ def test_a_read_list_shared_by_many_loci_is_uploaded_once(monkeypatch):
             assert len(sp) >= 3 and len(lengths) == len(sp)
         # pieces by alignments: 2 loci x 3 000 000 shared "reads" would be 24 M alignments -> at least 6 pieces
         calls = []
-        monkeypatch.setattr(vntr_finder, "_spanning_hits", lambda fp, rl, size=100: calls.append(len(fp)))
+        monkeypatch.setattr(vntr_finder, "_spanning_prepare", lambda fp, rl, size=100: calls.append(len(fp)))
         big = [None] * 3000000
         res = vntr_finder.genotype_pacbio_loci(loci[:2] * 6, [big] * 12, chunks=1)
         assert len(res) == 12 and len(calls) >= 9 and all(g.copy_numbers is None for g in res)
