@@ -164,3 +164,21 @@ def test_builder_aligns_ragged_units_only_on_request():
         _same(stepwise_builder.get_read_matcher_model(left, right, units, 3), want, exact=True)
     finally:
         settings.ALIGN_REPEATS = False
+
+
+def test_kept_flank_blocks_do_not_leak_between_loci():
+    """The builder keeps the flank blocks it has built per thread and per flank length (model_builder.h, FlankBlocks) and fills
+    in a locus's bases: a locus built after fifty others -- more flank lengths than the threads keep, flanks longer than what
+    they keep at all, the same lengths with other bases -- equals the same locus built alone, and the stepwise assembly."""
+    rng = np.random.default_rng(404)
+    dna = lambda n: "".join(rng.choice(list("ACGT"), n))
+    lengths = [int(x) for x in rng.integers(1, 70, 50)] + [150, 150, 1100, 30]
+    loci = [(dna(n), dna(lengths[-1 - i]), [dna(12)], 3) for i, n in enumerate(lengths)]
+    together = hmm_utils.build_read_matcher_models(loci, threads=1)
+    again = hmm_utils.build_read_matcher_models(loci[::-1], threads=2)[::-1]
+    for k in (0, 17, 49, 50, 51, 52, 53):
+        alone = hmm_utils.build_read_matcher_models([loci[k]], threads=1)[0]
+        _same(together[k], alone, exact=True)
+        _same(again[k], alone, exact=True)
+    for k in (3, 51, 53):
+        _same(together[k], stepwise_builder.get_read_matcher_model(*loci[k]), exact=True)
