@@ -16,6 +16,17 @@ done
 # the end-to-end run (builder, recruit kernels, genotype caller) under the kernel trace: what the device does in it
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_e2e -- python3 $root/bench.py --no-upstream --no-cpu --steps 2 > $root/$out/trace_e2e.log 2>&1 < /dev/null
 cd $root
+# the bench lines kept under profiles/: the default line, C2 / C4 alone, both strong-scaling lines over RCCL on one rank,
+# config 5 at full size, the workgroup clocks of an 8-rank share (measurement build)
+timeout 600 python3 bench.py > $out/c1_bench.json 2> $out/c1_bench.err
+timeout 300 python3 bench.py --workload c2 --no-cpu --steps 5 --warmup 2 > $out/c2_bench.json 2> $out/c2_bench.err
+timeout 300 python3 bench.py --workload c4 --no-cpu --steps 5 --warmup 2 > $out/c4_bench.json 2> $out/c4_bench.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 timeout 300 python3 bench.py --workload c3 --no-cpu --steps 5 --warmup 1 > $out/c3_1gpu_rccl_bench.json 2> $out/c3_rccl.err
+RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29652 timeout 300 python3 bench.py --workload c4 --no-cpu --steps 3 --warmup 1 > $out/c4_1gpu_rccl_bench.json 2> $out/c4_rccl.err
+timeout 600 python3 scripts/pacbio_full_size.py 8960 $out/c5_full_size.json > /dev/null 2> $out/c5_full_size.err
+if [ -f exp/wgclocks.so ]; then
+  for w in "c4 1120" "c2 840" "ref150" "s300"; do timeout 200 python3 scripts/wg_clocks.py $w 2>/dev/null | tail -1; done > $out/wg_clocks.jsonl
+fi
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
