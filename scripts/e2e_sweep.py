@@ -15,15 +15,16 @@ import gc
 gc.collect(); gc.freeze()
 _lib.require_gpu()
 vntr_finder.genotype_loci_pipelined(desc[:64], cand[:64], chunks=2)
-plans = [dict(chunks=16, ramp=4), dict(chunks=16, ramp=4, stage_threads=(8, 4, 4)), dict(chunks=16, ramp=4, stage_threads=(10, 4, 2)),
-         dict(chunks=16, ramp=4, stage_threads=(12, 4, 4)), dict(chunks=16, ramp=4, stage_threads=(12, 8, 4)),
-         dict(chunks=16, ramp=4, stage_threads=(16, 8, 4)), dict(chunks=24, ramp=4), dict(chunks=24, ramp=4, stage_threads=(12, 4, 4))]
+plans = [dict()]
 import collections
 res = collections.defaultdict(list)
-for rep in range(6):
+cpu = collections.defaultdict(list)
+for rep in range(8):
     for plan in plans:
         T = {}
+        c0 = time.process_time()
         vntr_finder.genotype_loci_pipelined(desc, cand, timings=T, **plan)
+        cpu[str(plan)].append(time.process_time() - c0)
         res[str(plan)].append(T["total"])
 for k, v in res.items():
-    print("%-70s median %.3f  min %.3f  max %.3f" % (k, float(np.median(v)), min(v), max(v)))
+    print("%-50s median %.3f  min %.3f  max %.3f   cpu %.2f core-s" % (k, float(np.median(v)), min(v), max(v), float(np.median(cpu[k]))))
