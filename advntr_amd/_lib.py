@@ -68,6 +68,7 @@ SYMBOLS = {
     "advntr_encode_texts": (ctypes.c_int, [_vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_encode_spans": (ctypes.c_int, [_vp, _vp, _vp, _i32, _u32, _i32, _vp, _vp, _vp]),
     "advntr_cut_pieces": (ctypes.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "advntr_pylist_texts": (_i64, [_vp, _vp, _vp, _i64]),          # (called through _list_texts: needs the interpreter lock)
     "advntr_line_index": (ctypes.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     "advntr_genotype_illumina": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "advntr_genotype_observed": (ctypes.c_int, [_vp, _vp, _i32, _u32, _i32, _vp, _vp]),
@@ -164,6 +165,26 @@ def encode_reads(seqs):
     return np.ascontiguousarray(bases), off
 
 
+_pylist_texts = None
+
+
+def _list_texts(seqs):
+    """The buffers of a list of ASCII str -- (pointers uint64[n], lengths int64[n]) -- through ONE library call that walks the
+    list (advntr_pylist_texts, entered with the interpreter lock held), or None when the list holds anything else."""
+    global _pylist_texts
+    if type(seqs) is not list:
+        return None
+    if _pylist_texts is None:
+        load()
+        fn = ctypes.PyDLL(LIB_PATH).advntr_pylist_texts
+        fn.restype = _i64
+        fn.argtypes = [ctypes.py_object, _vp, _vp, _i64]
+        _pylist_texts = fn
+    n = len(seqs)
+    ptrs, lens = np.empty(n, np.uint64), np.empty(n, np.int64)
+    return (ptrs, lens) if _pylist_texts(seqs, ptr(ptrs), ptr(lens), n) == n else None
+
+
 def encode_ascii(seqs, threads=0):
     """advntr_encode_ascii: list of str -> (codes uint8 over the concatenation, read_off int64, bad uint8[n]) on host
     threads: upper/lower-case ACGT -> 0..3, N -> 254, anything else -> 255; bad[read] = 1 for a read holding N (the
@@ -171,6 +192,14 @@ def encode_ascii(seqs, threads=0):
     ValueError there, hmm.pyx:72,79), 0 otherwise."""
     n = len(seqs)
     off = np.zeros(n + 1, dtype=np.int64)
+    texts = _list_texts(seqs) if n else None
+    if texts is not None:
+        # a list of ASCII str (every read file): encoded straight out of the strings' own buffers, the interpreter touched once
+        np.cumsum(texts[1], out=off[1:])
+        codes = np.empty(int(off[n]), np.uint8)
+        bad = np.zeros(n, np.uint8)
+        check(load().advntr_encode_texts(ptr(texts[0]), n, 0, int(threads), ptr(off), ptr(codes), ptr(bad)))
+        return codes, off, bad
     if n:
         np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n), out=off[1:])
     if n and off[n] >= LONG_TEXT_MEAN * n:

@@ -1,5 +1,6 @@
 // abi_genotype.h -- C-ABI entry point of the host-side genotype caller (genotype_caller.h).  Included by engine.hip.
 #pragma once
+#include <dlfcn.h>
 #include "genotype_caller.h"
 
 extern "C" int advntr_genotype_illumina(const int32_t *summaries, const int64_t *locus_off, int32_t n_loci, uint32_t flags,
@@ -208,6 +209,46 @@ extern "C" int advntr_encode_texts(const char *const *texts, int32_t n_reads, ui
         n = out_off[r + 1] - out_off[r];
         return (const uint8_t *)texts[r];
     }, n_reads, flags, n_threads, out_off, out_codes, out_bad);
+}
+
+// A CPython host's list of str -> buffer pointers and lengths (include/advntr_hip.h).  Called with the interpreter lock held.
+extern "C" int64_t advntr_pylist_texts(void *list, const char **texts, int64_t *lengths, int64_t capacity)
+{
+    typedef long (*SizeFn)(void *);
+    typedef void *(*ItemFn)(void *, long);
+    typedef const char *(*Utf8Fn)(void *, long *);
+    typedef void (*ClearFn)(void);
+    struct Api {
+        SizeFn list_size = nullptr, str_length = nullptr;
+        ItemFn list_item = nullptr;
+        Utf8Fn utf8 = nullptr;
+        ClearFn clear = nullptr;
+        bool ok = false;
+        Api()
+        {
+            list_size = (SizeFn)dlsym(RTLD_DEFAULT, "PyList_Size");
+            str_length = (SizeFn)dlsym(RTLD_DEFAULT, "PyUnicode_GetLength");
+            list_item = (ItemFn)dlsym(RTLD_DEFAULT, "PyList_GetItem");
+            utf8 = (Utf8Fn)dlsym(RTLD_DEFAULT, "PyUnicode_AsUTF8AndSize");
+            clear = (ClearFn)dlsym(RTLD_DEFAULT, "PyErr_Clear");
+            ok = list_size && str_length && list_item && utf8 && clear;
+        }
+    };
+    static const Api api;
+    if (!api.ok || !list || !texts || !lengths) return -1;
+    const long n = api.list_size(list);
+    if (n < 0) { api.clear(); return -1; }
+    if (n > capacity) return -1;
+    for (long i = 0; i < n; ++i) {
+        void *item = api.list_item(list, i);                     // borrowed
+        long size = 0;
+        const char *p = item ? api.utf8(item, &size) : nullptr;
+        if (!p) { api.clear(); return -(int64_t)i - 2; }         // not a str (or one without a UTF-8 form)
+        if (api.str_length(item) != size) return -(int64_t)i - 2; // not ASCII: one byte per character does not hold
+        texts[i] = p;
+        lengths[i] = size;
+    }
+    return n;
 }
 
 extern "C" int advntr_cut_pieces(const uint8_t *codes, const int64_t *read_off, int32_t n_reads, const int32_t *piece_read,

@@ -270,6 +270,14 @@ int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_threads, int6
 int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flags, int32_t n_threads,
                         const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
 
+/* For a CPython host (the reference's language): the buffers of the strings of a Python list, without a call back into the
+ * interpreter per string.  list = a PyObject* that is a list of str, handed over WITH the interpreter lock held (ctypes.PyDLL);
+ * texts[i] / lengths[i] receive the UTF-8 buffer and length of item i -- for an ASCII str (every read file) its own buffer, valid
+ * while the list holds the str; they feed advntr_encode_texts.  Returns the number of items, or -1 when the interpreter's C API
+ * is not reachable from this process or `list` is not a list, or -(i + 2) when item i is not a str or not ASCII (the caller
+ * then takes its general route).  The C API is looked up at run time (dlsym): the library does not link against libpython. */
+int64_t advntr_pylist_texts(void *list, const char **texts, int64_t *lengths, int64_t capacity);
+
 /* Pieces of encoded reads, as reads of their own: piece p = codes[read_off[r] + begin[p] .. read_off[r] + end[p]) of read
  * r = piece_read[p] (0 <= begin <= end <= length of the read), reverse-complemented when reverse[p] != 0, written to
  * out_codes[out_off[p] .. out_off[p+1]) -- the trimming of spanning long reads (read[left_begin : right_begin + flank size] of

@@ -147,3 +147,20 @@ def test_cut_pieces_equals_slicing_strings():
         _lib.cut_pieces(codes, off, np.array([0], np.int32), np.array([0]), np.array([int(lens.max()) + 500]), np.array([0], np.uint8))
     with pytest.raises(_lib.EngineError):
         _lib.cut_pieces(codes, off, np.array([len(reads)], np.int32), np.array([0]), np.array([1]), np.array([0], np.uint8))
+
+
+def test_encode_ascii_list_walk_equals_general_route():
+    """A list of ASCII str is encoded straight out of the strings' buffers (advntr_pylist_texts walks the list in one library
+    call); a tuple of the same strings takes the general route (one joined text): same codes, offsets and flags -- empty strings,
+    lower case, N, foreign symbols included; a list holding a non-ASCII str, a lone surrogate or a non-str falls back by itself."""
+    rng = np.random.default_rng(8)
+    reads = ["".join(rng.choice(list("ACGTacgtNnX-"), int(n))) for n in rng.integers(0, 300, 400)] + ["", "ACGT", "n"]
+    assert _lib._list_texts(reads) is not None
+    a, b = _lib.encode_ascii(reads, 3), _lib.encode_ascii(tuple(reads), 3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert set(a[2].tolist()) == {0, 1, 2} and len(a[0]) == sum(map(len, reads))
+    for odd in (["ACGT", "ACGéT"], ["AC\ud800GT"], ["ACGT", b"ACGT"], ["ACGT", None]):
+        assert _lib._list_texts(odd) is None
+    c, d = _lib.encode_ascii(["ACGT", "ACGéT", "AC\ud800GT"], 1), _lib.encode_ascii(("ACGT", "ACGéT", "AC\ud800GT"), 1)
+    assert all(np.array_equal(x, y) for x, y in zip(c, d)) and c[2].tolist() == [0, 2, 2]
+    assert _lib._list_texts((1, 2)) is None and len(_lib._list_texts([])[0]) == 0
