@@ -50,8 +50,8 @@ def algorithmic_bytes(n, m):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=100000, help="c1: reads per GPU")
     ap.add_argument("--cpu-sample", type=int, default=2000)
     ap.add_argument("--generic", action="store_true", help="force the generic-CSR kernel")

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Run on the GPU box: everything profiles/r05_* is made of.  scripts/profile_round5.sh gpurun_out/r05_prof
 # (every profiler pass under its own timeout: a pass that hangs must not eat the call)
+# scripts/profile_round5.sh OUT lines: only the bench lines / records at the end (no profiler passes)
 out=$1; root=$(pwd); mkdir -p $root/$out
 B="--no-cpu --no-s300 --no-c2"
+if [ "$2" != "lines" ]; then
 for w in c1 s300 c2 c4; do timeout 200 python3 bench.py --workload $w $B --steps 2 > $out/${w}_quick.json 2> $out/${w}_quick.err; done
 cd /tmp && export TMPDIR=/tmp
 declare -A passes=([c1]="--steps 20 --warmup 5" [s300]="--steps 20 --warmup 5" [c2]="--steps 10 --warmup 3" [c4]="--steps 5 --warmup 2")
@@ -15,6 +17,7 @@ for w in c1 s300 c2 c4; do
 done
 # the end-to-end run (builder, recruit kernels, genotype caller) under the kernel trace: what the device does in it
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace_e2e -- python3 $root/bench.py --no-upstream --no-cpu --steps 2 > $root/$out/trace_e2e.log 2>&1 < /dev/null
+fi
 cd $root
 # the bench lines kept under profiles/: the default line, C2 / C4 alone, both strong-scaling lines over RCCL on one rank,
 # config 5 at full size, the workgroup clocks of an 8-rank share (measurement build)
@@ -27,6 +30,7 @@ timeout 600 python3 scripts/pacbio_full_size.py 8960 $out/c5_full_size.json > /d
 if [ -f exp/wgclocks.so ]; then
   for w in "c4 1120" "c2 840" "ref150" "s300"; do timeout 200 python3 scripts/wg_clocks.py $w 2>/dev/null | tail -1; done > $out/wg_clocks.jsonl
 fi
+[ "$2" = "lines" ] && exit 0
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
