@@ -115,6 +115,7 @@ struct Name {
 // (a third of the build's time, measured).  Everything the builder allocates besides its result therefore comes from a
 // per-thread bump allocator over a buffer that is touched once and rewound per locus (what does not fit goes upstream).
 // State names are written once into it and then only pointed at: the nets share them.
+#ifndef ADVNTR_ARENA_PLAIN
 struct Arena {
     std::unique_ptr<unsigned char[]> buffer;
     std::pmr::monotonic_buffer_resource res;
@@ -128,6 +129,26 @@ struct Arena {
     }
     void rewind() { res.release(); }
 };
+#else
+// Sanitizer builds (tests/test_native_sanitizers.py): every array a block of its own from the general allocator, so that an
+// access past its end is one AddressSanitizer sees -- inside the bump buffer it would land in a neighbour unnoticed.
+struct Arena {
+    struct Plain : std::pmr::memory_resource {
+        void *do_allocate(size_t bytes, size_t align) override { return std::pmr::new_delete_resource()->allocate(bytes, align); }
+        void do_deallocate(void *p, size_t bytes, size_t align) override { std::pmr::new_delete_resource()->deallocate(p, bytes, align); }
+        bool do_is_equal(const std::pmr::memory_resource &o) const noexcept override { return this == &o; }
+    } res;
+    std::vector<std::unique_ptr<Name>> names;
+    LogMemo log;
+    explicit Arena(size_t = 0) {}
+    const Name *keep(const Name &nm)
+    {
+        names.emplace_back(new Name(nm));
+        return names.back().get();
+    }
+    void rewind() { names.clear(); }
+};
+#endif
 template <class T> using Vec = std::pmr::vector<T>;
 
 struct Arc { int to; int next; double logp; };       // next: the vertex's following arc in the pool (-1 = last)

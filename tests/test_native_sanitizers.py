@@ -6,11 +6,18 @@ import subprocess
 from conftest import ROOT
 
 
-def test_host_cpp_under_asan_ubsan(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("arena", ["bump", "plain"])
+def test_host_cpp_under_asan_ubsan(tmp_path, arena):
+    """arena = "plain": the builder's arrays as blocks of their own from the general allocator (-DADVNTR_ARENA_PLAIN), where the
+    sanitizer sees an access past the end of one; "bump": the shipped per-thread bump arena."""
     exe = str(tmp_path / "asan_host")
     src = os.path.join(ROOT, "tests", "native", "asan_host.cpp")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-fno-omit-frame-pointer", "-pthread", "-o", exe, src])
+                           "-fno-omit-frame-pointer", "-pthread"] + (["-DADVNTR_ARENA_PLAIN"] if arena == "plain" else []) +
+                          ["-o", exe, src])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert out.stdout.decode().startswith("ok ")
