@@ -297,7 +297,8 @@ class _Aborted(Exception):
 
 
 def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False,
-                            compute_reverse=True, chunks=16, threads=0, timings=None, stage_threads=None, ramp=4):
+                            compute_reverse=True, chunks=8, threads=0, timings=None, stage_threads=None, ramp=4,
+                            piece_fractions=None):
     """genotype_loci from the locus DESCRIPTIONS -- loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...], what
     the reference turns into a model per locus inside its serial loop (genome_analyzer.py:280-297 -> vntr_finder.py:117-138) --
     with the host stages overlapped with the device's.  The locus set is cut into `chunks` pieces that flow through a
@@ -307,17 +308,32 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     choice, recruit rule, more than two repeat bases: advntr_batch_recruit), so that only the selected reads' records come
     back.  The per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results
     as genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage.
-    ramp: the first piece goes in `ramp` parts, so that the device starts after a small piece's host work instead of a full
-    one's; stage_threads = (build, upload, encode) host threads of the three threaded stages."""
+    ramp: the first piece goes in parts of 1, 1, 2, 4 ... `ramp`-ths, so that the device starts after a small piece's host work
+    instead of a full one's; piece_fractions: explicit piece sizes instead (shares of the locus set); stage_threads = (build, upload, encode) host threads of the three threaded stages."""
     import threading
     import time
     from . import hmm_utils
     n_loci = len(loci)
     chunks = max(1, min(int(chunks), n_loci)) if n_loci else 1
     cuts = [n_loci * i // chunks for i in range(chunks + 1)]
-    if ramp and ramp > 1 and chunks > 1 and cuts[1] >= ramp:
-        # the first piece in `ramp` parts: the device starts on a small piece while the host is still building the rest
-        cuts = [cuts[1] * i // ramp for i in range(ramp)] + cuts[1:]
+    if piece_fractions:
+        # explicit piece sizes (shares of the locus set, in order; what they leave over is one more piece)
+        acc, cuts = 0.0, [0]
+        for f in piece_fractions:
+            acc += float(f)
+            at = min(n_loci, int(round(acc * n_loci)))
+            if at > cuts[-1]:
+                cuts.append(at)
+        if cuts[-1] < n_loci:
+            cuts.append(n_loci)
+        chunks = len(cuts) - 1
+    elif ramp and ramp > 1 and chunks > 1 and cuts[1] >= ramp:
+        # the first piece in growing parts -- 1, 1, 2, 4, ... of `ramp` shares: the device starts on a small piece while the
+        # host is still building the rest, and the pieces (a launch each, with its tail) do not stay small for long
+        parts = [0, 1]
+        while parts[-1] < ramp:
+            parts.append(min(int(ramp), 2 * parts[-1]))
+        cuts = [cuts[1] * q // int(ramp) for q in parts[:-1]] + cuts[1:]
         chunks = len(cuts) - 1
     T = dict(build_models=0.0, upload_models=0.0, encode_reads=0.0, bind_batch=0.0, score_recruit=0.0, aggregate_genotype=0.0)
     if timings is not None and "trace" in timings:
