@@ -27,6 +27,7 @@ timeout 300 python3 bench.py --workload c4 --no-cpu --steps 5 --warmup 2 > $out/
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 timeout 300 python3 bench.py --workload c3 --no-cpu --steps 5 --warmup 1 > $out/c3_1gpu_rccl_bench.json 2> $out/c3_rccl.err
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29652 timeout 300 python3 bench.py --workload c4 --no-cpu --steps 3 --warmup 1 > $out/c4_1gpu_rccl_bench.json 2> $out/c4_rccl.err
 timeout 600 python3 scripts/pacbio_full_size.py 8960 $out/c5_full_size.json > /dev/null 2> $out/c5_full_size.err
+# (measurement build of the SAME tree: scripts/build_variant.sh wgclocks -DADVNTR_WG_CLOCKS before the call)
 if [ -f exp/wgclocks.so ]; then
   for w in "c4 1120" "c2 840" "ref150" "s300"; do timeout 200 python3 scripts/wg_clocks.py $w 2>/dev/null | tail -1; done > $out/wg_clocks.jsonl
 fi
