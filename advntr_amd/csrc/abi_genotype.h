@@ -141,17 +141,8 @@ template <class Src>
 static int encode_reads_host(const char *who, Src &&src_of, int32_t n_reads, uint32_t flags, int32_t n_threads,
                              const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad)
 {
-    struct Table {
-        uint8_t code[256];
-        explicit Table(bool fold)
-        {
-            memset(code, 255, sizeof code);
-            code['A'] = 0; code['C'] = 1; code['G'] = 2; code['T'] = 3; code['N'] = 254;
-            if (fold) { code['a'] = 0; code['c'] = 1; code['g'] = 2; code['t'] = 3; code['n'] = 254; }
-        }
-    };
-    static const Table folded(true), exact(false);
-    const Table &table = (flags & ADVNTR_ENCODE_CASE_SENSITIVE) ? exact : folded;
+    // (clearing bit 5 folds a-z onto A-Z and maps nothing else onto a letter)
+    const uint8_t fold_mask = (flags & ADVNTR_ENCODE_CASE_SENSITIVE) ? 0xFF : 0xDF;
     const int64_t total = out_off[n_reads] - out_off[0];
     const int64_t mean = std::max<int64_t>(1, total / std::max(n_reads, 1));
     const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)512 << 10) / mean));
@@ -168,8 +159,17 @@ static int encode_reads_host(const char *who, Src &&src_of, int32_t n_reads, uin
                 if (n < 0 || out_off[r + 1] - out_off[r] != n || (n && !src)) { bad_span = r; continue; }
                 uint8_t *dst = out_codes + out_off[r];
                 uint8_t any = 0, other = 0;
+                // compare-and-select per byte instead of a table lookup: the loop vectorises (16-32 bases per instruction;
+                // the lookup was a dependent load per base -- 1.8 core-seconds for the 1.8 GB of config 5's reads)
+                const uint8_t keep = fold_mask;
                 for (int64_t i = 0; i < n; ++i) {
-                    const uint8_t c = table.code[src[i]];
+                    const uint8_t f = (uint8_t)(src[i] & keep);
+                    uint8_t c = 255;
+                    c = f == 'A' ? (uint8_t)0 : c;
+                    c = f == 'C' ? (uint8_t)1 : c;
+                    c = f == 'G' ? (uint8_t)2 : c;
+                    c = f == 'T' ? (uint8_t)3 : c;
+                    c = f == 'N' ? (uint8_t)254 : c;
                     dst[i] = c;
                     any |= c;
                     other |= (uint8_t)(c == 255);
