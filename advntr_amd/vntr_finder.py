@@ -306,7 +306,8 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     reads; -> bind reads and models into a device batch (routing, tile lists, upload); the calling thread only launches a
     piece's kernels (both strands, reverse complements made on the device) and has the reads selected on the device (strand
     choice, recruit rule, more than two repeat bases: advntr_batch_recruit), so that only the selected reads' records come
-    back.  The per-locus aggregation and the maximum-likelihood genotypes run once over all pieces at the end.  Same results
+    back.  The per-locus aggregation and the maximum-likelihood genotypes of a piece run on one more thread while the next
+    piece is scored (that thread also drops what the piece leaves behind).  Same results
     as genotype_loci(build_read_matcher_models(loci), ...).  timings (a dict) receives wall seconds per stage.
     ramp: the first piece goes in parts of 1, 1, 2, 4 ... `ramp`-ths, so that the device starts after a small piece's host work
     instead of a full one's; piece_fractions: explicit piece sizes instead (shares of the locus set); stage_threads = (build, upload, encode) host threads of the three threaded stages."""
@@ -369,18 +370,37 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
                      (T, "encode_reads"))
     bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
     stages = [built, uploaded, encoded, bound]
-    # what a scored piece leaves behind (its models' handles, the batch, the encoded reads) is dropped on a thread of its own:
-    # 840 models are 840 destructor calls, 3-20 ms that the calling thread would spend between two pieces' kernels
+    # What follows a piece's kernels runs on a thread of its own: the aggregation and the maximum-likelihood genotypes of the
+    # piece's loci (pieces are whole loci), and the release of what the piece leaves behind -- 840 models are 840 destructor
+    # calls, 3-20 ms that the calling thread would otherwise spend between two pieces' kernels
     import queue
     spent = queue.Queue()
+    results, after = [None] * chunks, {"error": None}
 
-    def reap():
-        while spent.get() is not None:
-            pass
+    def finish_pieces():
+        while True:
+            item = spent.get()
+            if item is None:
+                return
+            k, selected = item[0], item[1]
+            del item                                # the piece's models leave the device with their last reference
+            if after["error"] is not None:
+                continue
+            try:
+                t = time.perf_counter()
+                n_piece = cuts[k + 1] - cuts[k]
+                if selected is None:
+                    locus, summ = np.zeros(0, np.int64), np.zeros((0, _lib.SUMMARY_INTS), np.int32)
+                else:
+                    locus, summ = selected
+                bounds = np.searchsorted(locus, np.arange(n_piece + 1)).astype(np.int64)
+                results[k] = find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=max(1, t_enc))
+                T["aggregate_genotype"] += time.perf_counter() - t
+            except BaseException as e:              # noqa: BLE001 -- handed to the caller after the join
+                after["error"] = e
 
-    reaper = threading.Thread(target=reap, name="advntr-release", daemon=True)
-    reaper.start()
-    parts = []
+    finisher = threading.Thread(target=finish_pieces, name="advntr-aggregate-release", daemon=True)
+    finisher.start()
     try:
         for k in range(chunks):
             tw = time.perf_counter()
@@ -402,13 +422,15 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
                     t1 = time.perf_counter()
                     batch.close()
                     marks.append(("close", t1, time.perf_counter()))
-                parts.append((prep["locus"][index].astype(np.int64) + cuts[k], summ))
+                selected = (prep["locus"][index].astype(np.int64), summ)      # survivors in read order: grouped by locus
+            else:
+                selected = None
             T["score_recruit"] += time.perf_counter() - t
             if "trace" in T:
                 T["trace"].append(("score_recruit", k, t, time.perf_counter()))
             t1 = time.perf_counter()
-            spent.put((models, prep, batch, item))  # the piece's models leave the device with their last reference
-            del models, prep, batch, item
+            spent.put((k, selected, models, prep, batch, item))
+            del models, prep, batch, item, selected
             if "trace" in T:
                 marks.append(("release", t1, time.perf_counter()))
                 T["trace"] += [("  dev:" + nm, k, a, b) for nm, a, b in marks]
@@ -422,13 +444,10 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
             if isinstance(left, tuple) and left[2] is not None:
                 left[2].close()
         spent.put(None)
-    t = time.perf_counter()
-    locus = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
-    summ = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, _lib.SUMMARY_INTS), np.int32)
-    bounds = np.searchsorted(locus, np.arange(n_loci + 1)).astype(np.int64)
-    out = find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=threads)
-    T["aggregate_genotype"] = time.perf_counter() - t
-    reaper.join()
+    finisher.join()
+    if after["error"] is not None:
+        raise after["error"]
+    out = [g for piece in results for g in piece]
     T["total"] = time.perf_counter() - t0
     if timings is not None:
         timings.update(T)

@@ -16,7 +16,7 @@ gc.collect(); gc.freeze()
 _lib.require_gpu()
 vntr_finder.genotype_loci_pipelined(desc[:64], cand[:64], chunks=2)
 g = [1 / 64, 1 / 64, 1 / 32, 1 / 16]
-plans = [dict(), dict(chunks=16), dict(chunks=8, ramp=8), dict(chunks=6, ramp=4),
+plans = [dict(), dict(chunks=16, ramp=4),
          dict(piece_fractions=[1 / 32, 1 / 32, 1 / 16] + [1 / 8] * 7), dict(piece_fractions=g + [1 / 8, 1 / 8] + [1 / 4] * 3),
          dict(chunks=12, ramp=4), dict(chunks=10, ramp=6)]
 import collections
