@@ -297,7 +297,7 @@ class _Aborted(Exception):
 
 
 def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filter=False, is_haploid=False,
-                            compute_reverse=True, chunks=8, threads=0, timings=None, stage_threads=None, ramp=4,
+                            compute_reverse=True, chunks=12, threads=0, timings=None, stage_threads=None, ramp=4,
                             piece_fractions=None):
     """genotype_loci from the locus DESCRIPTIONS -- loci = [(left_flank, right_flank, aligned_repeat_units, copies), ...], what
     the reference turns into a model per locus inside its serial loop (genome_analyzer.py:280-297 -> vntr_finder.py:117-138) --
@@ -401,39 +401,60 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
 
     finisher = threading.Thread(target=finish_pieces, name="advntr-aggregate-release", daemon=True)
     finisher.start()
+    def finish(k, item):
+        """Piece k's kernels are queued: wait for them, have the reads selected, hand the piece to the finisher."""
+        models, prep, batch = item
+        t = time.perf_counter()
+        selected = None
+        if batch is not None:
+            try:
+                index, _, summ, _ = batch.recruit(None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]], 2)
+            finally:
+                batch.close()
+            selected = (prep["locus"][index].astype(np.int64), summ)      # survivors in read order: grouped by locus
+        T["score_recruit"] += time.perf_counter() - t
+        if "trace" in T:
+            T["trace"].append(("  dev:finish", k, t, time.perf_counter()))
+        spent.put((k, selected, models, prep, batch, item))
+
+    # The calling thread queues piece k + 1's kernels (every batch has a stream of its own) BEFORE it waits for piece k's: the
+    # device starts on the next piece while the last workgroups of the previous one drain, and the selection, the download and
+    # the interpreter's steps between two pieces are off the device's critical path
+    pending = None
     try:
         for k in range(chunks):
-            tw = time.perf_counter()
-            item = bound.out.get()
+            item = None
+            if pending is not None:
+                try:
+                    item = bound.out.get_nowait()
+                except queue.Empty:                 # nothing to launch yet: finish the piece in flight first
+                    finish(*pending)
+                    pending = None
+            if item is None:
+                tw = time.perf_counter()
+                item = bound.out.get()
+                if "trace" in T:
+                    T["trace"].append(("  dev:wait", k, tw, time.perf_counter()))
             if isinstance(item, BaseException):
                 raise item
-            models, prep, batch = item
             t = time.perf_counter()
-            marks = [("wait", tw, t)]
-            if batch is not None:
-                try:
-                    batch.run()
-                    batch.sync()
-                    marks.append(("run", t, time.perf_counter()))
-                    t1 = time.perf_counter()
-                    index, _, summ, _ = batch.recruit(None if scaled_scores is None else scaled_scores[cuts[k]:cuts[k + 1]], 2)
-                    marks.append(("recruit", t1, time.perf_counter()))
-                finally:
-                    t1 = time.perf_counter()
-                    batch.close()
-                    marks.append(("close", t1, time.perf_counter()))
-                selected = (prep["locus"][index].astype(np.int64), summ)      # survivors in read order: grouped by locus
-            else:
-                selected = None
+            try:
+                if item[2] is not None:
+                    item[2].run()
+            except BaseException:
+                if item[2] is not None:
+                    item[2].close()
+                raise
             T["score_recruit"] += time.perf_counter() - t
             if "trace" in T:
-                T["trace"].append(("score_recruit", k, t, time.perf_counter()))
-            t1 = time.perf_counter()
-            spent.put((k, selected, models, prep, batch, item))
-            del models, prep, batch, item, selected
-            if "trace" in T:
-                marks.append(("release", t1, time.perf_counter()))
-                T["trace"] += [("  dev:" + nm, k, a, b) for nm, a, b in marks]
+                T["trace"].append(("  dev:launch", k, t, time.perf_counter()))
+            if pending is not None:
+                finish(*pending)
+            pending = (k, item)
+            del item
+        if pending is not None:
+            finish(*pending)
+            pending = None
     finally:
         abort.set()                                 # (no stage is left waiting on a queue nobody serves any more)
         for st in stages:
@@ -443,6 +464,8 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
             left = bound.out.get_nowait()
             if isinstance(left, tuple) and left[2] is not None:
                 left[2].close()
+        if pending is not None and pending[1][2] is not None:      # launched, never finished (a failure in between)
+            pending[1][2].close()
         spent.put(None)
     finisher.join()
     if after["error"] is not None:

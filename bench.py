@@ -790,7 +790,7 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
            "stages_one_after_the_other": dict(T),
            "genotypes_identical_to_stage_by_stage": same == n_loci,
            "note": "from candidate reads in Python lists to RU-count genotypes; overlapped = model build / upload / read "
-                   "encoding of locus piece k+1 on host threads while piece k is scored (8 pieces, the first one in 3 growing parts); synthetic input "
+                   "encoding of locus piece k+1 on host threads while piece k is scored (12 pieces, the first one in 3 growing parts; a piece's kernels are queued before the previous piece's are waited for); synthetic input "
                    "generated in %.1f s (not timed)" % t_gen}
     # the kernel over the whole set's calls (mapped forward + unmapped on both strands, as BASELINE config 2 counts them)
     bases, off = _lib.encode_reads(reads)

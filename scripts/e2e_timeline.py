@@ -15,7 +15,7 @@ import gc
 gc.collect(); gc.freeze()
 _lib.require_gpu()
 vntr_finder.genotype_loci_pipelined(desc[:64], cand[:64], chunks=2)
-plans = [dict(chunks=8), dict(chunks=16, ramp=4), dict(chunks=16, ramp=4), dict(chunks=4), dict(chunks=16)]
+plans = [dict(), dict(chunks=16, ramp=4), dict(), dict(chunks=4), dict(chunks=16)]
 for i, plan in enumerate(plans):
     T = {"trace": None}
     t0 = time.perf_counter()
