@@ -1061,26 +1061,51 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     built = _Stage("advntr-pacbio-build", build, chunks, [extracted], abort, (T, "build_models"))
     ready = _Stage("advntr-pacbio-upload", upload_encode, chunks, [built], abort, None)
     ru_parts, count = [], np.zeros(n_loci, np.int64)
+
+    def collect(k, item):
+        """Piece k's kernels are queued: wait for them and take the RU counts."""
+        t = time.perf_counter()
+        have, models, batch, which = item
+        try:
+            _, summ = batch.fetch()
+        finally:
+            batch.close()
+        ru_parts.append(summ[:, _lib.SUM_RU].astype(np.int32))
+        np.add.at(count, cuts[k] + have.astype(np.int64)[which], 1)
+        T["score"] += time.perf_counter() - t
+        if "trace" in T:
+            T["trace"].append(("score", k, t, time.perf_counter()))
+
+    # (as in genotype_loci_pipelined: piece k + 1's kernels are queued before piece k's are waited for)
+    pending = None
     try:
         for k in range(chunks):
-            item = ready.out.get()
+            item = None
+            if pending is not None:
+                try:
+                    item = ready.out.get_nowait()
+                except queue.Empty:
+                    collect(*pending)
+                    pending = None
+            if item is None:
+                item = ready.out.get()
             if isinstance(item, BaseException):
                 raise item
-            t = time.perf_counter()
             if item is not None:
-                have, models, batch, which = item
+                t = time.perf_counter()
                 try:
-                    batch.run()
-                    _, summ = batch.fetch()
-                finally:
-                    batch.close()
-                ru_parts.append(summ[:, _lib.SUM_RU].astype(np.int32))
-                np.add.at(count, cuts[k] + have.astype(np.int64)[which], 1)
-                del have, models, batch, which
-            T["score"] += time.perf_counter() - t
-            if "trace" in T:
-                T["trace"].append(("score", k, t, time.perf_counter()))
+                    item[2].run()
+                except BaseException:
+                    item[2].close()
+                    raise
+                T["score"] += time.perf_counter() - t
+            if pending is not None:
+                collect(*pending)
+            pending = (k, item) if item is not None else None
             del item
+        if pending is not None:
+            collect(*pending)
+            pending = None
     finally:
         abort.set()
         for st in (whole, extracted, built, ready):
@@ -1089,6 +1114,8 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
             left = ready.out.get_nowait()
             if isinstance(left, tuple):
                 left[2].close()
+        if pending is not None:                     # launched, never collected (a failure in between)
+            pending[1][2].close()
     t = time.perf_counter()
     off = np.zeros(n_loci + 1, np.int64)
     np.cumsum(count, out=off[1:])
