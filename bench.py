@@ -12,11 +12,15 @@ reads; inputs are in HBM before the timed region.  Prints ONE JSON line on rank 
       `end_to_end` (BASELINE config 2: 6 719 loci, kernel alone and candidate reads -> genotypes), `scale_rehearsal` (the 8-rank
       strong-scaling line projected from this one GPU), `c4`, `c4_scale_rehearsal` and `pacbio_end_to_end` (BASELINE config 5:
       8 960 PacBio loci, its 8-rank split rehearsed; whole 5-15 kb reads -> genotypes), `prefilter` and `flank_align` (the two
-      kernels upstream of the scoring path).  About 30 s on the GPU box.
+      kernels upstream of the scoring path), `two_passes_in_flight` (the C1 batch with the next pass queued on a second copy's
+      stream).  About 40 s on the GPU box.
   --gpus N > 1: config C3 -- ONE set of 6 719 synthetic Illumina loci (~1.07 M calls) partitioned over the N GPUs by
       estimated work (strong scaling; whole loci per rank, LPT), every rank scores its share with no exchange, and the
       per-call result records are gathered to rank 0 over RCCL inside the timed region (the gather of pass i overlaps
       the kernels of pass i+1; all gathers complete before the clock stops).  `value` = calls of the WHOLE set per second.
+      The strong-scaling lines keep TWO passes in flight (--in-flight, class Passes): consecutive passes alternate between two
+      copies of the rank's device batch (scratch, results and stream of their own), so pass i+1 starts while the last
+      workgroups of pass i drain -- the end of a launch is most of what separates an 8-rank share from an eighth of the set.
   --workload c4 --gpus N: BASELINE config 5 the same way -- ONE set of 8 960 PacBio loci (179 200 calls), whole loci to ranks
       by LPT on what is known of a locus before its reads exist (workloads.c4_plan), records gathered over RCCL, "strong".
 
@@ -70,6 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-c2", action="store_true",
                     help="c1 at --gpus 1: leave out the `c2` and `end_to_end` sub-records (the 6719-locus target configuration)")
     ap.add_argument("--c2-loci", type=int, default=6719, help="loci of the `c2` / `end_to_end` sub-records")
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="passes queued at a time (0 = the workload's default: 2 for the strong-scaling lines c3 / c4, else 1): "
+                         "with 2, consecutive passes alternate between two copies of the device batch (own scratch, own stream) "
+                         "and pass k + 1 starts while the last workgroups of pass k drain")
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one process, one GPU (--workload c3 or c4): partition the locus set for this many ranks (LPT, as --gpus N does), run every "
                          "rank's share as its own resident batch with the multi-GPU launch parameters and print a "
@@ -305,6 +313,8 @@ def main(argv=None):
     flags = (_lib.FLAG_FORCE_GENERIC if args.generic else _lib.FLAG_STREAM if args.stream else
              _lib.FLAG_ANTIDIAGONAL if args.antidiagonal else 0)
     total_calls, t_build, plan_info = None, 0.0, {}
+    # passes queued at a time (class Passes): the strong-scaling lines alternate between two copies of a rank's device batch
+    in_flight = args.in_flight if args.in_flight else (2 if workload in ("c3", "c4") else 1)
     host_workers = max(1, min(32, (os.cpu_count() or 2) // world - 1))
     if workload in ("c3", "c4"):
         # every rank derives the same plan and the same LPT partition without communicating
@@ -356,7 +366,9 @@ def main(argv=None):
         from advntr_amd.pomegranate import device_models
         dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
         n_reads = len(reads)
-        batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
+        make_batch = lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags)          # noqa: E731
+        passes = Passes(make_batch, in_flight)
+        batch = passes.batches[0]
         ms = np.array([d.m for d in dms])
         m = int(round(float(np.mean(ms[which]))))
         edges_per_locus = np.array([l.model.n_edges for l in loci], np.int64)
@@ -387,7 +399,10 @@ def main(argv=None):
         bases, off = _lib.encode_reads(reads)
         comm = join_job()
         _lib.require_gpu()
-        batch = _lib.DeviceBatch([locus.model.device_model()], bases, off, np.zeros(n_reads, np.int32), flags=flags)
+        c1_model = locus.model.device_model()
+        make_batch = lambda: _lib.DeviceBatch([c1_model], bases, off, np.zeros(n_reads, np.int32), flags=flags)    # noqa: E731
+        passes = Passes(make_batch, in_flight)
+        batch = passes.batches[0]
         alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
         relax_total = float(n_reads) * (n + 1) * E
     kinfo = batch.kernel_info()                 # what the engine launches for this batch (advntr_batch_info)
@@ -404,15 +419,18 @@ def main(argv=None):
     host_gather = comm is not None and comm.backend == "host" and world > 1 and comm.fallback_reason is not None
 
     def step():
-        batch.run()
+        b = passes.run()                                    # (two in flight: the copy whose previous pass is the older one)
         if use_gather:
             if state["pending"]:                            # the previous gather has had a whole pass to finish
                 comm.gather_results_finish(fetch=False)
                 state["gather_ms"] = comm.last_gather_ms()
-            comm.gather_results_start(batch, counts, root=0)      # queued behind this pass; the next pass overlaps it
+            # queued behind this pass on its copy's stream; the next pass overlaps it (the copy's own next pass leaves the
+            # slots the gather asks for: with two copies that is the pass that overlaps the NEXT gather -- every pass but the
+            # first two leaves them)
+            comm.gather_results_start(b, counts, root=0)
             state["pending"] = True
         elif host_gather:
-            state["host"] = comm.gather_results(batch, counts, root=0)
+            state["host"] = comm.gather_results(b, counts, root=0)
 
     def drain(fetch=False):
         out = (None, None)
@@ -425,14 +443,14 @@ def main(argv=None):
     for _ in range(args.warmup):
         step()
     drain()
-    batch.sync()
+    passes.sync()
     if comm:
         comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()                                                # every gather of the timed steps completes inside the region
-    batch.sync()
+    passes.sync()                                          # ... and so does every pass, on either copy
     if comm:
         comm.barrier()
     elapsed_mine = time.perf_counter() - t0
@@ -523,6 +541,7 @@ def main(argv=None):
                             "calls_this_rank": int(n_reads), "read_len": n, "kernel": kernel,
                             "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
                             "outputs": "logp + RU count + 6 path summaries per read",
+                            "passes_in_flight": in_flight,
                             "relaxations_per_s": value * relax_total / max(n_reads, 1)}, **plan_info),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -560,6 +579,14 @@ def main(argv=None):
                 b["issue_bound_ms_at_measured_clock"] = valu_insts * 4 / (SIMDS * ghz * 1e9) * 1e3
                 b["frac_at_measured_clock"] = b["issue_bound_ms_at_measured_clock"] / kernel_ms
                 b["frac_at_measured_clock_and_4p5_cycles_per_inst"] = b["issue_bound_ms_at_measured_clock"] * 4.5 / 4 / kernel_ms
+        if workload in ("c1", "s300") and world == 1 and in_flight == 1:
+            # the same batch with two passes queued at a time (class Passes; what `--in-flight 2` makes the line itself): the
+            # next pass starts while the last workgroups of this one drain.  Reported beside the line, not as its value: the
+            # line's kernel time, roofline and profiles are those of one launch at a time
+            ms2 = two_in_flight_ms(batch, make_batch, max(1, args.steps))
+            out["two_passes_in_flight"] = {"ms_per_step": ms2, "value": total_reads / (ms2 * 1e-3), "unit": "reads/s",
+                                           "note": "consecutive passes alternate between two copies of the device batch "
+                                                   "(own scratch, results and stream); every pass scores every read"}
         if workload == "c1" and not args.no_s300:
             out["s300"] = s300_record(_lib, workloads, flags, args)
             out["log_probability"] = forward_record(_lib, locus, batch, bases, off, n_reads, n, args)
@@ -573,10 +600,13 @@ def main(argv=None):
                 out["flank_align"] = flank_align_record(_lib, upstream_input, args)
                 out["prefilter"] = prefilter_record(_lib, upstream_input, args)
         if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3", "c4"):
-            batch.close()                                   # (a rank has its GPU to itself: see c4_record)
+            whole = {"calls": int(n_reads), "kernel_ms": kernel_ms,
+                     "loop_ms": Passes.ms_per_pass(passes_of(batch), max(1, args.steps)),
+                     "loop_ms_two_passes_in_flight": (elapsed / args.steps * 1e3 if in_flight == 2 else
+                                                      two_in_flight_ms(batch, make_batch, max(1, args.steps)))}
+            passes.close()                                  # (a rank has its GPU to itself: see c4_record)
             out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
-                                                     {"calls": int(n_reads), "loop_ms": elapsed / args.steps * 1e3,
-                                                      "kernel_ms": kernel_ms}, flags, max(1, args.steps),
+                                                     whole, flags, max(1, args.steps),
                                                      planned_work=work if workload == "c4" else None,
                                                      root_capacity=args.root_capacity)
         if workload == "c1" and world == 1 and not args.no_cpu:
@@ -609,7 +639,7 @@ def main(argv=None):
                                              "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
                                                        "bit-equal on the sample" % (n_mt, cores)}
         emit(out)
-    batch.close()
+    passes.close()
     if comm:
         comm.close()
     return rc
@@ -669,6 +699,62 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     return rec
 
 
+class Passes(object):
+    """Consecutive passes over ONE resident batch, one or two of them queued at a time.  With two, the passes alternate between
+    two copies of the device batch -- same models, same reads, scratch, result arrays and stream of their own: pass k + 1 is
+    queued behind nothing but its own copy's previous pass and starts while the last workgroups of pass k drain (the dynamic
+    dequeue of a launch ends on single sweeps: 2-4 % of a launch, most of what separates an 8-rank share from an eighth of the
+    whole set).  Every pass scores every read; the copies hold identical results."""
+
+    def __init__(self, make, in_flight):
+        self.batches = [make() for _ in range(max(1, int(in_flight)))]
+        self.k = 0
+
+    def run(self, reserve=0):
+        b = self.batches[self.k % len(self.batches)]
+        self.k += 1
+        if reserve:
+            b.reserve_next(reserve)
+        b.run()
+        return b
+
+    def sync(self):
+        for b in self.batches:
+            b.sync()
+
+    def ms_per_pass(self, steps, warm=2, reserve=0):
+        for _ in range(warm):
+            self.run(reserve)
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.run(reserve)
+        self.sync()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def close(self):
+        for b in self.batches:
+            b.close()
+
+
+def passes_of(batch):
+    """One pass at a time over an existing device batch."""
+    one = Passes(lambda: None, 0)
+    one.batches = [batch]
+    return one
+
+
+def two_in_flight_ms(batch, make, steps, reserve=0):
+    """ms per pass with two passes in flight: `batch` and a second copy of it made here (and given back)."""
+    twin = make()
+    try:
+        both = passes_of(batch)
+        both.batches.append(twin)
+        return both.ms_per_pass(steps, reserve=reserve)
+    finally:
+        twin.close()
+
+
 def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole, flags, steps, planned_work=None,
                     root_capacity=0.99):
     """What a 1-GPU lease can say about the north star's "strong scaling to 8 GPUs": the C3 locus set partitioned for
@@ -701,22 +787,19 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
             sub_bases = bases[np.repeat(sel, lens)]
         sub_off = np.zeros(int(sel.sum()) + 1, np.int64)
         np.cumsum(lens[sel], out=sub_off[1:])
-        batch = _lib.DeviceBatch([dms[int(k)] for k in mine], sub_bases, sub_off, remap[which[sel]], flags=flags)
-        for _ in range(2):
-            batch.reserve_next(8)
-            batch.run()
-        batch.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            batch.reserve_next(8)
-            batch.run()
-        batch.sync()
-        loop_ms = (time.perf_counter() - t0) / steps * 1e3
+        make = lambda: _lib.DeviceBatch([dms[int(k)] for k in mine], sub_bases, sub_off, remap[which[sel]], flags=flags)   # noqa: E731
+        one = Passes(make, 1)
+        batch = one.batches[0]
+        loop_ms = one.ms_per_pass(steps, reserve=8)
+        loop2_ms = two_in_flight_ms(batch, make, steps, reserve=8)
         kernel_ms = batch.run_timed(steps)                  # (no reservation: the kernel alone)
-        shares.append({"rank": r, "loci": int(len(mine)), "calls": int(sel.sum()), "loop_ms": loop_ms, "kernel_ms": kernel_ms})
-        batch.close()
+        shares.append({"rank": r, "loci": int(len(mine)), "calls": int(sel.sum()), "loop_ms": loop_ms,
+                       "loop_ms_two_passes_in_flight": loop2_ms, "kernel_ms": kernel_ms})
+        one.close()
     worst_loop = max(x["loop_ms"] for x in shares)
+    worst_loop2 = max(x["loop_ms_two_passes_in_flight"] for x in shares)
     worst_kernel = max(x["kernel_ms"] for x in shares)
+    whole2 = whole.get("loop_ms_two_passes_in_flight")
     return {"projection": True, "ranks": n_ranks, "whole_set": whole, "shares": shares,
             "sum_of_shares_loop_ms": sum(x["loop_ms"] for x in shares), "slowest_share_loop_ms": worst_loop,
             "load_imbalance_max_over_mean": max(loads) / (sum(loads) / n_ranks),
@@ -724,9 +807,13 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
             "root_share_loop_ms_over_slowest": shares[0]["loop_ms"] / worst_loop,
             "actual_cells_imbalance_max_over_mean": max(actual) / (sum(actual) / n_ranks),
             "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0),
-            "projected_efficiency": whole["loop_ms"] / (n_ranks * worst_loop),
+            # as the strong-scaling lines run (bench.py --workload c3|c4: two passes in flight, class Passes) ...
+            "projected_efficiency": (whole2 / (n_ranks * worst_loop2)) if whole2 else whole["loop_ms"] / (n_ranks * worst_loop),
+            "passes_in_flight": 2 if whole2 else 1,
+            # ... and with one pass at a time (rounds 3-5: a share's launch ends on single sweeps that nothing overlaps)
+            "projected_efficiency_one_pass_in_flight": whole["loop_ms"] / (n_ranks * worst_loop),
             "projected_efficiency_kernels_only": whole["kernel_ms"] / (n_ranks * worst_kernel),
-            "projected_value_calls_per_s": float(len(lens)) / (worst_loop * 1e-3),
+            "projected_value_calls_per_s": float(len(lens)) / ((worst_loop2 if whole2 else worst_loop) * 1e-3),
             "partitioned_by": ("estimated work per locus (calls x (reference VNTR length + 201) x expected states, workloads.c4_plan)"
                                if planned_work is not None else "exact work per locus (calls x 151 x states)"),
             "excludes": "the RCCL gather of the result records (40 B per call to rank 0, queued behind pass i and overlapped with "
@@ -804,6 +891,7 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     batch.sync()
     dt = (time.perf_counter() - t0) / steps
     kernel_ms = batch.run_timed(steps)
+    dt2_ms = two_in_flight_ms(batch, lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags), steps)
     logp, summ = batch.fetch()
     kinfo = batch.kernel_info()
     kernels = [k[:3] for k in kinfo]
@@ -816,6 +904,7 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
     c2 = {"loci": n_loci, "calls": len(reads), "mean_states": float(np.mean(ms[which])), "read_len": int(round(float(lens.mean()))),
           "value": len(reads) / dt, "unit": "calls/s", "ms_per_step": dt * 1e3, "steps": steps, "kernel_ms": kernel_ms,
+          "ms_per_step_two_passes_in_flight": dt2_ms,
           "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBPS, "algorithmic_gb_per_launch": alg / 1e9,
@@ -823,7 +912,8 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
                        "note": "exact sum over the calls of n + (n+1) m + (n+m) + 32 bytes (SURVEY 8d) / HIP-event kernel time"}}
     from advntr_amd import sharding
     c2["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
-                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
+                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms,
+                                             "loop_ms_two_passes_in_flight": dt2_ms}, flags, steps,
                                             root_capacity=args.root_capacity)
     if not args.no_cpu:
         # per-locus sample against the oracle: log-probabilities bit for bit, repeat-unit counts as hmm_utils derives them
@@ -932,6 +1022,7 @@ def c4_record(_lib, workloads, inp, flags, args):
     batch.sync()
     dt = (time.perf_counter() - t0) / steps
     kernel_ms = batch.run_timed(steps)
+    dt2_ms = two_in_flight_ms(batch, lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags), steps)
     logp, summ = batch.fetch()
     kinfo = batch.kernel_info()
     kernel = max(kinfo, key=lambda k: k[1])[0]
@@ -945,6 +1036,7 @@ def c4_record(_lib, workloads, inp, flags, args):
     rec = {"loci": len(loci), "calls": len(reads), "mean_states": float(np.mean(ms[which])), "read_len_mean": float(lens.mean()),
            "read_len_min_max": [int(lens.min()), int(lens.max())], "model_build_s": t_build,
            "value": len(reads) / dt, "unit": "calls/s", "ms_per_step": dt * 1e3, "steps": steps, "kernel_ms": kernel_ms,
+           "ms_per_step_two_passes_in_flight": dt2_ms,
            "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
            "relaxations_per_s": float(np.sum((lens + 1) * edges[which])) / dt,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -962,7 +1054,8 @@ def c4_record(_lib, workloads, inp, flags, args):
     # back before the shares are laid out, or their launches would be sized for what is left)
     batch.close()
     rec["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
-                                             {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms}, flags, steps,
+                                             {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms,
+                                              "loop_ms_two_passes_in_flight": dt2_ms}, flags, steps,
                                              planned_work=[c * (ln + 1) * st for c, ln, st in plan],
                                              root_capacity=args.root_capacity)
     if not args.no_cpu:

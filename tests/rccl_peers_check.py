@@ -33,17 +33,23 @@ def scenario(world, root, counts, seed):
             c = comm.RcclComm(comm.FileRendezvous(rank, world, rdzv_dir, timeout=120.0), init_timeout=120.0)
             reads = workloads.make_reads(np.random.default_rng(seed + rank), locus, counts[rank], 150)
             bases, off = _lib.encode_reads(reads) if reads else (np.zeros(0, np.uint8), np.zeros(1, np.int64))
+            # two copies of the rank's device batch, as bench.py's strong-scaling lines alternate them (class Passes)
             batch = _lib.DeviceBatch([dm], bases, off, np.zeros(counts[rank], np.int32))
+            twin = _lib.DeviceBatch([dm], bases, off, np.zeros(counts[rank], np.int32))
             batch.run()
             mine = batch.fetch()
             seen = c.allgather_i64(batch.n_reads)
             assert seen == list(counts), (seen, counts)
-            # pass 1's gather is in flight while pass 2 runs; pass 2's is fetched
+            # pass 1's gather (first copy) is in flight while pass 2 runs on the other copy; pass 2's gather is queued while
+            # pass 3 is on the first copy again, and fetched
             c.gather_results_start(batch, seen, root=root)
-            batch.run()
+            twin.run()
             c.gather_results_finish(fetch=False)
-            c.gather_results_start(batch, seen, root=root)
+            c.gather_results_start(twin, seen, root=root)
+            batch.run()
             logp, summ = c.gather_results_finish(fetch=True)
+            batch.sync()
+            twin.close()
             blobs = c.gather_bytes(blob_of(rank, world), root)
             c.barrier()
             top = c.allreduce_max(10.0 + rank)
