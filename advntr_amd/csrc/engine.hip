@@ -62,7 +62,7 @@ struct DeviceCaches {
     std::mutex mu;
     std::multimap<size_t, void *> blocks[16];          // per device: free blocks by size
     size_t cached[16] = {0};
-    std::vector<hipStream_t> streams[16];
+    std::vector<hipStream_t> streams[16], streams_second[16];   // (second class: ADVNTR_FLAG_SECOND_QUEUE)
     std::vector<hipEvent_t> events[16];
     static constexpr size_t kMaxCached = (size_t)24 << 30;
 
@@ -126,6 +126,25 @@ struct DeviceCaches {
         return s;
     }
     void put_stream(int dev, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); streams[dev].push_back(s); }
+
+    // a stream of the second class: the highest stream priority the device offers (the runtime keeps the hardware queues of
+    // different priorities apart), or a plain one where it offers none
+    hipStream_t get_stream_second(int dev)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!streams_second[dev].empty()) { hipStream_t s = streams_second[dev].back(); streams_second[dev].pop_back(); return s; }
+        }
+        int least = 0, greatest = 0;
+        hipStream_t s = nullptr;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+            hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) == hipSuccess)
+            return s;
+        (void)hipGetLastError();
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return s;
+    }
+    void put_stream_second(int dev, hipStream_t s) { std::lock_guard<std::mutex> lk(mu); streams_second[dev].push_back(s); }
 
     hipEvent_t get_event(int dev)
     {
@@ -682,7 +701,7 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
     for (auto *H : B->models) B->m_max = std::max(B->m_max, H->m);
 
     B->device = current_device();
-    B->stream = g_cache.get_stream(B->device);
+    B->stream = (flags & ADVNTR_FLAG_SECOND_QUEUE) ? g_cache.get_stream_second(B->device) : g_cache.get_stream(B->device);
     B->ev0 = g_cache.get_event(B->device);
     B->ev1 = g_cache.get_event(B->device);
     if (!B->stream || !B->ev0 || !B->ev1) return fail(ADVNTR_ERR_DEVICE, "stream/event creation failed");
@@ -1042,7 +1061,10 @@ extern "C" void advntr_batch_destroy(advntr_batch *B)
     for (auto &a : B->allocs) g_cache.put(B->device, a.first, a.second);
     if (B->ev0) g_cache.put_event(B->device, B->ev0);
     if (B->ev1) g_cache.put_event(B->device, B->ev1);
-    if (B->stream) g_cache.put_stream(B->device, B->stream);
+    if (B->stream) {
+        if (B->flags & ADVNTR_FLAG_SECOND_QUEUE) g_cache.put_stream_second(B->device, B->stream);
+        else g_cache.put_stream(B->device, B->stream);
+    }
     std::vector<advntr_hmm *> last;                               // models destroyed by their owner while this batch lived
     {
         std::lock_guard<std::mutex> lock(g_model_life);

@@ -366,7 +366,7 @@ def main(argv=None):
         from advntr_amd.pomegranate import device_models
         dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
         n_reads = len(reads)
-        make_batch = lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags)          # noqa: E731
+        make_batch = lambda extra=0: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra)          # noqa: E731
         passes = Passes(make_batch, in_flight)
         batch = passes.batches[0]
         ms = np.array([d.m for d in dms])
@@ -400,7 +400,7 @@ def main(argv=None):
         comm = join_job()
         _lib.require_gpu()
         c1_model = locus.model.device_model()
-        make_batch = lambda: _lib.DeviceBatch([c1_model], bases, off, np.zeros(n_reads, np.int32), flags=flags)    # noqa: E731
+        make_batch = lambda extra=0: _lib.DeviceBatch([c1_model], bases, off, np.zeros(n_reads, np.int32), flags=flags | extra)    # noqa: E731
         passes = Passes(make_batch, in_flight)
         batch = passes.batches[0]
         alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
@@ -699,6 +699,9 @@ def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):
     return rec
 
 
+SECOND_QUEUE = 128        # ADVNTR_FLAG_SECOND_QUEUE (include/advntr_hip.h)
+
+
 class Passes(object):
     """Consecutive passes over ONE resident batch, one or two of them queued at a time.  With two, the passes alternate between
     two copies of the device batch -- same models, same reads, scratch, result arrays and stream of their own: pass k + 1 is
@@ -707,7 +710,9 @@ class Passes(object):
     whole set).  Every pass scores every read; the copies hold identical results."""
 
     def __init__(self, make, in_flight):
-        self.batches = [make() for _ in range(max(1, int(in_flight)))]
+        # make(extra_flags) -> device batch; the second copy's stream is of a class of its own (ADVNTR_FLAG_SECOND_QUEUE): two
+        # streams of one class can land on the same hardware queue, where their kernels would run strictly one after the other
+        self.batches = [make(SECOND_QUEUE if i else 0) for i in range(max(1, int(in_flight)))]
         self.k = 0
 
     def run(self, reserve=0):
@@ -739,14 +744,14 @@ class Passes(object):
 
 def passes_of(batch):
     """One pass at a time over an existing device batch."""
-    one = Passes(lambda: None, 0)
+    one = Passes(lambda extra: None, 0)
     one.batches = [batch]
     return one
 
 
 def two_in_flight_ms(batch, make, steps, reserve=0):
     """ms per pass with two passes in flight: `batch` and a second copy of it made here (and given back)."""
-    twin = make()
+    twin = make(SECOND_QUEUE)
     try:
         both = passes_of(batch)
         both.batches.append(twin)
@@ -787,7 +792,8 @@ def scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, n_ranks, whole
             sub_bases = bases[np.repeat(sel, lens)]
         sub_off = np.zeros(int(sel.sum()) + 1, np.int64)
         np.cumsum(lens[sel], out=sub_off[1:])
-        make = lambda: _lib.DeviceBatch([dms[int(k)] for k in mine], sub_bases, sub_off, remap[which[sel]], flags=flags)   # noqa: E731
+        make = lambda extra=0: _lib.DeviceBatch([dms[int(k)] for k in mine], sub_bases, sub_off, remap[which[sel]],      # noqa: E731
+                                                flags=flags | extra)
         one = Passes(make, 1)
         batch = one.batches[0]
         loop_ms = one.ms_per_pass(steps, reserve=8)
@@ -891,7 +897,7 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     batch.sync()
     dt = (time.perf_counter() - t0) / steps
     kernel_ms = batch.run_timed(steps)
-    dt2_ms = two_in_flight_ms(batch, lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags), steps)
+    dt2_ms = two_in_flight_ms(batch, lambda extra: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra), steps)
     logp, summ = batch.fetch()
     kinfo = batch.kernel_info()
     kernels = [k[:3] for k in kinfo]
@@ -1022,7 +1028,7 @@ def c4_record(_lib, workloads, inp, flags, args):
     batch.sync()
     dt = (time.perf_counter() - t0) / steps
     kernel_ms = batch.run_timed(steps)
-    dt2_ms = two_in_flight_ms(batch, lambda: _lib.DeviceBatch(dms, bases, off, which, flags=flags), steps)
+    dt2_ms = two_in_flight_ms(batch, lambda extra: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra), steps)
     logp, summ = batch.fetch()
     kinfo = batch.kernel_info()
     kernel = max(kinfo, key=lambda k: k[1])[0]

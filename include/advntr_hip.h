@@ -49,6 +49,13 @@ extern "C" {
                                          end of the batch; by default small batches and the tail of a large one get shallower
                                          tiles so that the work spreads over the CUs.  Results are identical */
 
+#define ADVNTR_FLAG_SECOND_QUEUE 128u /* the batch's stream is of a second class (a stream priority of its own): it never shares
+                                         a hardware queue with the stream of a batch created without the flag.  Streams of one
+                                         class are spread over a few hardware queues by the runtime, and two that land on the
+                                         same one run their kernels strictly one after the other; a caller that keeps two
+                                         copies of a batch so that the next pass starts while the previous one's last
+                                         workgroups drain creates one copy with the flag and one without.  Results identical */
+
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8
 #define ADVNTR_SUM_RU         0   /* get_number_of_repeats_in_vpath            [155-188] */

@@ -35,7 +35,7 @@ def scenario(world, root, counts, seed):
             bases, off = _lib.encode_reads(reads) if reads else (np.zeros(0, np.uint8), np.zeros(1, np.int64))
             # two copies of the rank's device batch, as bench.py's strong-scaling lines alternate them (class Passes)
             batch = _lib.DeviceBatch([dm], bases, off, np.zeros(counts[rank], np.int32))
-            twin = _lib.DeviceBatch([dm], bases, off, np.zeros(counts[rank], np.int32))
+            twin = _lib.DeviceBatch([dm], bases, off, np.zeros(counts[rank], np.int32), flags=_lib.FLAG_SECOND_QUEUE)
             batch.run()
             mine = batch.fetch()
             seen = c.allgather_i64(batch.n_reads)

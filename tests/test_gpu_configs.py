@@ -217,8 +217,14 @@ def test_scale_rehearsal_partitions_the_set_like_the_multi_gpu_job():
     assert r["projection"] is True and r["ranks"] == 4 and len(r["shares"]) == 4
     assert sum(x["calls"] for x in r["shares"]) == d["config"]["calls_this_rank"] == r["whole_set"]["calls"]
     assert sum(x["loci"] for x in r["shares"]) == 240
-    assert all(x["loop_ms"] > 0 and x["kernel_ms"] > 0 for x in r["shares"])
+    assert all(x["loop_ms"] > 0 and x["kernel_ms"] > 0 and x["loop_ms_two_passes_in_flight"] > 0 for x in r["shares"])
     assert 0.0 < r["projected_efficiency"] <= 1.5 and r["load_imbalance_max_over_mean"] >= 1.0
+    # the strong-scaling lines keep two passes in flight (two copies of the device batch): the line says so, both projections
+    # are in the record, and a pass of either copy gives the records the line's own check compares
+    assert d["config"]["passes_in_flight"] == 2 and r["passes_in_flight"] == 2
+    assert 0.0 < r["projected_efficiency_one_pass_in_flight"] <= 1.5 and r["whole_set"]["loop_ms_two_passes_in_flight"] > 0
+    one = _bench(["--workload", "c3", "--loci", "240", "--steps", "2", "--warmup", "1", "--no-cpu", "--in-flight", "1"])
+    assert one["config"]["passes_in_flight"] == 1 and one["config"]["calls_this_rank"] == d["config"]["calls_this_rank"]
     from advntr_amd import sharding, workloads
     plan = workloads.c2_plan(240, seed=20240602)
     parts = sharding.partition_loci([c * 151 * m for c, m in plan], 4, [0.99, 1, 1, 1])
