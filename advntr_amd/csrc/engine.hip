@@ -1277,7 +1277,10 @@ static int viterbi_batch_chunked(advntr_hmm *const *models, int32_t n_models, co
         for (int32_t i = 0; i <= m; ++i) off[i] = read_off[r0 + i] - read_off[r0];
         if (off[m] < 0) { rc = fail(ADVNTR_ERR_ARG, "batch: read_off not monotone"); break; }
         batches[c] = new advntr_batch();
-        rc = batch_build(batches[c], models, n_models, bases ? bases + read_off[r0] : nullptr, off.data(), read_model + r0, m, flags);
+        // (neighbouring chunks on streams of different classes: the next chunk's kernels start while the last workgroups of
+        // this one drain -- two streams of one class may share a hardware queue and then never overlap)
+        rc = batch_build(batches[c], models, n_models, bases ? bases + read_off[r0] : nullptr, off.data(), read_model + r0, m,
+                         flags | ((c & 1) ? ADVNTR_FLAG_SECOND_QUEUE : 0u));
         if (rc == ADVNTR_OK) rc = advntr_batch_run(batches[c]);
     }
     std::vector<double> lp;
