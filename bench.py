@@ -579,7 +579,8 @@ def main(argv=None):
                 b["issue_bound_ms_at_measured_clock"] = valu_insts * 4 / (SIMDS * ghz * 1e9) * 1e3
                 b["frac_at_measured_clock"] = b["issue_bound_ms_at_measured_clock"] / kernel_ms
                 b["frac_at_measured_clock_and_4p5_cycles_per_inst"] = b["issue_bound_ms_at_measured_clock"] * 4.5 / 4 / kernel_ms
-        if workload in ("c1", "s300") and world == 1 and in_flight == 1:
+        if workload in ("c1", "s300") and world == 1 and in_flight == 1 and not args.no_s300:
+            # (not with --no-s300: the profiler passes of scripts/profile_round5.sh trace one launch at a time only)
             # the same batch with two passes queued at a time (class Passes; what `--in-flight 2` makes the line itself): the
             # next pass starts while the last workgroups of this one drain.  Reported beside the line, not as its value: the
             # line's kernel time, roofline and profiles are those of one launch at a time
