@@ -3,7 +3,7 @@
 # (every profiler pass under its own timeout: a pass that hangs must not eat the call)
 # scripts/profile_round5.sh OUT lines: only the bench lines / records at the end (no profiler passes)
 out=$1; root=$(pwd); mkdir -p $root/$out
-B="--no-cpu --no-s300 --no-c2"
+B="--no-cpu --no-s300 --no-c2 --in-flight 1"       # (the profiler passes trace one launch at a time)
 if [ "$2" != "lines" ]; then
 for w in c1 s300 c2 c4; do timeout 200 python3 bench.py --workload $w $B --steps 2 > $out/${w}_quick.json 2> $out/${w}_quick.err; done
 cd /tmp && export TMPDIR=/tmp
