@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ADVNTR_HIP_LIB") or os.path.join(_HERE, "libadvntr_hi
 OK, ERR_ARG, ERR_SYMBOL, ERR_DEVICE, ERR_TOO_LARGE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY, FLAG_STREAM, FLAG_ANTIDIAGONAL, FLAG_BOTH_STRANDS = 1, 2, 4, 8, 16, 32
 FLAG_DEEP_TILES = 64
+FLAG_SPLIT_FINISH = 256   # sweep and finish as launches of their own (include/advntr_hip.h)
 FLAG_SECOND_QUEUE = 128      # a stream class of its own: see include/advntr_hip.h (two copies of a batch whose passes overlap)
 SUMMARY_INTS = 8
 SUM_RU, SUM_MATCHES, SUM_REPEAT_BP, SUM_LEFT_BP, SUM_RIGHT_BP, SUM_LEFT_MATCH, SUM_RIGHT_MATCH, SUM_PATH_LEN = range(8)

@@ -110,14 +110,17 @@ extern "C" int advntr_batch_recruit(advntr_batch *B, const double *scaled_score,
     if (n_fwd == 0) return ADVNTR_OK;
     const int n_waves = (n_fwd + 63) / 64;
     int rc;
-    if (!B->d_rec_choice) {
-        if ((rc = B->dmalloc(&B->d_rec_choice, (size_t)n_fwd))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_count, (size_t)n_waves + 1))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_scaled, B->models.size()))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_index, (size_t)n_fwd))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_logp, (size_t)n_fwd))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_summary, (size_t)n_fwd * ADVNTR_SUMMARY_INTS))) return rc;
-        if ((rc = B->dmalloc(&B->d_rec_reversed, (size_t)n_fwd))) return rc;
+    if (!B->d_rec_ready) {
+        // all or nothing: `d_rec_ready` is set behind the last allocation, so a call after a failed one allocates what is
+        // missing instead of launching the kernels on null pointers (what a failed call did get stays with the batch's blocks)
+        if (!B->d_rec_choice && (rc = B->dmalloc(&B->d_rec_choice, (size_t)n_fwd))) return rc;
+        if (!B->d_rec_count && (rc = B->dmalloc(&B->d_rec_count, (size_t)n_waves + 1))) return rc;
+        if (!B->d_rec_scaled && (rc = B->dmalloc(&B->d_rec_scaled, B->models.size()))) return rc;
+        if (!B->d_rec_index && (rc = B->dmalloc(&B->d_rec_index, (size_t)n_fwd))) return rc;
+        if (!B->d_rec_logp && (rc = B->dmalloc(&B->d_rec_logp, (size_t)n_fwd))) return rc;
+        if (!B->d_rec_summary && (rc = B->dmalloc(&B->d_rec_summary, (size_t)n_fwd * ADVNTR_SUMMARY_INTS))) return rc;
+        if (!B->d_rec_reversed && (rc = B->dmalloc(&B->d_rec_reversed, (size_t)n_fwd))) return rc;
+        B->d_rec_ready = true;
     }
     RecruitArgs a{};
     a.logp = B->d_logp; a.summary = B->d_summary; a.read_off = B->d_read_off; a.read_model = B->d_read_model;

@@ -56,6 +56,13 @@ extern "C" {
                                          copies of a batch so that the next pass starts while the previous one's last
                                          workgroups drain creates one copy with the flag and one without.  Results identical */
 
+#define ADVNTR_FLAG_SPLIT_FINISH 256u /* short reads of a large batch: the row-blocked kernel only sweeps, and the tail states,
+                                         tracebacks and path summaries of a chunk of reads run as a launch of their own behind
+                                         it (viterbi_rows_finish_kernel: many light wavefronts per SIMD hide the dependent round
+                                         trips of a traceback, which the three heavy sweeping wavefronts of a SIMD cannot).  Takes
+                                         back-pointer scratch per sweep of a chunk (~100 000 reads: ~9 GB on a 1 400-state model)
+                                         instead of per resident wavefront.  Results are identical */
+
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8
 #define ADVNTR_SUM_RU         0   /* get_number_of_repeats_in_vpath            [155-188] */
