@@ -14,7 +14,6 @@ LIB_PATH = os.environ.get("ADVNTR_HIP_LIB") or os.path.join(_HERE, "libadvntr_hi
 OK, ERR_ARG, ERR_SYMBOL, ERR_DEVICE, ERR_TOO_LARGE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 FLAG_PATH, FLAG_FORCE_GENERIC, FLAG_NO_SUMMARY, FLAG_STREAM, FLAG_ANTIDIAGONAL, FLAG_BOTH_STRANDS = 1, 2, 4, 8, 16, 32
 FLAG_DEEP_TILES = 64
-FLAG_SPLIT_FINISH = 256   # sweep and finish as launches of their own (include/advntr_hip.h)
 FLAG_SECOND_QUEUE = 128      # a stream class of its own: see include/advntr_hip.h (two copies of a batch whose passes overlap)
 SUMMARY_INTS = 8
 SUM_RU, SUM_MATCHES, SUM_REPEAT_BP, SUM_LEFT_BP, SUM_RIGHT_BP, SUM_LEFT_MATCH, SUM_RIGHT_MATCH, SUM_PATH_LEN = range(8)
@@ -172,7 +171,9 @@ _pylist_texts = None
 
 def _list_texts(seqs):
     """The buffers of a list of ASCII str -- (pointers uint64[n], lengths int64[n]) -- through ONE library call that walks the
-    list (advntr_pylist_texts, entered with the interpreter lock held), or None when the list holds anything else."""
+    list (advntr_pylist_texts of include/advntr_pyhost.h, entered with the interpreter lock held), or None when the list holds
+    anything else.  The pointers are borrowed from the strings: the caller keeps `seqs` unchanged until they have been consumed
+    (encode_ascii does so before it returns; str objects are immutable, so only removing items from the list could free one)."""
     global _pylist_texts
     if type(seqs) is not list:
         return None

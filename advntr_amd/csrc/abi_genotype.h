@@ -211,7 +211,7 @@ extern "C" int advntr_encode_texts(const char *const *texts, int32_t n_reads, ui
     }, n_reads, flags, n_threads, out_off, out_codes, out_bad);
 }
 
-// A CPython host's list of str -> buffer pointers and lengths (include/advntr_hip.h).  Called with the interpreter lock held.
+// A CPython host's list of str -> buffer pointers and lengths (include/advntr_pyhost.h: an optional helper beside the C ABI).  Called with the interpreter lock held.
 extern "C" int64_t advntr_pylist_texts(void *list, const char **texts, int64_t *lengths, int64_t capacity)
 {
     typedef long (*SizeFn)(void *);

@@ -27,15 +27,6 @@ struct ColumnLaunch {
                                             // gather runs beside it: abi_comm.h); consumed by that pass (advntr_batch_run)
     std::vector<ColTile> tiles[9];          // per chunk count K = 1..4, [4] = row-tiled long reads, [5..7] = row-blocked kernels,
                                             // [8] = row-blocked kernel for reads of more than 155 bases (row tiles)
-    // ADVNTR_FLAG_SPLIT_FINISH: the row-blocked short-read lists go out in chunks -- a sweep launch over the chunk's tiles, then a
-    // finish launch over its items (viterbi_rows.h) -- on scratch per sweep unit, reused chunk after chunk
-    struct RowsChunk { int slot, tile0, n_tiles, item0, n_items, n_units; };
-    bool split = false;
-    std::vector<RowsChunk> chunks;
-    std::vector<RowsFinishItem> items;
-    RowsFinishItem *d_items = nullptr;
-    int32_t *d_split_counters = nullptr;     // two per chunk (sweep, finish)
-    int finish_grid = 0;                    // workgroups of a finish launch (device full at its occupancy)
     ColTile *d_tiles[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t *d_tile_counters = nullptr;     // 9 counters
     double *d_rown = nullptr;
@@ -99,50 +90,6 @@ static inline void column_launch_rows(const ColumnLaunch &cl, const BatchArgs &a
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((viterbi_rows_kernel<R, G>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
-}
-
-// One chunk of a split launch (ColumnLaunch::RowsChunk): the sweeps of its tiles, then the finish of its reads
-template <int R, int G>
-static inline void column_launch_rows_split(const ColumnLaunch &cl, const BatchArgs &a, uint32_t flags, hipStream_t stream,
-                                            const ColumnLaunch::RowsChunk &ch, const int chunk_index)
-{
-    ColArgs g{};
-    g.a = a;
-    g.tiles = cl.d_tiles[ch.slot] + ch.tile0;
-    g.n_tiles = ch.n_tiles;
-    g.tile_counter = cl.d_split_counters + 2 * chunk_index;
-    g.rown = cl.d_rown; g.rown_stride = cl.rown_stride;
-    g.aux = cl.d_aux; g.aux_stride = cl.aux_stride;
-    g.bp = cl.d_bp; g.bp_stride = cl.bp_stride;
-    g.lds_tables = (int32_t)cl.lds_bytes;
-    g.lds_level = cl.lds_level;
-    g.sink_stride = cl.sink_stride;
-    g.rows_depth = cl.rows_depth;
-    const int grid = launch_grid(cl, g.n_tiles);
-    const size_t lds = cl.lds_bytes + 16 + ROWS_STASH_BYTES + ROWS_REV_BYTES + ROWS_TAIL_LDS_BYTES;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)viterbi_rows_kernel<R, G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((viterbi_rows_kernel<R, G, true>), dim3(grid), dim3(COL_WAVES * 64), lds, stream, g, flags);
-    g.tile_counter = cl.d_split_counters + 2 * chunk_index + 1;
-    const int fgrid = std::max(1, std::min(cl.finish_grid, (ch.n_items + COL_WAVES - 1) / COL_WAVES));
-    hipLaunchKernelGGL((viterbi_rows_finish_kernel<R, G>), dim3(fgrid), dim3(COL_WAVES * 64), ROWS_FINISH_LDS_BYTES, stream, g, flags,
-                       cl.d_items + ch.item0, ch.n_items);
-}
-
-// workgroups of the finish kernel that are resident per compute unit (asked of the runtime once per instantiation)
-template <int R, int G>
-static inline int rows_finish_occupancy()
-{
-    static const int wgs = [] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)viterbi_rows_finish_kernel<R, G>, COL_WAVES * 64,
-                                                         ROWS_FINISH_LDS_BYTES) != hipSuccess || n <= 0) {
-            (void)hipGetLastError();
-            n = 4;
-        }
-        return n;
-    }();
-    return wgs;
 }
 
 // reads of more than 155 bases, one per wavefront, row tiles of 64 * ROWS_LONG_R rows (viterbi_rows.h); tile list 8

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/advntr_hip.h"
+#include "../../include/advntr_pyhost.h"
 #include "device_model.h"
 #include "column_program.h"
 #include "viterbi_generic.h"
@@ -884,51 +885,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
             C.sink_stride = C.ring * TP + 2;
             C.rown_stride = 6 * (int64_t)C.nc_max + (int64_t)COL_STREAM_CAPS * (3 * (int64_t)C.nc_max + COL_MAX_TAIL);
         } else {
-            // ADVNTR_FLAG_SPLIT_FINISH: the short reads' lists are cut into chunks of about kSplitChunkReads reads, each shaped like
-            // a launch of its own (full depth, half depth, single sweeps), because each is one: sweep kernel, then finish kernel.
-            // Scratch is per sweep unit of ONE chunk (reused by the next: the launches of a batch are stream ordered).
-            int64_t bstart[4] = {0, 0, 0, 0};         // reads of buckets 0..2 are col_reads[bstart[b] .. bstart[b + 1])
-            {
-                int64_t cnt[3] = {0, 0, 0};
-                for (int r : col_reads) { const int b = kof(r); if (b < 3) cnt[b]++; }
-                for (int b = 0; b < 3; ++b) bstart[b + 1] = bstart[b] + cnt[b];
-            }
-            int64_t chunk_reads = 131072;
-            if (const char *e = getenv("ADVNTR_SPLIT_CHUNK_READS")) chunk_reads = std::max<int64_t>(1024, atoll(e));
-            C.split = (flags & ADVNTR_FLAG_SPLIT_FINISH) && use_rows && bstart[3] > 0;
-            if (C.split) {
-                // (a conservative estimate of what the units of one chunk take -- twice the sweeps of full depth -- against the memory
-                // that can be had; a batch that would not fit runs fused)
-                size_t free_b = 0, total_b = 0;
-                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
-                const int64_t budget = (int64_t)(free_b / 10 * 5) + (int64_t)g_cache.cached[B->device];
-                const int64_t unit_bytes = ((int64_t)ROWS_DEPTH * C.nc_max + 33) * 256 + 8 * (ROWS_MAX_GROUPS * 3 * ((int64_t)ROWS_DEPTH * C.nc_max + 64) + COL_MAX_TAIL) +
-                                           4 * (COL_MAX_TAIL + (int64_t)4 * (ROWS_DEPTH + 1) * COL_MAX_SINKS * (std::max(COL_MAX_READ, n_max_col) + 1));
-                while (chunk_reads > 8192 && std::min<int64_t>(chunk_reads, bstart[3]) / 4 * unit_bytes > budget) chunk_reads /= 2;
-                if (std::min<int64_t>(chunk_reads, bstart[3]) / 4 * unit_bytes > budget) C.split = false;
-            }
-            // chunk of bucket b that holds position i: equal chunks, multiples of 64 reads
-            auto chunk_of = [&](const int b, const int64_t i, int64_t &c0, int64_t &c1) {
-                const int64_t nb = bstart[b + 1] - bstart[b], nchunks = std::max<int64_t>(1, (nb + chunk_reads - 1) / chunk_reads);
-                const int64_t len = (((nb + nchunks - 1) / nchunks) + 63) & ~int64_t(63);
-                const int64_t ci = (i - bstart[b]) / len;
-                c0 = bstart[b] + ci * len;
-                c1 = std::min(bstart[b + 1], c0 + len);
-                return (int)ci;
-            };
             // tiles of up to 16 reads of one model and one chunk count; the last ~15 % of the reads go out in
             // smaller tiles (8, then 4 = one read per wave) so the dynamic dequeue ends evenly across the CUs
-            int split_chunk_id = -1;
             for (int i = 0; i < B->n_col;) {
                 const int r0 = col_reads[i], bucket = kof(r0), mod = read_model[r0];
-                int left = B->n_col - i, launch_reads = B->n_col, chunk_id = 0;
-                int64_t chunk_end = B->n_col;
-                if (C.split && bucket < 3) {
-                    int64_t c0 = 0;
-                    chunk_id = chunk_of(bucket, i, c0, chunk_end);
-                    launch_reads = (int)(chunk_end - c0);
-                    left = (int)(chunk_end - i);
-                }
+                const int left = B->n_col - i;
                 // small batches (a locus-sized call): one read per wavefront so the reads spread over the CUs
                 const int full = std::max<int>(COL_WAVES, std::min<int>(COL_TILE_READS, B->n_col / std::max(1, cus * per_cu)));
                 int cap = left > B->n_col * 15 / 100 ? full : (left > B->n_col * 5 / 100 ? std::max<int>(COL_WAVES, full / 2) : COL_WAVES);
@@ -946,54 +907,18 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                     const int nc = B->models[mod]->colprog.n_cols;
                     int depth = nc >= ROWS_STREAM_MIN_COLS ? ROWS_DEPTH : 1;
                     if (!(flags & ADVNTR_FLAG_DEEP_TILES)) {
-                        depth = std::max(1, std::min(depth, launch_reads / std::max(1, cus * per_cu * round)));
-                        if (left <= (int64_t)launch_reads * ROWS_TAIL_HALF_PCT / 100) depth = std::min(depth, std::max(1, ROWS_DEPTH / 2));
-                        if (left <= (int64_t)launch_reads * ROWS_TAIL_SINGLE_PCT / 100) depth = 1;
+                        depth = std::max(1, std::min(depth, B->n_col / std::max(1, cus * per_cu * round)));
+                        if (left <= B->n_col * ROWS_TAIL_HALF_PCT / 100) depth = std::min(depth, std::max(1, ROWS_DEPTH / 2));
+                        if (left <= B->n_col * ROWS_TAIL_SINGLE_PCT / 100) depth = 1;
                     }
                     cap = round * depth;
                     rows_groups = std::max(rows_groups, G);
                     C.rows_depth = std::max(C.rows_depth, depth);
                 }
                 int j = i;
-                while (j < chunk_end && j - i < cap && kof(col_reads[j]) == bucket && read_model[col_reads[j]] == mod) ++j;
-                const int slot = bucket <= 3 ? 5 + bucket : bucket - 4;
-                if (C.split && bucket < 3) {
-                    // (chunks of a list are numbered in order: a new chunk id opens the next RowsChunk; n_units is filled in below,
-                    // once the deepest tile of the batch -- the stride of a tile's rounds -- is known)
-                    if (C.chunks.empty() || C.chunks.back().slot != slot || split_chunk_id != chunk_id) {
-                        C.chunks.push_back(ColumnLaunch::RowsChunk{slot, (int)C.tiles[slot].size(), 0, 0, 0, 0});
-                        split_chunk_id = chunk_id;
-                    }
-                    C.chunks.back().n_tiles++;
-                }
-                C.tiles[slot].push_back(ColTile{mod, i, j - i, 0});
+                while (j < B->n_col && j - i < cap && kof(col_reads[j]) == bucket && read_model[col_reads[j]] == mod) ++j;
+                C.tiles[bucket <= 3 ? 5 + bucket : bucket - 4].push_back(ColTile{mod, i, j - i, 0});
                 i = j;
-            }
-            if (C.split) {
-                // sweep units and finish items of every chunk: a tile's rounds are COL_WAVES * G * dmax reads apart (dmax: the batch's
-                // deepest tile, or 1 on a model too narrow for back-to-back sweeps -- viterbi_rows_kernel), a unit is one wavefront of
-                // one round, an item the G reads side by side at one depth of a unit
-                for (ColumnLaunch::RowsChunk &ch : C.chunks) {
-                    const int G = rows_configs[ch.slot - 5].G, round = COL_WAVES * G;
-                    ch.item0 = (int)C.items.size();
-                    int units = 0;
-                    for (int t = 0; t < ch.n_tiles; ++t) {
-                        ColTile &tile = C.tiles[ch.slot][(size_t)ch.tile0 + t];
-                        const int nc = B->models[tile.model]->colprog.n_cols;
-                        const int dmax = nc >= ROWS_STREAM_MIN_COLS ? C.rows_depth : 1;
-                        tile.pad = units;
-                        for (int j0 = 0, rnd = 0; j0 < tile.count; j0 += round * dmax, ++rnd)
-                            for (int w = 0; w < COL_WAVES; ++w) {
-                                const int jw = j0 + w * G;
-                                if (jw >= tile.count) break;
-                                const int depth = std::min(dmax, (tile.count - jw + round - 1) / round);
-                                for (int k = 0; k < depth; ++k) C.items.push_back(RowsFinishItem{t, jw, k, units + rnd * COL_WAVES + w});
-                            }
-                        units += COL_WAVES * ((tile.count + round * dmax - 1) / (round * dmax));
-                    }
-                    ch.n_units = units;
-                    ch.n_items = (int)C.items.size() - ch.item0;
-                }
             }
             // long reads, one per wavefront: the tiles of a launch differ by an order of magnitude in work (columns x rows of
             // their longest read, which is the first one) -- heaviest first, so that what the dynamic dequeue hands out last is
@@ -1085,24 +1010,11 @@ static int batch_build(advntr_batch *B, advntr_hmm *const *models, int32_t n_mod
                         "%lld B per wavefront, %lld B for one workgroup; %lld B of device memory can be had", n_max_col, C.nc_max,
                         (long long)C.bp_stride, (long long)COL_WAVES * C.bp_stride, (long long)bp_budget);
         C.aux_stride = COL_MAX_TAIL + (int64_t)rows_groups * (rows_groups > 1 ? C.rows_depth + 1 : 1) * COL_MAX_SINKS * C.sink_stride;
-        size_t waves = (size_t)C.grid * COL_WAVES, path_waves = waves;
-        if (C.split) {
-            // scratch per sweep unit of the largest chunk (the fused kernels of the same batch -- longer reads -- use the head of it
-            // as scratch per resident wavefront, as ever); the finish launches fill the device at their own occupancy
-            int units_max = 0;
-            for (const ColumnLaunch::RowsChunk &ch : C.chunks) units_max = std::max(units_max, ch.n_units);
-            waves = std::max(waves, (size_t)units_max);
-            const int occ = std::max({rows_finish_occupancy<5, 2>(), rows_finish_occupancy<4, 2>(), rows_finish_occupancy<4, 4>()});
-            C.finish_grid = cus * occ;
-            path_waves = std::max(path_waves, (size_t)C.finish_grid * COL_WAVES);
-            if ((rc = B->dmalloc(&C.d_items, C.items.size()))) return rc;
-            HIP_TRY(hipMemcpy(C.d_items, C.items.data(), C.items.size() * sizeof(RowsFinishItem), hipMemcpyHostToDevice));
-            if ((rc = B->dmalloc(&C.d_split_counters, 2 * C.chunks.size()))) return rc;
-        }
+        const size_t waves = (size_t)C.grid * COL_WAVES;
         if ((rc = B->dmalloc(&C.d_bp, waves * C.bp_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_rown, waves * C.rown_stride))) return rc;
         if ((rc = B->dmalloc(&C.d_aux, waves * C.aux_stride))) return rc;
-        if ((rc = B->dmalloc(&B->d_pathbuf_col, path_waves * B->path_cap))) return rc;
+        if ((rc = B->dmalloc(&B->d_pathbuf_col, waves * B->path_cap))) return rc;
         for (int k = 0; k < 9; ++k) {
             if (C.tiles[k].empty()) continue;
             if ((rc = B->dmalloc(&C.d_tiles[k], C.tiles[k].size()))) return rc;
@@ -1259,19 +1171,9 @@ extern "C" int advntr_batch_run(advntr_batch *B)
             column_launch_k<3, false>(B->col, a, B->flags, B->stream);
             column_launch_k<4, false>(B->col, a, B->flags, B->stream);
             column_launch_k<COL_LONG_K, true>(B->col, a, B->flags, B->stream);
-            if (B->col.split) {
-                HIP_TRY(hipMemsetAsync(B->col.d_split_counters, 0, 2 * B->col.chunks.size() * sizeof(int32_t), B->stream));
-                for (size_t ci = 0; ci < B->col.chunks.size(); ++ci) {
-                    const ColumnLaunch::RowsChunk &ch = B->col.chunks[ci];
-                    if (ch.slot == 5) column_launch_rows_split<5, 2>(B->col, a, B->flags, B->stream, ch, (int)ci);
-                    else if (ch.slot == 6) column_launch_rows_split<4, 2>(B->col, a, B->flags, B->stream, ch, (int)ci);
-                    else column_launch_rows_split<4, 4>(B->col, a, B->flags, B->stream, ch, (int)ci);
-                }
-            } else {
-                column_launch_rows<5, 2>(B->col, a, B->flags, B->stream, 0);
-                column_launch_rows<4, 2>(B->col, a, B->flags, B->stream, 1);
-                column_launch_rows<4, 4>(B->col, a, B->flags, B->stream, 2);
-            }
+            column_launch_rows<5, 2>(B->col, a, B->flags, B->stream, 0);
+            column_launch_rows<4, 2>(B->col, a, B->flags, B->stream, 1);
+            column_launch_rows<4, 4>(B->col, a, B->flags, B->stream, 2);
             column_launch_rows_long(B->col, a, B->flags, B->stream);
         }
     }

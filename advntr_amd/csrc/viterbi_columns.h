@@ -580,9 +580,7 @@ __device__ __forceinline__ double col_tail(const ColProgram *__restrict__ cp, do
 // and the run's states are written in parallel.  Everything else advances one cell at a time (broadcast load).
 // bp_at(t, c, st) -> back-pointer byte of cell (t, c), of which the walk uses the two bits of state st (0 = I, 1 = M, 2 = b):
 // the layout of the back-pointer store belongs to the sweep that wrote it
-// MRUN: lanes of the diagonal gather (a round then covers at most MRUN cells of a match run; the split launch's finish kernel is
-// bound by the bytes its gathers fetch, not by their latency, and a repeat unit's run is as long as the pattern)
-template <class BpAt, class Rev, int MRUN = 64>
+template <class BpAt, class Rev>
 __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__ cp, const LdsTables &L, const int n,
                                                   const int start_state, const int P, const BpAt &bp_at, const int sink_stride,
                                                   const int32_t *__restrict__ tailwin, const int32_t *__restrict__ sinkbp,
@@ -609,18 +607,16 @@ __device__ __forceinline__ int col_traceback_walk(const ColProgram *__restrict__
         if (slot == 1) {
             // diagonal gather: lane i looks at the M cell (t-i, c-i)
             const int tt = t - lane, cc = c - lane;
-            const bool valid = tt >= 1 && cc >= 1 && (MRUN >= 64 || lane < MRUN);
+            const bool valid = tt >= 1 && cc >= 1;
             const int byte = valid ? bp_at(tt, cc, 1) : 0xff;
-            unsigned long long mm = __ballot(valid && tt > 1 && bp_ptr_M(byte) == 1);      // row 1: 1 = entry edge
-            // (a narrow gather: the lanes behind it count as "still on the diagonal", exactly as the 65th cell of a full one does)
-            if (MRUN < 64) mm |= __ballot(lane >= MRUN && tt > 1 && cc >= 1);
+            const unsigned long long mm = __ballot(valid && tt > 1 && bp_ptr_M(byte) == 1);      // row 1: 1 = entry edge
             // run = number of leading lanes whose pointer is "M of the previous column"; the cell after the run
             // (lane `run`) is an M cell too (reached through an M pointer) unless it is invalid
-            const int run = min(MRUN, (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1));
-            const int cells = min(run + 1, MRUN);                     // M cells visited, lanes 0..cells-1
+            const int run = (~mm == 0ull) ? 64 : (__ffsll((long long)~mm) - 1);
+            const int cells = min(run + 1, 64);                       // M cells visited, lanes 0..cells-1
             if (lane < cells) rev_put(rev, len + lane, L.state[cc + 1].sM);
             len += cells;
-            if (run >= MRUN) { t -= MRUN; c -= MRUN; continue; }      // still on the diagonal: gather again
+            if (run >= 64) { t -= 64; c -= 64; continue; }            // still on the diagonal: gather again
             // leave through the pointer of the last visited cell (lane `run`)
             const int lastbyte = __builtin_amdgcn_readlane(byte, run);
             int p = bp_ptr_M(lastbyte);

@@ -404,7 +404,7 @@ __device__ __forceinline__ unsigned rows_pack_read(const uint8_t *__restrict__ s
 
 // tail states, traceback (row-blocked back-pointer layout), summary and outputs of one read of the group; col0 = the steps
 // the read's sweep began after (k * NC for the kth read of a back-to-back sweep)
-template <int R, class Rev, int MRUN = 64>
+template <int R, class Rev>
 __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_t flags, const ColProgram *__restrict__ cp,
                                                  const LdsTables &L, const DevModel &M, const int r,
                                                  const uint8_t *__restrict__ seq, const int n, double *final_row,
@@ -425,8 +425,8 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
 #ifndef ADVNTR_BUDGET_NO_TRACEBACK
     if (logp != -INFINITY) {
         auto bp_at = [&](int tt, int cc, int st) -> int { return rows_bp_at<R>(bpw, lane0, tt, cc, st); };
-        len = col_traceback_walk<decltype(bp_at), Rev, MRUN>(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev,
-                                                             g.a.path_cap, lane, 0, 1 << 30, col0);
+        len = col_traceback_walk(cp, L, n, M.start, M.P, bp_at, g.sink_stride, tailwin, sinkbp, rev, g.a.path_cap, lane, 0,
+                                 1 << 30, col0);
         len = __builtin_amdgcn_readfirstlane(len);
     }
 #endif
@@ -459,13 +459,7 @@ __device__ __forceinline__ void rows_finish_read(const ColArgs &g, const uint32_
 #define WG_CLOCKS_END(g, tid) ((void)0)
 #endif
 
-// SPLIT (ADVNTR_FLAG_SPLIT_FINISH): the kernel only SWEEPS.  Back-pointer masks, row-n values and fan-in winners of a sweep go to
-// scratch of the sweep UNIT (tile.pad + wavefront: one unit per wavefront and round of a tile, numbered by the host per chunk of
-// the launch) instead of the resident wavefront's, and viterbi_rows_finish_kernel (below) does the tail states, the traceback and
-// the summaries of the chunk's reads afterwards -- as a launch of its own at eight or more light wavefronts per SIMD, where the
-// chain of dependent round trips of one read's traceback is hidden behind those of the other wavefronts instead of taking a third
-// of a SIMD's sweeping wavefronts with it.
-template <int R, int G, bool SPLIT = false>
+template <int R, int G>
 __global__ void __launch_bounds__(COL_WAVES * 64, ROWS_WAVES_PER_SIMD)
 viterbi_rows_kernel(ColArgs g, uint32_t flags)
 {
@@ -527,12 +521,6 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             const int jw = j0 + wave * G;
             if (jw >= tile.count) break;
             const int depth = min(dmax, (tile.count - jw + COL_WAVES * G - 1) / (COL_WAVES * G));
-            if (SPLIT) {
-                const int64_t unit = tile.pad + (int64_t)(j0 / (COL_WAVES * G * dmax)) * COL_WAVES + wave;
-                bpw = (unsigned *)(g.bp + unit * g.bp_stride);
-                rown = g.rown + unit * g.rown_stride;
-                aux = g.aux + unit * g.aux_stride;
-            }
             if (!padded) {                                                 // the host never routes such a tile here
                 for (int k = 0; k < depth; ++k) {
                     const int idx = jw + k * COL_WAVES * G + grp;
@@ -574,14 +562,13 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
             int nlast = 0;
 #pragma unroll
             for (int q = 0; q < G; ++q) nlast = max(nlast, __builtin_amdgcn_readlane(fn, (depth - 1) * G + q));
-            if (!SPLIT && lane < ROWS_DEPTH * G) stash[lane] = make_int4(fr, fn, (int)fo, (int)(fo >> 32));
+            if (lane < ROWS_DEPTH * G) stash[lane] = make_int4(fr, fn, (int)fo, (int)(fo >> 32));
             const unsigned cap_base = (unsigned)(grp * grp_doubles);
             const unsigned sink_base = (unsigned)(COL_MAX_TAIL + grp * (dmax + 1) * COL_MAX_SINKS * g.sink_stride);
             const int s_end = depth * NC - 1 + (max(nlast, 1) - 1) / R;
             rows_sweep<R, G>(L, NC, s_end, seq, n, lp, lane, bpw, rown, cap_base, aux, sink_base, g.sink_stride, 0, nullptr,
                              queue, depth);
             rows_bp_publish();
-            if (SPLIT) continue;                                           // the chunk's finish launch takes it from here
             __threadfence_block();
             __builtin_amdgcn_wave_barrier();
             int4 what = make_int4(0, 0, 0, 0);
@@ -600,65 +587,6 @@ viterbi_rows_kernel(ColArgs g, uint32_t flags)
                                         aux + COL_MAX_TAIL + (int64_t)(q * (dmax + 1) + k) * COL_MAX_SINKS * g.sink_stride, rev, lane, k * NC);
                 }
             }
-        }
-    }
-}
-
-// The finish launch of a split chunk: one ITEM per wavefront at a time = the G reads that sit side by side at depth k of one sweep
-// unit ({tile, first read of the wavefront in the tile, k, unit}; the host lists them, batch_build).  Nothing is staged: the walk
-// reads the column -> state and column-info tables from the model blob (L2), the reversed path and the tail states' values sit in
-// the wavefront's piece of LDS as in the fused kernel, and the per-read code is the fused kernel's own (rows_finish_read).
-struct RowsFinishItem { int32_t tile, jw, k, unit; };
-#ifndef ROWS_FINISH_WAVES_PER_SIMD
-#define ROWS_FINISH_WAVES_PER_SIMD 8
-#endif
-#ifndef ROWS_FINISH_MRUN
-#define ROWS_FINISH_MRUN 64      // lanes of the finish kernel's diagonal gathers (col_traceback_walk)
-#endif
-#define ROWS_FINISH_LDS_BYTES (COL_WAVES * (REV_LDS_ENTRIES * 2 + COL_MAX_TAIL * 12))
-template <int R, int G>
-__global__ void __launch_bounds__(COL_WAVES * 64, ROWS_FINISH_WAVES_PER_SIMD)
-viterbi_rows_finish_kernel(ColArgs g, uint32_t flags, const RowsFinishItem *__restrict__ items, const int n_items)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int W = 64 / G, WORDS = (R + 4) / 5;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * COL_WAVES + wave;
-    double *tailv = (double *)(lds + COL_WAVES * REV_LDS_ENTRIES * 2) + wave * COL_MAX_TAIL;
-    int32_t *tailwin = (int32_t *)(lds + COL_WAVES * REV_LDS_ENTRIES * 2 + COL_WAVES * COL_MAX_TAIL * 8) + wave * COL_MAX_TAIL;
-    const RevLds rev{(__attribute__((address_space(3))) unsigned short *)(size_t)lds_addr(lds) + wave * REV_LDS_ENTRIES,
-                     g.a.path_scratch + gw * g.a.path_cap};
-    for (;;) {
-        int it = 0;
-        if (lane == 0) it = atomicAdd(g.tile_counter, 1);
-        it = __builtin_amdgcn_readfirstlane(it);
-        if (it >= n_items) break;
-        const RowsFinishItem item = items[it];
-        const ColTile tile = g.tiles[item.tile];
-        const DevModel M = g.a.models[tile.model];
-        const ColProgram *cp = M.cols;
-        LdsTables L{};
-        L.info0 = (const ColInfo *)((const uint8_t *)cp + cp->off_info);
-        L.state = (const ColState *)((const uint8_t *)cp + cp->off_state);
-        const int NC = __builtin_amdgcn_readfirstlane(cp->n_cols);
-        const int dmax = NC >= ROWS_STREAM_MIN_COLS ? g.rows_depth : 1;
-        const int64_t grp_doubles = 3 * ((int64_t)dmax * NC + 2 * W);
-        const int jw = __builtin_amdgcn_readfirstlane(item.jw), k = __builtin_amdgcn_readfirstlane(item.k);
-        const int64_t unit = __builtin_amdgcn_readfirstlane(item.unit);
-        const unsigned *bpw = (const unsigned *)(g.bp + unit * g.bp_stride);
-        double *rown = g.rown + unit * g.rown_stride;
-        const int32_t *aux = g.aux + unit * g.aux_stride;
-#pragma unroll 1
-        for (int q = 0; q < G; ++q) {
-            const int idx = jw + k * COL_WAVES * G + q;
-            if (idx >= tile.count) break;
-            const int rq = __builtin_amdgcn_readfirstlane(g.a.order[tile.first + idx]);
-            const int64_t fo = g.a.read_off[rq];
-            const int nq = __builtin_amdgcn_readfirstlane((int)(g.a.read_off[rq + 1] - fo));
-            rows_finish_read<R, RevLds, ROWS_FINISH_MRUN>(g, flags, cp, L, M, rq, g.a.bases + fo, nq, rown + q * grp_doubles + 3 * (W + (int64_t)k * NC), tailv,
-                                bpw + (int64_t)k * NC * (64 * WORDS), q * W, tailwin,
-                                aux + COL_MAX_TAIL + (int64_t)(q * (dmax + 1) + k) * COL_MAX_SINKS * g.sink_stride, rev, lane, k * NC);
         }
     }
 }

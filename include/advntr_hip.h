@@ -56,13 +56,6 @@ extern "C" {
                                          copies of a batch so that the next pass starts while the previous one's last
                                          workgroups drain creates one copy with the flag and one without.  Results identical */
 
-#define ADVNTR_FLAG_SPLIT_FINISH 256u /* short reads of a large batch: the row-blocked kernel only sweeps, and the tail states,
-                                         tracebacks and path summaries of a chunk of reads run as a launch of their own behind
-                                         it (viterbi_rows_finish_kernel: many light wavefronts per SIMD hide the dependent round
-                                         trips of a traceback, which the three heavy sweeping wavefronts of a SIMD cannot).  Takes
-                                         back-pointer scratch per sweep of a chunk (~100 000 reads: ~9 GB on a 1 400-state model)
-                                         instead of per resident wavefront.  Results are identical */
-
 /* out_summary layout: ADVNTR_SUMMARY_INTS int32 per read (hmm_utils.py line numbers in brackets) */
 #define ADVNTR_SUMMARY_INTS   8
 #define ADVNTR_SUM_RU         0   /* get_number_of_repeats_in_vpath            [155-188] */
@@ -283,14 +276,6 @@ int advntr_line_index(const char *text, int64_t n_bytes, int32_t n_threads, int6
  * reads are not joined into one text first): read r = texts[r][0 .. out_off[r+1] - out_off[r]).                    */
 int advntr_encode_texts(const char *const *texts, int32_t n_reads, uint32_t flags, int32_t n_threads,
                         const int64_t *out_off, uint8_t *out_codes, uint8_t *out_bad);
-
-/* For a CPython host (the reference's language): the buffers of the strings of a Python list, without a call back into the
- * interpreter per string.  list = a PyObject* that is a list of str, handed over WITH the interpreter lock held (ctypes.PyDLL);
- * texts[i] / lengths[i] receive the UTF-8 buffer and length of item i -- for an ASCII str (every read file) its own buffer, valid
- * while the list holds the str; they feed advntr_encode_texts.  Returns the number of items, or -1 when the interpreter's C API
- * is not reachable from this process or `list` is not a list, or -(i + 2) when item i is not a str or not ASCII (the caller
- * then takes its general route).  The C API is looked up at run time (dlsym): the library does not link against libpython. */
-int64_t advntr_pylist_texts(void *list, const char **texts, int64_t *lengths, int64_t capacity);
 
 /* Pieces of encoded reads, as reads of their own: piece p = codes[read_off[r] + begin[p] .. read_off[r] + end[p]) of read
  * r = piece_read[p] (0 <= begin <= end <= length of the read), reverse-complemented when reverse[p] != 0, written to
