@@ -171,6 +171,7 @@ class InitWatchdog(object):
         import threading
         self._dir, self._rank, self._timeout, self._poll = directory, rank, float(timeout), float(poll)
         self._on_end = on_end or self._exit
+        self._born = time.time()
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, name="advntr-init-watchdog", daemon=True)
         self._thread.start()
@@ -182,13 +183,27 @@ class InitWatchdog(object):
         sys.stderr.flush()
         os._exit(status)
 
+    def _fresh_markers(self):
+        """Abort markers written since this watchdog started.  A marker left behind by an EARLIER job in a reused rendezvous
+        directory (ADVNTR_RDZV_DIR: the crashed job never reached close()) must not end a healthy later one."""
+        out = []
+        try:
+            for f in sorted(os.listdir(self._dir)):
+                if not f.startswith("abort."):
+                    continue
+                try:
+                    if os.stat(os.path.join(self._dir, f)).st_mtime >= self._born - 1.0:
+                        out.append(f)
+                except OSError:
+                    pass
+        except OSError:
+            pass
+        return out
+
     def _run(self):
         t0 = time.monotonic()
         while not self._stop.wait(self._poll):
-            try:
-                gone = sorted(f for f in os.listdir(self._dir) if f.startswith("abort."))
-            except OSError:
-                gone = []
+            gone = self._fresh_markers()
             if gone:
                 self._on_end(71, "advntr_amd.comm: rank %d: a peer could not create its communicator (%s); ending this process"
                              % (self._rank, ", ".join(gone)))
@@ -223,6 +238,10 @@ class RcclComm(HostComm):
         self._lib = _lib
         self._h = None
         L = _lib.load()
+        try:                                                 # this rank's marker of an earlier job in a reused directory
+            os.unlink(os.path.join(rdzv.dir, "abort.%d" % self.rank))
+        except OSError:
+            pass
         err = b""
         if L.advntr_comm_available() != _lib.OK:
             err = ("rank %d: %s" % (self.rank, _lib.last_error())).encode("utf-8", "replace")
@@ -246,7 +265,14 @@ class RcclComm(HostComm):
         finally:
             watchdog.cancel()
         if not self._h:
-            raise _lib.EngineError(_lib.ERR_DEVICE, _lib.last_error())
+            msg = _lib.last_error()
+            # the peers are inside the collective and cannot be called back: their watchdogs end them on this marker (written
+            # here, so that a direct user of RcclComm gets the fast abort too, not only init_from_env)
+            try:
+                rdzv.put("abort.%d" % self.rank, msg.encode("utf-8", "replace"))
+            except OSError:
+                pass
+            raise _lib.EngineError(_lib.ERR_DEVICE, msg)
 
     def barrier(self):
         self._lib.check(self._lib.load().advntr_comm_barrier(self._h))
@@ -313,6 +339,21 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def frugal_host_for_ranks(world):
+    """N ranks share one host (and, in a container, one CPU quota).  Before this rank touches its GPU: its waits on the device
+    sleep instead of spinning (ADVNTR_BLOCKING_SYNC, read by advntr_set_device), and the bulk host-side calls of the library use
+    1 / world of the CPUs the process group may use (ADVNTR_HOST_THREADS, read by advntr_host_threads at every call).  Values
+    already in the environment win.  Returns what was set."""
+    from . import _lib
+    out = {}
+    if "ADVNTR_BLOCKING_SYNC" not in os.environ:
+        os.environ["ADVNTR_BLOCKING_SYNC"] = out["ADVNTR_BLOCKING_SYNC"] = "1"
+    if "ADVNTR_HOST_THREADS" not in os.environ:
+        share = max(1, int(_lib.load().advntr_host_threads()) // max(1, int(world)))
+        os.environ["ADVNTR_HOST_THREADS"] = out["ADVNTR_HOST_THREADS"] = str(share)
+    return out
+
+
 def init_from_env(backend=None, set_device=True):
     """Join the job the launcher described (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT): bind this rank's GPU and
     return a communicator -- RcclComm by default, HostComm with backend="host" (or ADVNTR_DIST_BACKEND=host).  Returns
@@ -323,6 +364,8 @@ def init_from_env(backend=None, set_device=True):
     backend = backend or os.environ.get("ADVNTR_DIST_BACKEND", "rccl")
     if backend not in ("rccl", "host"):
         raise ValueError("backend must be 'rccl' or 'host', not %r" % (backend,))
+    if world > 1:
+        frugal_host_for_ranks(world)
     if set_device:
         from . import _lib
         n = _lib.load().advntr_device_count()

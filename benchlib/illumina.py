@@ -1,0 +1,137 @@
+"""BASELINE config 2 (6 719 Illumina loci) on one GPU: the `end_to_end` and `c2` sub-records of the N = 1 line."""
+import time
+
+import numpy as np
+
+from .common import HBM_PEAK_GBPS, cpu_model_name, load_json, pmc_section
+from .passes import two_in_flight_ms
+from .rehearsal import scale_rehearsal
+
+
+def target_configuration_records(_lib, workloads, c2_input, flags, args):
+    """The north star's target configuration on one GPU (BASELINE config 2: 6719 Illumina loci x a 30x-equivalent read
+    batch) as two sub-records of the C1 line.
+
+    `end_to_end`: candidate reads -> genotypes, what the reference's per-locus loop does (genome_analyzer.py:280-297 ->
+    vntr_finder.py:727-767, 807-887): models built by the native builder, both strands of every candidate scored, recruit
+    rule, aggregation, maximum-likelihood genotype -- the host stages of one piece of the locus set overlapped with the
+    scoring of the previous one (vntr_finder.genotype_loci_pipelined), next to the same stages run one after the other.
+    `c2`: the scoring kernel alone over the whole set's calls, resident in HBM, with its roofline object."""
+    from advntr_amd import hmm_utils, vntr_finder
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which, counts, t_gen = c2_input
+    n_loci = len(loci)
+    desc = [(l.left, l.right, l.units, l.copies) for l in loci]
+    first = np.concatenate([[0], np.cumsum([nm + 2 * nu for nm, nu in counts])])
+    candidates = [reads[first[k]:first[k] + nm + nu] for k, (nm, nu) in enumerate(counts)]      # forward strands only
+    n_cand = int(sum(len(c) for c in candidates))
+    hmm_utils.build_read_matcher_models(desc[:4])                                                   # warm-up
+    vntr_finder.score_reads_arrays(hmm_utils.build_read_matcher_models(desc[:1]), [candidates[0][:8]])
+    # the stages one after the other
+    T = {}
+    t0 = time.perf_counter()
+    models = hmm_utils.build_read_matcher_models(desc)
+    T["build_models"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dms = device_models(models)
+    T["upload_models"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    res = vntr_finder.score_reads_arrays(models, candidates, None, compute_reverse=True)
+    T["encode_score_recruit"] = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    plain = vntr_finder._genotypes_from_scores(res, n_loci, False, False, 0)
+    T["aggregate_genotype"] = time.perf_counter() - t1
+    T["total"] = time.perf_counter() - t0
+    recruited = int((res["recruited"] & (res["summary"][:, _lib.SUM_REPEAT_BP] > 2)).sum())
+    # ... and overlapped
+    # (three passes: host threads, page cache and the PCIe path make a single pass vary by +-15 %; the fastest one is reported,
+    # all three totals are listed)
+    P, totals = None, []
+    for _ in range(3):
+        Pk = {}
+        piped = vntr_finder.genotype_loci_pipelined(desc, candidates, timings=Pk)
+        totals.append(Pk["total"])
+        if P is None or Pk["total"] < P["total"]:
+            P = Pk
+    same = sum(a.copy_numbers == b.copy_numbers and a.recruited_reads_count == b.recruited_reads_count
+               for a, b in zip(plain, piped))
+    assert same == n_loci, "pipelined and stage-by-stage genotypes differ on %d loci" % (n_loci - same)
+    e2e = {"loci": n_loci, "candidate_reads": n_cand, "viterbi_calls": 2 * n_cand, "recruited_reads": recruited,
+           "loci_with_genotype": sum(g.copy_numbers is not None for g in piped),
+           "value": 2 * n_cand / P["total"], "unit": "calls/s", "total_s": P["total"], "total_s_of_each_pass": totals,
+           "stage_s_overlapped": {k: v for k, v in P.items() if k != "total"},
+           "stages_one_after_the_other": dict(T),
+           "genotypes_identical_to_stage_by_stage": same == n_loci,
+           "note": "from candidate reads in Python lists to RU-count genotypes; overlapped = model build / upload / read "
+                   "encoding of locus piece k+1 on host threads while piece k is scored (12 pieces, the first one in 3 growing parts; a piece's kernels are queued before the previous piece's are waited for); synthetic input "
+                   "generated in %.1f s (not timed)" % t_gen}
+    # the kernel over the whole set's calls (mapped forward + unmapped on both strands, as BASELINE config 2 counts them)
+    bases, off = _lib.encode_reads(reads)
+    batch = _lib.DeviceBatch(dms, bases, off, which, flags=flags)
+    batch.run()
+    batch.sync()
+    steps = max(1, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+    batch.sync()
+    dt = (time.perf_counter() - t0) / steps
+    kernel_ms = batch.run_timed(steps)
+    dt2_ms = two_in_flight_ms(batch, lambda extra: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra), steps)
+    logp, summ = batch.fetch()
+    kinfo = batch.kernel_info()
+    kernels = [k[:3] for k in kinfo]
+    kernel = max(kernels, key=lambda k: k[1])[0]
+    ms = np.array([d.m for d in dms])
+    lens = np.diff(off)
+    alg = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    pmc = pmc_section("c2", len(reads), kernel) or {}
+    traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
+    c2 = {"loci": n_loci, "calls": len(reads), "mean_states": float(np.mean(ms[which])), "read_len": int(round(float(lens.mean()))),
+          "value": len(reads) / dt, "unit": "calls/s", "ms_per_step": dt * 1e3, "steps": steps, "kernel_ms": kernel_ms,
+          "ms_per_step_two_passes_in_flight": dt2_ms,
+          "kernel": kernel, "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
+          "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBPS, "algorithmic_gb_per_launch": alg / 1e9,
+                       "traffic": traffic / 1e9 if traffic else None, "traffic_source": pmc.get("file"),
+                       "note": "exact sum over the calls of n + (n+1) m + (n+m) + 32 bytes (SURVEY 8d) / HIP-event kernel time"}}
+    from advntr_amd import sharding
+    c2["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, 8,
+                                            {"calls": len(reads), "loop_ms": dt * 1e3, "kernel_ms": kernel_ms,
+                                             "loop_ms_two_passes_in_flight": dt2_ms}, flags, steps,
+                                            root_capacity=args.root_capacity)
+    if not args.no_cpu:
+        # per-locus sample against the oracle: log-probabilities bit for bit, repeat-unit counts as hmm_utils derives them
+        # from the oracle's path; its single-thread rate on these models prices the whole set for the reference
+        from oracle import oracle as Or
+        sample = np.linspace(0, n_loci - 1, 48).astype(int)
+        n_chk = same_ru = 0
+        t_cpu = 0.0
+        for k in sample:
+            arr = models[k].baked_arrays()
+            edges = [(int(arr["in_src"][e]), l, float(arr["in_logp"][e]))
+                     for l in range(arr["m"]) for e in range(arr["in_ptr"][l], arr["in_ptr"][l + 1])]
+            O = Or.OracleModel(arr["m"], arr["silent_start"], arr["start_index"], arr["end_index"], edges, arr["emis_logp"])
+            names = [st.name for st in models[k].states]
+            for i in range(int(first[k]), int(first[k]) + 6):
+                t1 = time.perf_counter()
+                olp, opath = O.viterbi(reads[i])
+                t_cpu += time.perf_counter() - t1
+                assert logp[i] == olp, "GPU/oracle log-prob mismatch on the C2 sample (locus %d)" % k
+                ru = Or.number_of_repeats([names[j] for j in opath][1:-1]) if opath else 0
+                same_ru += int(ru == int(summ[i][0]))
+                n_chk += 1
+        cal = load_json("profiles", "cpu_calibration.json") or {}
+        ratio = cal.get("oracle_over_pomegranate")
+        cps = n_chk / t_cpu
+        c2["ru_concordance"] = {"loci": len(sample), "calls": n_chk, "identical_ru_counts": same_ru, "logp_bit_equal": True}
+        c2["cpu_baseline"] = {"value": cps, "unit": "calls/s", "cores": 1, "kind": "port", "cpu_model": cpu_model_name(),
+                              "sample": "6 calls of each of 48 loci spread over the set, oracle/viterbi_oracle.c through its "
+                                        "per-call entry, 1 thread",
+                              "pomegranate_equivalent": cps / ratio if ratio else None}
+        if ratio:
+            c2["speedup_vs_pomegranate_equivalent_1thread"] = c2["value"] / (cps / ratio)
+            e2e["reference_scoring_alone_s_pomegranate_equivalent"] = 2 * n_cand / (cps / ratio)
+    batch.close()
+    return e2e, c2

@@ -1,0 +1,400 @@
+"""The bench line itself (contract in the task statement; bench.py is the entry point)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from .cli import parse_args, spawn_ranks
+from .common import (CLOCK_GHZ, HBM_PEAK_GBPS, SIMDS, algorithmic_bytes, cpu_baseline, cpu_model_name, load_json,
+                     measured_clock_ghz, pmc_section, ru_concordance)
+from .illumina import target_configuration_records
+from .passes import Passes, passes_of, two_in_flight_ms
+from .records import forward_record, s300_record
+from .rehearsal import scale_rehearsal
+from .upstream import (c4_record, flank_align_record, pacbio_end_to_end_record, prefilter_record, upstream_inputs)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "RANK" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, argv)
+
+    # stdout carries exactly ONE line, the JSON record: anything a library prints while the bench runs (RCCL's version
+    # banner, HIP warnings) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+
+    from advntr_amd import comm as comm_mod
+    rank, local_rank, world = comm_mod.env_world()
+    if args.fault:
+        kind, _, who = args.fault.partition(":")
+        if int(who or -1) == rank:
+            if kind == "exit":
+                return 3
+            if kind == "hang":
+                time.sleep(10 ** 6)
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; using %d\n" % (args.gpus, world, world))
+    workload = args.workload or ("c1" if world == 1 else "c3")
+    n_loci = args.loci if args.loci is not None else (8960 if workload == "c4" else 6719)
+
+    import __graft_entry__ as entry
+    entry.build()
+    from advntr_amd import _lib, sharding, workloads
+
+    # The GPU and RCCL are touched only AFTER the synthetic reads exist: their generators fork a process pool, and a child
+    # forked from a process that holds an initialised HIP runtime and an RCCL communicator (proxy threads, shared-memory
+    # segments) must not be left to tear those down at its exit.
+    def join_job():
+        if world > 1 or "RANK" in os.environ:
+            # (under a launcher the RCCL path is exercised even with one rank, so the gather code runs on a 1-GPU box too)
+            return comm_mod.init_from_env(backend="host" if args.dry_run else None, set_device=not args.dry_run)
+        if not args.dry_run:
+            _lib.check(_lib.load().advntr_set_device(local_rank))
+        return None
+
+    comm = join_job() if args.dry_run else None
+
+    # ---------------------------------------------------------------- workload
+    n = 150
+    flags = (_lib.FLAG_FORCE_GENERIC if args.generic else _lib.FLAG_STREAM if args.stream else
+             _lib.FLAG_ANTIDIAGONAL if args.antidiagonal else 0)
+    total_calls, t_build, plan_info = None, 0.0, {}
+    # passes queued at a time (class Passes): the strong-scaling lines alternate between two copies of a rank's device batch
+    in_flight = args.in_flight if args.in_flight else (2 if workload in ("c3", "c4") else 1)
+    host_workers = max(1, min(32, (os.cpu_count() or 2) // world - 1))
+    if workload in ("c3", "c4"):
+        # every rank derives the same plan and the same LPT partition without communicating
+        if workload == "c3":
+            plan = workloads.c2_plan(n_loci, seed=20240602)
+            work = [calls * 151 * states for calls, states in plan]
+        else:
+            # (PacBio: what is known of a locus before its reads are extracted -- pattern and reference VNTR length -- prices it)
+            plan = workloads.c4_plan(n_loci, seed=20240603)
+            work = [calls * (length + 1) * states for calls, length, states in plan]
+        capacity = [args.root_capacity] + [1.0] * (world - 1) if world > 1 else None
+        parts = sharding.partition_loci(work, world, capacity)
+        mine = parts[rank]
+        total_calls = int(sum(p[0] for p in plan))
+        loads = [float(sum(work[int(k)] for k in p)) for p in parts]
+        plan_info = {"loci_per_rank": [int(len(p)) for p in parts],
+                     "calls_per_rank": [int(sum(plan[int(k)][0] for k in p)) for p in parts],
+                     "load_imbalance_max_over_mean": max(loads) / (sum(loads) / world),
+                     "root_capacity": capacity[0] if capacity else None, "root_load_over_mean": loads[0] / (sum(loads) / world),
+                     "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0)}
+    if args.dry_run:
+        counts = comm.allgather_i64(plan_info["calls_per_rank"][rank] if plan_info else args.reads) if comm else [args.reads]
+        if comm:
+            comm.barrier()
+            got = comm.allreduce_max(float(rank))
+            assert got == float(world - 1), got
+        if rank == 0:
+            emit({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
+                  "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload in ("c3", "c4") else "weak",
+                  "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
+                                  "comm": comm.backend if comm else None}, **plan_info)})
+        if comm:
+            comm.close()
+        return 0
+    if workload in ("c2", "c3", "c4"):
+        if workload == "c4":
+            loci, reads, which = workloads.make_c4(n_loci, seed=20240603, workers=host_workers, only=mine)
+        elif workload == "c3":
+            loci, reads, which = workloads.make_c2_parallel(n_loci, seed=20240602, build=False, only=mine, workers=host_workers)
+        else:
+            loci, reads, which = workloads.make_c2_parallel(n_loci, seed=20240602 + rank, build=False, workers=host_workers)
+        t_build = time.perf_counter()
+        workloads.build_models(loci)           # native builder, host threads
+        t_build = time.perf_counter() - t_build
+        locus = loci[0]
+        bases, off = _lib.encode_reads(reads)
+        comm = join_job()
+        _lib.require_gpu()
+        from advntr_amd.pomegranate import device_models
+        dms = device_models([l.model for l in loci])          # one allocation + one copy for the whole model set
+        n_reads = len(reads)
+        make_batch = lambda extra=0: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra)          # noqa: E731
+        passes = Passes(make_batch, in_flight)
+        batch = passes.batches[0]
+        ms = np.array([d.m for d in dms])
+        m = int(round(float(np.mean(ms[which]))))
+        edges_per_locus = np.array([l.model.n_edges for l in loci], np.int64)
+        P, E = locus.model.silent_start, int(np.mean(edges_per_locus))
+        lens = np.diff(off)
+        n = int(round(float(lens.mean())))
+        # exact sums over the calls (models and read lengths differ per call)
+        alg_bytes_total = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
+        relax_total = float(np.sum((lens + 1) * edges_per_locus[which]))
+    else:
+        c2_input = upstream_input = None
+        if world == 1 and workload == "c1" and not args.no_c2 and not args.no_s300:
+            # the target configuration of the north star rides on the C1 line as sub-records `c2` / `end_to_end`; its
+            # synthetic reads come out of a process pool, which must have gone before the GPU is touched (see above)
+            t_gen = time.perf_counter()
+            c2_input = workloads.make_c2_parallel(args.c2_loci, seed=20240602, build=False, workers=host_workers,
+                                                  return_counts=True) + (time.perf_counter() - t_gen,)
+            # (a million read strings: out of the garbage collector's sight, or its passes land in the timed loops)
+            upstream_input = None if args.no_upstream else upstream_inputs(workloads, host_workers, args)
+            import gc
+            gc.collect()
+            gc.freeze()
+        locus = workloads.s300() if workload == "s300" else workloads.ref150()
+        a = locus.model.baked_arrays()
+        m, P, E = a["m"], a["silent_start"], len(a["in_src"])
+        n_reads = args.reads
+        reads = workloads.make_reads(np.random.default_rng(20240601 + rank), locus, n_reads, n)
+        bases, off = _lib.encode_reads(reads)
+        comm = join_job()
+        _lib.require_gpu()
+        c1_model = locus.model.device_model()
+        make_batch = lambda extra=0: _lib.DeviceBatch([c1_model], bases, off, np.zeros(n_reads, np.int32), flags=flags | extra)    # noqa: E731
+        passes = Passes(make_batch, in_flight)
+        batch = passes.batches[0]
+        alg_bytes_total = float(algorithmic_bytes(n, m)) * n_reads
+        relax_total = float(n_reads) * (n + 1) * E
+    kinfo = batch.kernel_info()                 # what the engine launches for this batch (advntr_batch_info)
+    kernels = [k[:3] for k in kinfo]
+    kernel = max(kernels, key=lambda k: k[1])[0] if kernels else "none"
+
+    # ---------------------------------------------------------------- timed region
+    counts = comm.allgather_i64(n_reads) if comm else [n_reads]
+    use_gather = comm is not None and comm.backend == "rccl"
+    state = {"pending": False}
+
+    # (only when RCCL could not be set up on a multi-GPU node and comm.py fell back: the gather then goes through host
+    # memory inside the timed region, unoverlapped -- slower, but the line stays a measurement of the whole path)
+    host_gather = comm is not None and comm.backend == "host" and world > 1 and comm.fallback_reason is not None
+
+    def step():
+        b = passes.run()                                    # (two in flight: the copy whose previous pass is the older one)
+        if use_gather:
+            if state["pending"]:                            # the previous gather has had a whole pass to finish
+                comm.gather_results_finish(fetch=False)
+                state["gather_ms"] = comm.last_gather_ms()
+            # queued behind this pass on its copy's stream; the next pass overlaps it (the copy's own next pass leaves the
+            # slots the gather asks for: with two copies that is the pass that overlaps the NEXT gather -- every pass but the
+            # first two leaves them)
+            comm.gather_results_start(b, counts, root=0)
+            state["pending"] = True
+        elif host_gather:
+            state["host"] = comm.gather_results(b, counts, root=0)
+
+    def drain(fetch=False):
+        out = (None, None)
+        if state["pending"]:
+            out = comm.gather_results_finish(fetch=fetch)
+            state["pending"] = False
+            state["gather_ms"] = comm.last_gather_ms()
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    passes.sync()
+    if comm:
+        comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()                                                # every gather of the timed steps completes inside the region
+    passes.sync()                                          # ... and so does every pass, on either copy
+    if comm:
+        comm.barrier()
+    elapsed_mine = time.perf_counter() - t0
+    elapsed = comm.allreduce_max(elapsed_mine) if comm else elapsed_mine
+
+    # one more pass outside the timed region whose gathered records rank 0 checks against what its engine holds
+    gathered = (None, None)
+    if use_gather:
+        step()
+        gathered = drain(fetch=True)
+    elif host_gather:
+        step()
+        gathered = state["host"]
+    # kernel-only duration, HIP events on the engine's launch stream
+    # (as many passes as the timed region had: a burst of two or three passes after a pause runs 1-3 % faster than the
+    # sustained loop on this part, and the roofline is about the sustained rate)
+    kernel_ms = batch.run_timed(max(1, args.steps))
+    logp, summ = batch.fetch()
+    per_rank = None
+    if comm:
+        rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
+                          "kernel_ms": kernel_ms, "model_build_s": t_build,
+                          # the share's ACTUAL work (the plan prices a locus before its reads exist)
+                          "relaxations": relax_total, "cells": float(np.sum((np.diff(off) + 1) * ms[which])) if workload in ("c2", "c3", "c4") else None,
+                          # the last gather of the timed region on the communicator's stream (HIP events): the transfer alone
+                          # when it ran beside the next pass, about a pass when it had to wait for that pass's kernels
+                          "gather_ms": state.get("gather_ms")}).encode()
+        parts_json = comm.gather_bytes(rec, 0)
+        if rank == 0:
+            per_rank = [json.loads(p) for p in parts_json]
+    if (use_gather or host_gather) and rank == 0:
+        at = 0                                              # rank 0's own records sit first
+        assert np.array_equal(gathered[0][at:at + n_reads], logp), "RCCL gather returned different log-probabilities"
+        assert np.array_equal(gathered[1][at:at + n_reads], summ), "RCCL gather returned different summaries"
+        assert len(gathered[0]) == sum(counts)
+        if workload in ("c3", "c4"):
+            assert sum(counts) == total_calls, (sum(counts), total_calls)
+
+    if args.dump_records:
+        if workload in ("c3", "c4"):                        # global call id = position in the whole set's locus order
+            first = np.concatenate([[0], np.cumsum([p[0] for p in plan])])
+            ids = np.concatenate([np.arange(first[int(k)], first[int(k) + 1]) for k in mine]) if len(mine) else np.zeros(0, np.int64)
+        else:
+            ids = np.arange(n_reads, dtype=np.int64) + rank * n_reads
+        res = sharding.gather_records(comm, ids, logp, summ) if comm else (ids, logp, summ)
+        if rank == 0:
+            np.savez(args.dump_records, ids=res[0], logp=res[1], summary=res[2])
+
+    rc = 0
+    if rank == 0:
+        total_reads = total_calls if total_calls is not None else n_reads * world
+        value = total_reads * args.steps / elapsed
+        B = algorithmic_bytes(n, m)
+        achieved = alg_bytes_total / (kernel_ms * 1e-3) / 1e9
+        pmc = pmc_section(workload, n_reads, kernel) or {}
+        traffic = pmc.get("hbm_bytes_per_launch_fetch_x2")
+        traffic = traffic / 1e9 if traffic else None
+        valu_insts = pmc.get("valu_insts_per_launch")
+        if workload == "s300":
+            metric = "reads/sec Viterbi-scored (150 bp reads, S300 profile HMM: %d states / %d edges)" % (m, E)
+            wl = "S300: 1 VNTR locus (flank 30, 12-bp pattern, 3 copies) x 100k synthetic 150-bp reads per GPU, seed 20240601"
+        elif workload == "c1":
+            metric = "reads/sec Viterbi-scored (150 bp reads, REF150 profile HMM: 1413 states / 4626 edges)"
+            wl = ("C1: 1 VNTR locus REF150 (flank 150, 14-bp pattern, 11 copies) x 100k synthetic 150-bp reads per GPU, "
+                  "seed 20240601")
+        elif workload == "c4":
+            metric = ("calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs%s, "
+                      "mean %d states)" % (n, n_loci, " partitioned over %d GPUs" % world if world > 1 else "", m))
+            wl = ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x 20 trimmed "
+                  "spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution noise, seed 20240603 "
+                  "(ONE set; whole loci assigned to ranks by LPT on calls x (reference VNTR length + 201) x expected states; "
+                  "%d calls in total); host model build %.2f s" % (n_loci, total_calls, t_build))
+        else:
+            metric = ("calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs partitioned over %d GPUs)" % (n_loci, world)
+                      if workload == "c3" else
+                      "calls/sec Viterbi-scored (150 bp reads, %d per-locus profile HMMs, mean %d states)" % (n_loci, m))
+            wl = ("%s: %d synthetic loci (pattern 6-100 bp, 2-20 repeat units, flank 150) x ~Poisson(80) mapped + "
+                  "2*Poisson(40) unmapped-strand calls, seed 20240602%s; host model build %.2f s (native builder)"
+                  % (workload.upper(), n_loci,
+                     " (whole loci assigned to ranks by LPT on calls x states; %d calls in total)" % total_calls
+                     if workload == "c3" else "", t_build))
+        out = {
+            "metric": metric, "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if workload in ("c3", "c4") else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": dict({"workload": wl, "states": int(m), "emitting": int(P), "edges": int(E),
+                            "calls_this_rank": int(n_reads), "read_len": n, "kernel": kernel,
+                            "kernels": [{"name": k, "reads": r, "tiles": t, "useful_lane_steps": u} for k, r, t, u in kinfo],
+                            "outputs": "logp + RU count + 6 path summaries per read",
+                            "passes_in_flight": in_flight,
+                            "relaxations_per_s": value * relax_total / max(n_reads, 1)}, **plan_info),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "GB per launch (WRITE_SIZE + 2 x FETCH_SIZE of the committed PMC passes)",
+                         "traffic_source": pmc.get("file"),
+                         "algorithmic_gb_per_launch": alg_bytes_total / 1e9,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_read": B,
+                         "note": "tier rule: algorithmic bytes (SURVEY 8d) / HIP-event kernel time against HBM; the "
+                                 "roof that actually binds this max-plus recurrence is fp64 VALU issue -> bound_actual"},
+        }
+        if comm:
+            # what carried the gather, at the top level of the line: "rccl", or "host" when ADVNTR_COMM_FALLBACK=1 let the
+            # ranks drop to the file rendezvous (without that variable a job whose RCCL cannot be set up ends with an error)
+            out["comm"] = comm.backend
+            out["rccl"] = comm.backend == "rccl"
+            out["config"]["comm"] = comm.backend if comm.fallback_reason is None else "host (RCCL unavailable: %s)" % comm.fallback_reason
+            out["config"]["world_size_seen_by_comm"] = comm.world
+            out["config"]["per_rank"] = per_rank
+        if valu_insts:
+            # what actually bounds the kernel: every wave64 VALU instruction holds its SIMD for >= 4 cycles (fp64: 16
+            # lanes per cycle); SQ_INSTS_VALU per launch from the committed PMC pass of this same command
+            bound_ms = valu_insts * 4 / (SIMDS * CLOCK_GHZ * 1e9) * 1e3
+            out["roofline"]["bound_actual"] = {"bound": "valu_f64", "valu_insts_per_launch": valu_insts, "cycles_per_inst": 4,
+                                               "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "issue_bound_ms": bound_ms,
+                                               "kernel_ms": kernel_ms, "frac": bound_ms / kernel_ms,
+                                               "source": pmc.get("file"), "stale": pmc.get("stale")}
+            ghz = measured_clock_ghz()
+            if ghz:
+                # at the clock the chip really holds under this kernel, and at the rate it really issues 64-bit-encoded vector
+                # instructions (fp64 arithmetic, DPP, three-operand forms: ~4.5 cycles each at 3-4 wavefronts per SIMD,
+                # profiles/r01_valu_ubench.txt, r02_f64_issue_ubench.txt) -- nominal: 4 cycles at 2.4 GHz
+                b = out["roofline"]["bound_actual"]
+                b["clock_ghz_measured"] = ghz
+                b["clock_source"] = "profiles/r04_clock_summary.json (GRBM_GUI_ACTIVE / dispatch duration)"
+                b["issue_bound_ms_at_measured_clock"] = valu_insts * 4 / (SIMDS * ghz * 1e9) * 1e3
+                b["frac_at_measured_clock"] = b["issue_bound_ms_at_measured_clock"] / kernel_ms
+                b["frac_at_measured_clock_and_4p5_cycles_per_inst"] = b["issue_bound_ms_at_measured_clock"] * 4.5 / 4 / kernel_ms
+        if workload in ("c1", "s300") and world == 1 and in_flight == 1 and not args.no_s300:
+            # (not with --no-s300: the profiler passes of scripts/profile_round5.sh trace one launch at a time only)
+            # the same batch with two passes queued at a time (class Passes; what `--in-flight 2` makes the line itself): the
+            # next pass starts while the last workgroups of this one drain.  Reported beside the line, not as its value: the
+            # line's kernel time, roofline and profiles are those of one launch at a time
+            ms2 = two_in_flight_ms(batch, make_batch, max(1, args.steps))
+            out["two_passes_in_flight"] = {"ms_per_step": ms2, "value": total_reads / (ms2 * 1e-3), "unit": "reads/s",
+                                           "note": "consecutive passes alternate between two copies of the device batch "
+                                                   "(own scratch, results and stream); every pass scores every read"}
+        if workload == "c1" and not args.no_s300:
+            out["s300"] = s300_record(_lib, workloads, flags, args)
+            out["log_probability"] = forward_record(_lib, locus, batch, bases, off, n_reads, n, args)
+            if c2_input is not None:
+                out["end_to_end"], out["c2"] = target_configuration_records(_lib, workloads, c2_input, flags, args)
+                out["scale_rehearsal"] = out["c2"].pop("scale_rehearsal")
+            if upstream_input is not None:
+                out["c4"] = c4_record(_lib, workloads, upstream_input, flags, args)
+                out["c4_scale_rehearsal"] = out["c4"].pop("scale_rehearsal")
+                out["pacbio_end_to_end"] = pacbio_end_to_end_record(_lib, upstream_input, args)
+                out["flank_align"] = flank_align_record(_lib, upstream_input, args)
+                out["prefilter"] = prefilter_record(_lib, upstream_input, args)
+        if args.emulate_ranks > 1 and world == 1 and workload in ("c2", "c3", "c4"):
+            whole = {"calls": int(n_reads), "kernel_ms": kernel_ms,
+                     "loop_ms": Passes.ms_per_pass(passes_of(batch), max(1, args.steps)),
+                     "loop_ms_two_passes_in_flight": (elapsed / args.steps * 1e3 if in_flight == 2 else
+                                                      two_in_flight_ms(batch, make_batch, max(1, args.steps)))}
+            passes.close()                                  # (a rank has its GPU to itself: see c4_record)
+            out["scale_rehearsal"] = scale_rehearsal(_lib, sharding, loci, dms, bases, off, which, args.emulate_ranks,
+                                                     whole, flags, max(1, args.steps),
+                                                     planned_work=work if workload == "c4" else None,
+                                                     root_capacity=args.root_capacity)
+        if workload == "c1" and world == 1 and not args.no_cpu:
+            cps, cpu_logp, O = cpu_baseline(locus, bases, off, min(args.cpu_sample, n_reads))
+            assert np.array_equal(cpu_logp, logp[:len(cpu_logp)]), "GPU/oracle log-prob mismatch on the bench sample"
+            n_ru = min(500, len(cpu_logp))
+            same = ru_concordance(O, locus, reads, summ, n_ru)
+            out["ru_concordance"] = {"reads": n_ru, "identical_ru_counts": same, "fraction": same / n_ru,
+                                     "note": "GPU path summaries vs hmm_utils.get_number_of_repeats_in_vpath on the oracle path"}
+            cal = load_json("profiles", "cpu_calibration.json") or {}
+            ratio = cal.get("oracle_over_pomegranate")
+            out["cpu_baseline"] = {"value": cps, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu_model_name(),
+                                   "host_threads_available": os.cpu_count(),
+                                   "sample": "first %d reads of rank 0's batch, oracle/viterbi_oracle.c, 1 thread; "
+                                             "GPU logp bit-equal on the sample" % len(cpu_logp),
+                                   "pomegranate_equivalent": (cps / ratio) if ratio else None,
+                                   "calibration": ("oracle / vendored pomegranate = %.2f on %s, same 2000-read REF150 batch, 1 "
+                                                   "thread (profiles/cpu_calibration.json, oracle/tools/calibrate_cpu.py)"
+                                                   % (ratio, cal.get("cpu_model", "?"))) if ratio else None}
+            out["config"]["speedup_vs_cpu_1thread"] = value / cps
+            # the same restatement on every host core (the reference has no such mode; stated for scale only)
+            cores = os.cpu_count() or 1
+            n_mt = min(n_reads, max(2000, 150 * cores))
+            t0 = time.perf_counter()
+            mt_logp = O.viterbi_many_threads(bases[:off[n_mt]], off[:n_mt + 1], cores)
+            dt = time.perf_counter() - t0
+            assert np.array_equal(mt_logp, logp[:n_mt]), "GPU/oracle log-prob mismatch on the all-cores sample"
+            out["cpu_baseline_all_cores"] = {"value": n_mt / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                                             "cpu_model": cpu_model_name(),
+                                             "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
+                                                       "bit-equal on the sample" % (n_mt, cores)}
+        emit(out)
+    passes.close()
+    if comm:
+        comm.close()
+    return rc

@@ -246,13 +246,14 @@ def test_host_comm_world_size_3(tmp_path):
 
 
 def test_product_imports_no_torch():
-    """north_star: no PyTorch on the path -- nothing under advntr_amd/ and not bench.py either."""
+    """north_star: no PyTorch on the path -- nothing under advntr_amd/, and neither bench.py nor its package benchlib/."""
     import re
     from conftest import ROOT
     offenders = []
     files = [os.path.join(ROOT, "bench.py")]
-    for dirpath, _, names in os.walk(os.path.join(ROOT, "advntr_amd")):
-        files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
+    for pkg in ("advntr_amd", "benchlib"):
+        for dirpath, _, names in os.walk(os.path.join(ROOT, pkg)):
+            files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
     for path in files:
         if re.search(r"^\s*(import|from)\s+torch\b", open(path).read(), re.M):
             offenders.append(path)
@@ -378,3 +379,35 @@ def test_init_watchdog_ends_a_rank_whose_peer_left_an_abort_marker(tmp_path):
     w3.cancel()                                                 # the call returned in time: nobody is ended
     time.sleep(0.1)
     assert quiet == []
+    # a marker an EARLIER job left in a reused rendezvous directory (its mtime lies before this watchdog's start) ends nobody
+    d3 = tmp_path / "rdzv3"
+    d3.mkdir(mode=0o700)
+    stale = d3 / "abort.1"
+    stale.write_bytes(b"left by a job that crashed yesterday")
+    os.utime(str(stale), (time.time() - 3600, time.time() - 3600))
+    old = []
+    w4 = comm.InitWatchdog(str(d3), 0, timeout=30.0, on_end=lambda status, msg: old.append(status), poll=0.02)
+    time.sleep(0.2)
+    assert old == []
+    (d3 / "abort.2").write_bytes(b"this job's")                 # ... a fresh one does
+    t0 = time.monotonic()
+    while not old and time.monotonic() - t0 < 5:
+        time.sleep(0.01)
+    w4.cancel()
+    assert old == [71]
+
+
+def test_ranks_of_one_host_are_frugal_with_its_cpus(monkeypatch):
+    """N ranks on one host: each rank's waits on the device sleep (ADVNTR_BLOCKING_SYNC) and its bulk host calls use 1 / N of the
+    CPUs the job may use (ADVNTR_HOST_THREADS); values the caller set win."""
+    from advntr_amd import _lib, comm
+    monkeypatch.delenv("ADVNTR_BLOCKING_SYNC", raising=False)
+    monkeypatch.delenv("ADVNTR_HOST_THREADS", raising=False)
+    total = int(_lib.load().advntr_host_threads())
+    got = comm.frugal_host_for_ranks(4)
+    assert got["ADVNTR_BLOCKING_SYNC"] == "1" and int(got["ADVNTR_HOST_THREADS"]) == max(1, total // 4)
+    assert int(_lib.load().advntr_host_threads()) == max(1, total // 4)      # (read at every call)
+    monkeypatch.setenv("ADVNTR_HOST_THREADS", "3")
+    monkeypatch.setenv("ADVNTR_BLOCKING_SYNC", "0")
+    assert comm.frugal_host_for_ranks(4) == {}
+    assert int(_lib.load().advntr_host_threads()) == 3
