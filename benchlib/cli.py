@@ -50,6 +50,9 @@ def parse_args(argv=None):
                     help="loci of the `pacbio_end_to_end` sub-record (whole 5-15 kb reads: 896 loci are 180 MB of read text)")
     ap.add_argument("--filter-reads", type=int, default=2000000, help="reads of the `prefilter` sub-record")
     ap.add_argument("--flank-reads", type=int, default=4000, help="reads of the `flank_align` sub-record")
+    ap.add_argument("--no-n1", action="store_true",
+                    help="c3 / c4 with more than one rank: leave out `same_workload_n1` (rank 0 scoring the WHOLE set alone after the "
+                         "timed region, the line's own baseline) and `efficiency_measured`")
     ap.add_argument("--dry-run", action="store_true", help="plan + rendezvous only, no GPU work (host communicator)")
     ap.add_argument("--launch-timeout", type=float, default=1800.0,
                     help="--gpus N > 1 started without a launcher: seconds after which the ranks are ended and the status is non-zero")

@@ -1,0 +1,63 @@
+"""What the host gives this process: the CPU quota of its control group, and how often the scheduler throttled the group while a
+region ran (cpu.stat: a process that exhausts its quota is stopped as a whole -- the thread that launches kernels included -- for
+the rest of the 100-ms accounting period)."""
+import os
+
+
+def _cgroup_dir():
+    """The process's own control group in the mounted hierarchy (cgroup v2: '0::<path>' in /proc/self/cgroup)."""
+    rel = "/"
+    try:
+        for line in open("/proc/self/cgroup"):
+            if line.startswith("0::"):
+                rel = line[3:].strip() or "/"
+    except OSError:
+        pass
+    d = os.path.join("/sys/fs/cgroup", rel.lstrip("/"))
+    return d if os.path.isdir(d) else "/sys/fs/cgroup"
+
+
+def cpu_stat():
+    """{nr_periods, nr_throttled, throttled_usec} of the control group (walking up to the first cpu.stat that has them), or {}."""
+    d = _cgroup_dir()
+    while True:
+        for name in ("cpu.stat", os.path.join("cpu", "cpu.stat")):            # v2, then the v1 controller directory
+            try:
+                kv = dict(line.split()[:2] for line in open(os.path.join(d, name)) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if "nr_throttled" in kv:
+                usec = int(kv["throttled_usec"]) if "throttled_usec" in kv else int(kv.get("throttled_time", 0)) // 1000
+                return {"nr_periods": int(kv.get("nr_periods", 0)), "nr_throttled": int(kv["nr_throttled"]), "throttled_usec": usec}
+        if d in ("/sys/fs/cgroup", "/"):
+            return {}
+        d = os.path.dirname(d)
+
+
+def cpu_quota_cores():
+    """CPUs the process may really use (advntr_host_threads: hardware threads cut down to affinity and the cgroup quota)."""
+    from advntr_amd import _lib
+    return int(_lib.load().advntr_host_threads())
+
+
+class HostRegion(object):
+    """Throttle counters around a region: `with HostRegion() as h: ...; h.record()`."""
+
+    def __enter__(self):
+        self.before = cpu_stat()
+        return self
+
+    def __exit__(self, *exc):
+        self.after = cpu_stat()
+        return False
+
+    def record(self):
+        b, a = self.before, getattr(self, "after", None) or cpu_stat()
+        rec = {"cpu_quota_cores": cpu_quota_cores(), "host_threads_available": os.cpu_count()}
+        if a and b:
+            rec.update({"nr_periods_delta": a["nr_periods"] - b["nr_periods"], "nr_throttled_delta": a["nr_throttled"] - b["nr_throttled"],
+                        "throttled_usec_delta": a["throttled_usec"] - b["throttled_usec"]})
+        else:
+            rec.update({"nr_periods_delta": None, "nr_throttled_delta": None, "throttled_usec_delta": None,
+                        "note": "no cpu.stat with throttle counters in this control group"})
+        return rec

@@ -7,6 +7,7 @@ import time
 import numpy as np
 
 from .cli import parse_args, spawn_ranks
+from .hostinfo import HostRegion, cpu_quota_cores
 from .common import (CLOCK_GHZ, HBM_PEAK_GBPS, SIMDS, algorithmic_bytes, cpu_baseline, cpu_model_name, load_json,
                      measured_clock_ghz, pmc_section, ru_concordance)
 from .illumina import target_configuration_records
@@ -33,6 +34,7 @@ def main(argv=None):
 
     from advntr_amd import comm as comm_mod
     rank, local_rank, world = comm_mod.env_world()
+    quota_total = cpu_quota_cores()          # CPUs of the whole job's control group (before a rank takes its 1 / world of them)
     if args.fault:
         kind, _, who = args.fault.partition(":")
         if int(who or -1) == rank:
@@ -69,7 +71,9 @@ def main(argv=None):
     total_calls, t_build, plan_info = None, 0.0, {}
     # passes queued at a time (class Passes): the strong-scaling lines alternate between two copies of a rank's device batch
     in_flight = args.in_flight if args.in_flight else (2 if workload in ("c3", "c4") else 1)
-    host_workers = max(1, min(32, (os.cpu_count() or 2) // world - 1))
+    # (process-pool workers of the synthetic-read generators: out of the CPUs this process GROUP may use -- the control group's
+    # quota, 16 cores on the GPU boxes of this pool, not the 256 hardware threads -- divided among the ranks of the host)
+    host_workers = max(1, min(32, quota_total // world - 1))
     if workload in ("c3", "c4"):
         # every rank derives the same plan and the same LPT partition without communicating
         if workload == "c3":
@@ -91,19 +95,43 @@ def main(argv=None):
                      "per_locus_work_max_over_min": float(max(work)) / max(float(min(work)), 1.0)}
     if args.dry_run:
         counts = comm.allgather_i64(plan_info["calls_per_rank"][rank] if plan_info else args.reads) if comm else [args.reads]
+        per_rank = None
+        with HostRegion() as h:
+            if comm:
+                comm.barrier()
+                got = comm.allreduce_max(float(rank))
+                assert got == float(world - 1), got
         if comm:
-            comm.barrier()
-            got = comm.allreduce_max(float(rank))
-            assert got == float(world - 1), got
+            # the per-rank records of a real line, with the fields a dry run can fill (no GPU work: no timings)
+            mine_rec = json.dumps({"rank": rank, "calls": int(counts[rank]), "loop_ms": None, "kernel_ms": None, "gather_ms": None,
+                                   "cells": None, "host": h.record()}).encode()
+            parts_json = comm.gather_bytes(mine_rec, 0)
+            if rank == 0:
+                per_rank = [json.loads(p) for p in parts_json]
         if rank == 0:
-            emit({"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
-                  "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if workload in ("c3", "c4") else "weak",
-                  "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
-                                  "comm": comm.backend if comm else None}, **plan_info)})
+            strong = workload in ("c3", "c4")
+            line = {"metric": "dry run: plan and rendezvous only", "value": None, "unit": "reads/s", "n_gpus": world,
+                    "steps": 0, "warmup": 0, "dry_run": True, "scaling": "strong" if strong else "weak", "host": h.record(),
+                    "config": dict({"workload": workload, "loci": n_loci, "calls_seen_by_ranks": counts,
+                                    "comm": comm.backend if comm else None, "per_rank": per_rank}, **plan_info)}
+            if strong:
+                line["same_workload_n1"] = {"value": None, "where": "dry run",
+                                            "command": "python bench.py --workload %s --gpus 1 --loci %d --steps %d --warmup %d --in-flight %d"
+                                                       % (workload, n_loci, args.steps, args.warmup, in_flight)}
+                line["efficiency_measured"] = None
+            emit(order_line(line))
         if comm:
             comm.close()
         return 0
+    whole_input = None
     if workload in ("c2", "c3", "c4"):
+        if workload in ("c3", "c4") and world > 1 and rank == 0 and not args.no_n1:
+            # the line's own baseline: rank 0 will score the WHOLE set alone after the timed region (same_workload_n1), so its reads
+            # are made here, before the GPU is touched like every other synthetic input
+            t_whole = time.perf_counter()
+            whole_input = (workloads.make_c4(n_loci, seed=20240603, workers=host_workers) if workload == "c4" else
+                           workloads.make_c2_parallel(n_loci, seed=20240602, build=False, workers=host_workers))
+            whole_input = whole_input + (time.perf_counter() - t_whole,)
         if workload == "c4":
             loci, reads, which = workloads.make_c4(n_loci, seed=20240603, workers=host_workers, only=mine)
         elif workload == "c3":
@@ -200,14 +228,18 @@ def main(argv=None):
     passes.sync()
     if comm:
         comm.barrier()
+    host_region = HostRegion().__enter__()                  # the control group's throttle counters around the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()                                                # every gather of the timed steps completes inside the region
     passes.sync()                                          # ... and so does every pass, on either copy
+    loop_mine = time.perf_counter() - t0                    # this rank's own passes and gathers, before it waits for its peers
     if comm:
         comm.barrier()
     elapsed_mine = time.perf_counter() - t0
+    host_region.__exit__(None, None, None)
+    host_rec = host_region.record()
     elapsed = comm.allreduce_max(elapsed_mine) if comm else elapsed_mine
 
     # one more pass outside the timed region whose gathered records rank 0 checks against what its engine holds
@@ -225,8 +257,9 @@ def main(argv=None):
     logp, summ = batch.fetch()
     per_rank = None
     if comm:
-        rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
-                          "kernel_ms": kernel_ms, "model_build_s": t_build,
+        rec = json.dumps({"rank": rank, "calls": n_reads, "loop_ms": loop_mine / max(args.steps, 1) * 1e3,
+                          "loop_ms_per_step": elapsed_mine / max(args.steps, 1) * 1e3,
+                          "kernel_ms": kernel_ms, "model_build_s": t_build, "host": host_rec,
                           # the share's ACTUAL work (the plan prices a locus before its reads exist)
                           "relaxations": relax_total, "cells": float(np.sum((np.diff(off) + 1) * ms[which])) if workload in ("c2", "c3", "c4") else None,
                           # the last gather of the timed region on the communicator's stream (HIP events): the transfer alone
@@ -253,6 +286,17 @@ def main(argv=None):
         if rank == 0:
             np.savez(args.dump_records, ids=res[0], logp=res[1], summary=res[2])
 
+    # ---------------------------------------------------------------- the line's own N = 1 baseline
+    # An N-rank strong-scaling line is only worth its same-workload one-rank rate: rank 0 scores the WHOLE set alone, here, after
+    # the timed region, in the same process on the same GPU, with the line's own steps / warm-up / passes in flight; its peers wait
+    # at the barrier.  (`--gpus 1` without --workload runs C1, a different workload: the driver's curve across N mixes the two.)
+    n1 = None
+    if whole_input is not None:
+        passes.close()                                      # (rank 0 has its GPU to itself for this)
+        n1 = same_workload_n1(_lib, workloads, whole_input, flags, args, in_flight, workload)
+    if comm and world > 1 and workload in ("c3", "c4") and not args.no_n1:
+        comm.barrier()
+
     rc = 0
     if rank == 0:
         total_reads = total_calls if total_calls is not None else n_reads * world
@@ -272,7 +316,7 @@ def main(argv=None):
                   "seed 20240601")
         elif workload == "c4":
             metric = ("calls/sec Viterbi-scored (PacBio: trimmed spanning reads, mean %d bases, %d per-locus profile HMMs%s, "
-                      "mean %d states)" % (n, n_loci, " partitioned over %d GPUs" % world if world > 1 else "", m))
+                      "mean %d states)" % (n, n_loci, " partitioned over %d GPUs" % world, m))
             wl = ("C4: %d synthetic PacBio loci (pattern 10-60 bp, VNTR 100-1000 bp, flank 100, error rate 0.3) x 20 trimmed "
                   "spanning reads at +-20 %% of the reference copy number, 12 %% indel/substitution noise, seed 20240603 "
                   "(ONE set; whole loci assigned to ranks by LPT on calls x (reference VNTR length + 201) x expected states; "
@@ -306,6 +350,25 @@ def main(argv=None):
                          "note": "tier rule: algorithmic bytes (SURVEY 8d) / HIP-event kernel time against HBM; the "
                                  "roof that actually binds this max-plus recurrence is fp64 VALU issue -> bound_actual"},
         }
+        if workload in ("c3", "c4"):
+            # which one-rank run this line compares with -- and, for N > 1, that run's rate measured inside this very job
+            n1_cmd = "python bench.py --workload %s --gpus 1 --loci %d --steps %d --warmup %d --in-flight %d" % (
+                workload, n_loci, args.steps, args.warmup, in_flight)
+            if world == 1:
+                out["same_workload_n1"] = {"value": value, "unit": "reads/s", "ms_per_step": elapsed / args.steps * 1e3,
+                                           "kernel_ms": kernel_ms, "calls": int(n_reads), "passes_in_flight": in_flight,
+                                           "command": n1_cmd, "where": "this line"}
+                out["efficiency_measured"] = 1.0
+            elif n1 is not None:
+                out["same_workload_n1"] = dict(n1, command=n1_cmd)
+                out["efficiency_measured"] = value / (world * n1["value"])
+            else:
+                out["same_workload_n1"] = {"value": None, "command": n1_cmd, "where": "not measured (--no-n1)"}
+                out["efficiency_measured"] = None
+            out["efficiency_note"] = ("value / (n_gpus x same_workload_n1.value): the same locus set, the same metric string family, "
+                                      "steps, warm-up and passes in flight; the N = 1 figure has no gather, an N-rank one has it "
+                                      "inside its timed region")
+        out["host"] = host_rec
         if comm:
             # what carried the gather, at the top level of the line: "rccl", or "host" when ADVNTR_COMM_FALLBACK=1 let the
             # ranks drop to the file rendezvous (without that variable a job whose RCCL cannot be set up ends with an error)
@@ -382,19 +445,124 @@ def main(argv=None):
                                                    "thread (profiles/cpu_calibration.json, oracle/tools/calibrate_cpu.py)"
                                                    % (ratio, cal.get("cpu_model", "?"))) if ratio else None}
             out["config"]["speedup_vs_cpu_1thread"] = value / cps
-            # the same restatement on every host core (the reference has no such mode; stated for scale only)
-            cores = os.cpu_count() or 1
-            n_mt = min(n_reads, max(2000, 150 * cores))
-            t0 = time.perf_counter()
-            mt_logp = O.viterbi_many_threads(bases[:off[n_mt]], off[:n_mt + 1], cores)
-            dt = time.perf_counter() - t0
+            # the same restatement on every core this process may use (the reference has no such mode; stated for scale only).
+            # `cores` = the threads really used = the CPU quota of the process's control group (advntr_host_threads: 16 on the GPU
+            # boxes of this pool) -- NOT the 256 hardware threads of the host, which the quota would only throttle
+            cores = max(1, quota_total)
+            n_mt = min(n_reads, max(2000, 600 * cores))
+            with HostRegion() as h_mt:
+                t0 = time.perf_counter()
+                mt_logp = O.viterbi_many_threads(bases[:off[n_mt]], off[:n_mt + 1], cores)
+                dt = time.perf_counter() - t0
             assert np.array_equal(mt_logp, logp[:n_mt]), "GPU/oracle log-prob mismatch on the all-cores sample"
+            mt_host = h_mt.record()
             out["cpu_baseline_all_cores"] = {"value": n_mt / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-                                             "cpu_model": cpu_model_name(),
-                                             "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads; GPU logp "
-                                                       "bit-equal on the sample" % (n_mt, cores)}
-        emit(out)
+                                             "cpu_model": cpu_model_name(), "host_threads_available": os.cpu_count(),
+                                             "nr_throttled": mt_host.get("nr_throttled_delta"),
+                                             "throttled_usec": mt_host.get("throttled_usec_delta"),
+                                             "sample": "first %d reads, oracle/viterbi_oracle.c on %d pthreads (= the CPU quota of the "
+                                                       "process's control group); GPU logp bit-equal on the sample" % (n_mt, cores)}
+        emit(order_line(out))
     passes.close()
     if comm:
         comm.close()
     return rc
+
+
+def same_workload_n1(_lib, workloads, whole_input, flags, args, in_flight, workload):
+    """Rank 0 of an N-rank strong-scaling job scores the WHOLE locus set alone: what `--workload c3|c4 --gpus 1` measures, taken
+    inside the N-rank job (same box, same GPU, same build) with the line's own steps, warm-up and passes in flight."""
+    from advntr_amd.pomegranate import device_models
+    loci, reads, which, t_gen = whole_input
+    t0 = time.perf_counter()
+    workloads.build_models(loci)
+    t_build = time.perf_counter() - t0
+    bases, off = _lib.encode_reads(reads)
+    dms = device_models([l.model for l in loci])
+    make = lambda extra=0: _lib.DeviceBatch(dms, bases, off, which, flags=flags | extra)          # noqa: E731
+    passes = Passes(make, in_flight)
+    try:
+        for _ in range(args.warmup):
+            passes.run()
+        passes.sync()
+        with HostRegion() as h:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                passes.run()
+            passes.sync()
+            dt = time.perf_counter() - t0
+        kernel_ms = passes.batches[0].run_timed(max(1, args.steps))
+    finally:
+        passes.close()
+    return {"value": len(reads) * args.steps / dt, "unit": "reads/s", "ms_per_step": dt / args.steps * 1e3, "kernel_ms": kernel_ms,
+            "calls": int(len(reads)), "loci": int(len(loci)), "steps": args.steps, "warmup": args.warmup,
+            "passes_in_flight": in_flight, "model_build_s": t_build, "reads_generated_s": t_gen, "host": h.record(),
+            "where": "rank 0 alone on its GPU, after the timed region of the N-rank job (its peers wait at a barrier)"}
+
+
+# keys of the line in the order they are written: the compact summary FIRST (a driver that keeps only the head or a few parsed
+# keys of a long line still has every headline number), the contract's keys, then the sub-records, the bulky ones (per-share
+# lists of the rehearsals) last
+LINE_ORDER = ("summary", "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "roofline", "cpu_baseline", "same_workload_n1", "efficiency_measured", "efficiency_note",
+              "comm", "rccl", "host", "config", "ru_concordance", "cpu_baseline_all_cores", "two_passes_in_flight", "s300",
+              "log_probability", "c2", "end_to_end", "illumina_pipeline", "c4", "pacbio_end_to_end", "prefilter", "flank_align")
+LINE_LAST = ("scale_rehearsal", "c4_scale_rehearsal")
+
+
+def line_summary(out):
+    """The headline numbers of a line, a few hundred bytes."""
+    def pick(rec, *keys):
+        return {k: rec.get(k) for k in keys if rec and rec.get(k) is not None} if rec else None
+
+    def frac_of(rec):
+        return (rec.get("roofline") or {}).get("frac", rec.get("frac")) if rec else None
+    s = {"value": out.get("value"), "unit": out.get("unit"), "n_gpus": out.get("n_gpus"), "ms_per_step": out.get("ms_per_step"),
+         "roofline_frac": (out.get("roofline") or {}).get("frac"), "kernel_ms": (out.get("roofline") or {}).get("kernel_ms")}
+    if out.get("same_workload_n1") is not None:
+        s["same_workload_n1_value"] = out["same_workload_n1"].get("value")
+        s["efficiency_measured"] = out.get("efficiency_measured")
+    per_rank = (out.get("config") or {}).get("per_rank")
+    if per_rank:
+        s["slowest_rank_loop_ms"] = max(r.get("loop_ms") or 0.0 for r in per_rank)
+        s["slowest_rank_kernel_ms"] = max(r.get("kernel_ms") or 0.0 for r in per_rank)
+        gathers = [r["gather_ms"] for r in per_rank if r.get("gather_ms") is not None]
+        s["max_gather_ms"] = max(gathers) if gathers else None
+        throttled = [(r.get("host") or {}).get("nr_throttled_delta") for r in per_rank]
+        s["throttled_periods_in_timed_region"] = max([t for t in throttled if t is not None], default=None)
+    elif out.get("host"):
+        s["throttled_periods_in_timed_region"] = out["host"].get("nr_throttled_delta")
+    for key in ("s300", "c2", "c4"):
+        if out.get(key):
+            s[key] = {"value": out[key].get("value"), "frac": frac_of(out[key]), "kernel_ms": out[key].get("kernel_ms")}
+    if out.get("log_probability"):
+        s["log_probability"] = pick(out["log_probability"], "value", "kernel_ms")
+    if out.get("end_to_end"):
+        s["end_to_end_total_s"] = out["end_to_end"].get("total_s")
+    if out.get("illumina_pipeline"):
+        s["illumina_pipeline_total_s"] = out["illumina_pipeline"].get("total_s")
+    if out.get("pacbio_end_to_end"):
+        s["pacbio_end_to_end_total_s"] = out["pacbio_end_to_end"].get("total_s")
+    for key, name in (("scale_rehearsal", "projected_efficiency_c3_8_ranks"), ("c4_scale_rehearsal", "projected_efficiency_c4_8_ranks")):
+        if out.get(key):
+            s[name] = out[key].get("projected_efficiency")
+            s[name + "_one_pass_in_flight"] = out[key].get("projected_efficiency_one_pass_in_flight")
+    if out.get("cpu_baseline"):
+        s["cpu_baseline_value"] = out["cpu_baseline"].get("value")
+    return s
+
+
+def order_line(out):
+    out = dict(out)
+    out["summary"] = line_summary(out)
+    ordered = {}
+    for k in LINE_ORDER:
+        if k in out:
+            ordered[k] = out[k]
+    for k in out:
+        if k not in ordered and k not in LINE_LAST:
+            ordered[k] = out[k]
+    for k in LINE_LAST:
+        if k in out:
+            ordered[k] = out[k]
+    return ordered

@@ -24,6 +24,21 @@ def test_gpus_2_spawns_two_ranks():
     assert cfg["workload"] == "c3" and cfg["comm"] == "host"
     assert cfg["calls_seen_by_ranks"] == cfg["calls_per_rank"] and len(cfg["calls_per_rank"]) == 2      # both ranks reported in
     assert sum(cfg["loci_per_rank"]) == 48 and cfg["load_imbalance_max_over_mean"] < 1.05
+    # a multi-GPU line is self-contained: it names the one-rank run of the SAME workload it compares with, carries that run's rate
+    # (measured inside the N-rank job; not in a dry run) and the efficiency derived from it, per-rank records with the host's CPU
+    # quota and throttle counters, and a compact summary FIRST so that a truncated record keeps the headline numbers
+    assert list(d.keys())[0] == "summary"
+    n1 = d["same_workload_n1"]
+    assert "--workload c3 --gpus 1" in n1["command"] and "--loci 48" in n1["command"] and "efficiency_measured" in d
+    assert set(d["summary"]) >= {"value", "n_gpus", "same_workload_n1_value", "efficiency_measured", "slowest_rank_loop_ms",
+                                 "max_gather_ms", "throttled_periods_in_timed_region"}
+    ranks = cfg["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["calls"] for r in ranks] == cfg["calls_per_rank"]
+    for r in ranks:
+        assert set(r) >= {"loop_ms", "kernel_ms", "gather_ms", "cells", "host"}
+        assert set(r["host"]) >= {"cpu_quota_cores", "nr_throttled_delta", "throttled_usec_delta"}
+        assert 1 <= r["host"]["cpu_quota_cores"] <= max(1, (os.cpu_count() or 1) // 2)       # a rank's share of the host's CPUs
+    assert len(json.dumps(d["summary"])) < 1000
 
 
 def test_c4_gpus_2_is_one_set_partitioned():
@@ -35,6 +50,7 @@ def test_c4_gpus_2_is_one_set_partitioned():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cfg["workload"] == "c4"
     assert sum(cfg["loci_per_rank"]) == 40 and sum(cfg["calls_per_rank"]) == 800 == sum(cfg["calls_seen_by_ranks"])
     assert cfg["load_imbalance_max_over_mean"] < 1.05 and cfg["per_locus_work_max_over_min"] > 3
+    assert "--workload c4 --gpus 1" in d["same_workload_n1"]["command"] and list(d.keys())[0] == "summary"
 
 
 def test_gpus_3_under_torch_distributed_run():

@@ -266,6 +266,15 @@ def test_c3_rccl_communicator_world_size_1(tmp_path):
     assert d["config"]["comm"] == "rccl" and d["config"]["world_size_seen_by_comm"] == 1
     assert d["comm"] == "rccl" and d["rccl"] is True                      # at the top level of the line
     assert d["config"]["per_rank"][0]["gather_ms"] is not None and d["config"]["per_rank"][0]["gather_ms"] >= 0.0
+    # the line is self-contained (see tests/test_bench_launch.py): summary first, the same-workload one-rank figure (at world
+    # size 1: this line), per-rank loop / kernel / gather times and cells, the host's CPU quota and throttle counters
+    assert list(d.keys())[0] == "summary" and d["summary"]["value"] == d["value"] and d["summary"]["max_gather_ms"] is not None
+    assert d["efficiency_measured"] == 1.0 and d["same_workload_n1"]["value"] == d["value"]
+    assert "--workload c3 --gpus 1" in d["same_workload_n1"]["command"] and "partitioned over 1 GPUs" in d["metric"]
+    r0 = d["config"]["per_rank"][0]
+    assert r0["loop_ms"] > 0 and r0["kernel_ms"] > 0 and r0["cells"] > 0 and r0["loop_ms"] <= r0["loop_ms_per_step"] + 1e-6
+    assert r0["host"]["cpu_quota_cores"] >= 1 and r0["host"]["nr_throttled_delta"] is not None
+    assert d["host"]["cpu_quota_cores"] >= 1
     _bench(common + ["--dump-records", ref])
     a, b = np.load(rec), np.load(ref)
     assert np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
