@@ -171,6 +171,47 @@ class KeywordFilter(object):
         seq_of = lambda r: text[starts[2 * r + 1]:ends[2 * r + 1]].decode("latin-1")
         return self._select_records(recs, name_of, seq_of, min_matches, max_reads)
 
+    def fasta_spans(self, text):
+        """(name start, name end, sequence start, sequence end) of the records of a two-line FASTA file, as arrays."""
+        starts = _lib.line_index(text)
+        n_lines = len(starts) - 1
+        n_rec = n_lines // 2 if n_lines % 2 == 0 else (n_lines - 1) // 2
+        ends = starts[1:] - 1                                           # exclusive end of each line (before its newline)
+        if n_lines and not text.endswith(b"\n"):
+            ends = ends.copy()
+            ends[-1] = len(text)
+        name_lines, seq_lines = np.arange(n_rec) * 2, np.arange(n_rec) * 2 + 1
+        return starts[name_lines] + 1, ends[name_lines], starts[seq_lines], ends[seq_lines]
+
+    def candidate_spans(self, text, min_matches=5, max_reads=2000, timings=None):
+        """The per-VNTR read lists of select_fasta() -- what `GenomeAnalyzer.get_filtered_read_ids` parses out of the binary's
+        stdout (genome_analyzer.py:183-197) and the per-locus loop then looks up read by read (:283) -- as ARRAYS, without a Python
+        object per read: (locus_off int64[n_vntr + 1], read index, sequence span start, sequence span end), VNTRs in the order of
+        the keyword lines, a VNTR's reads in ascending name order (the order of the binary's read lines, main.cc:325-331).  Same
+        bookkeeping as _select_records (main.cc:286-331: the 3 x max_reads intake cap in file order, descending (count, name),
+        the max_reads + 1 names quirk); the keyword lines must name every VNTR once."""
+        if len(set(self.vntr_ids)) != len(self.vntr_ids):
+            raise ValueError("candidate_spans: a VNTR id occurs on several keyword lines")
+        import time
+        t0 = time.perf_counter()
+        name_s, name_e, seq_s, seq_e = self.fasta_spans(text)
+        t1 = time.perf_counter()
+        reads, vntrs, counts = self.scan_text(text, seq_s, seq_e)
+        t2 = time.perf_counter()
+        if timings is not None:
+            timings.update(line_index=t1 - t0, scan=t2 - t1, scan_kernel_ms=self.kernel_ms, hit_records=int(len(reads)))
+        picked_r, picked_v = select_candidates(reads, vntrs, counts, lambda idx: _name_keys(text, name_s[idx], name_e[idx]),
+                                               min_matches, max_reads)
+        # scan indices follow the SORTED ids; the lists go out in keyword-line order
+        line_of_sorted = np.argsort(np.asarray(self.vntr_ids), kind="stable")      # sorted-id index k -> line of that id
+        v_line = line_of_sorted[picked_v] if len(picked_v) else np.zeros(0, np.int64)
+        o = np.argsort(v_line, kind="stable")                                      # (name order inside a VNTR is kept)
+        picked_r, v_line = picked_r[o], v_line[o]
+        locus_off = np.searchsorted(v_line, np.arange(len(self.vntr_ids) + 1)).astype(np.int64)
+        if timings is not None:
+            timings.update(select=time.perf_counter() - t2, candidates=int(len(picked_r)))
+        return locus_off, picked_r, seq_s[picked_r], seq_e[picked_r]
+
     def _select_records(self, recs, name_of, seq_of, min_matches, max_reads):
         """recs = (read index, vntr id, occurrences) in read order, VNTR ids ascending within a read."""
         vntr_read_list, read_sequences = {}, {}
@@ -199,6 +240,57 @@ class KeywordFilter(object):
         for name in sorted(filtered):
             out.append("%s %s" % (name, read_sequences[name]))
         return "\n".join(out) + "\n"
+
+
+def _name_keys(text, start, end):
+    """Read names text[start[i]:end[i]] as a numpy bytes array that orders like the strings do (byte-wise)."""
+    start, end = np.asarray(start, np.int64), np.asarray(end, np.int64)
+    if len(start) == 0:
+        return np.zeros(0, "S1")
+    width = end - start
+    if width.min() == width.max() and width[0] > 0:                    # fixed-width names: one gather, no Python object per read
+        L = int(width[0])
+        buf = np.frombuffer(text, np.uint8)
+        return np.ascontiguousarray(buf[start[:, None] + np.arange(L)]).view("S%d" % L).reshape(-1)
+    return np.array([text[a:b] for a, b in zip(start.tolist(), end.tolist())], dtype=bytes)
+
+
+def select_candidates(reads, vntrs, counts, name_keys, min_matches=5, max_reads=2000):
+    """The bookkeeping of filtering/main.cc:286-331 on arrays.  (reads, vntrs, counts): one record per (read, VNTR) pair with
+    a keyword hit, in FILE order of the reads; name_keys(read indices) -> their names as a bytes array.  Returns (read index,
+    VNTR index) of the reads the binary lists for each VNTR: reads with >= min_matches hits, at most 3 * max_reads + 1 of them
+    taken in file order (the intake cap, main.cc:300), of those the max_reads + 1 first in descending (count, name) order (the
+    loop that prints names breaks AFTER index max_reads); grouped by VNTR, ascending name inside a VNTR.  (Two reads of one
+    name collapse in the binary's std::map; here they stay two -- read files do not repeat names.)"""
+    reads, vntrs, counts = np.asarray(reads, np.int64), np.asarray(vntrs, np.int64), np.asarray(counts, np.int64)
+    ok = counts >= min_matches
+    r, v, c = reads[ok], vntrs[ok], counts[ok]
+    if len(r) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+
+    def rank_in_group(group):                                           # position of every element inside its run of equal `group`
+        first = np.concatenate([[True], group[1:] != group[:-1]])
+        start = np.maximum.accumulate(np.where(first, np.arange(len(group)), 0))
+        return np.arange(len(group)) - start
+    o = np.lexsort((r, v))                                              # per VNTR, file order
+    r, v, c = r[o], v[o], c[o]
+    keep = rank_in_group(v) <= 3 * max_reads
+    r, v, c = r[keep], v[keep], c[keep]
+    names = name_keys(r)
+    name_rank = np.empty(len(r), np.int64)
+    name_rank[np.argsort(names, kind="stable")] = np.arange(len(r))
+    # equal names share a rank (so that descending and ascending orders agree on them)
+    sorted_names = names[np.argsort(names, kind="stable")]
+    same = np.concatenate([[False], sorted_names[1:] == sorted_names[:-1]])
+    if same.any():
+        dense = np.cumsum(~same) - 1
+        name_rank[np.argsort(names, kind="stable")] = dense
+    o = np.lexsort((-name_rank, -c, v))                                 # per VNTR, descending (count, name)
+    r, v, name_rank = r[o], v[o], name_rank[o]
+    keep = rank_in_group(v) <= max_reads
+    r, v, name_rank = r[keep], v[keep], name_rank[keep]
+    o = np.lexsort((name_rank, v))
+    return r[o], v[o]
 
 
 def run(fasta_text, keywords_text, min_matches=5):

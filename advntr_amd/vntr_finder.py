@@ -168,6 +168,51 @@ def _prepare_reads(read_lists, threads=0):
     return dict(locus=locus_all[keep], index=index_all[keep], lens=lens, bases=codes[np.repeat(keep, all_len)], off=off)
 
 
+class TextReads(object):
+    """The candidate reads of many loci as SPANS of one text -- the bytes of the FASTA file the keyword prefilter scanned
+    (filtering.KeywordFilter.candidate_spans) -- instead of a list of str per locus: locus k's reads are spans
+    locus_off[k] .. locus_off[k + 1].  genotype_loci_pipelined encodes a piece's reads straight out of the text
+    (advntr_encode_spans, host threads); no Python object per read exists anywhere between the file and the genotypes."""
+
+    def __init__(self, text, span_start, span_end, locus_off):
+        self.text = text
+        self.span_start = np.ascontiguousarray(span_start, np.int64)
+        self.span_end = np.ascontiguousarray(span_end, np.int64)
+        self.locus_off = np.ascontiguousarray(locus_off, np.int64)
+
+    def __len__(self):
+        return len(self.locus_off) - 1
+
+    def read_lists(self):
+        """The same reads as lists of str (the stage-by-stage route and the tests)."""
+        t = self.text
+        return [[t[a:b].decode("latin-1") for a, b in zip(self.span_start[lo:hi].tolist(), self.span_end[lo:hi].tolist())]
+                for lo, hi in zip(self.locus_off[:-1].tolist(), self.locus_off[1:].tolist())]
+
+    def prepare(self, lo, hi, threads=0):
+        """_prepare_reads for loci lo .. hi - 1."""
+        a, b = int(self.locus_off[lo]), int(self.locus_off[hi])
+        if a == b:
+            return None
+        counts = np.diff(self.locus_off[lo:hi + 1])
+        codes, off, bad = _lib.encode_spans(self.text, self.span_start[a:b], self.span_end[a:b], threads=threads)
+        if np.any(bad == 2):
+            raise ValueError("Symbol is not defined in a distribution (read %d holds a symbol outside ACGTN)" % int(np.argmax(bad == 2)))
+        lens = np.diff(off)
+        locus_all = np.repeat(np.arange(hi - lo, dtype=np.int32), counts)
+        index_all = (np.arange(b - a, dtype=np.int64) - np.repeat(np.cumsum(counts) - counts, counts)).astype(np.int32)
+        keep = bad == 0
+        nf = int(keep.sum())
+        if nf == 0:
+            return None
+        if nf == b - a:
+            return dict(locus=locus_all, index=index_all, lens=lens, bases=codes, off=off)
+        klens = lens[keep]
+        koff = np.zeros(nf + 1, np.int64)
+        np.cumsum(klens, out=koff[1:])
+        return dict(locus=locus_all[keep], index=index_all[keep], lens=klens, bases=codes[np.repeat(keep, lens)], off=koff)
+
+
 def _score_prepared(models, prep, scaled_scores=None, compute_reverse=True):
     """The device half: both strands in one engine batch -- the reverse complements are made on the device
     (ADVNTR_FLAG_BOTH_STRANDS), call nf + i = reverse complement of read i --, the strand choice and the recruit rule."""
@@ -366,8 +411,10 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     built = _Stage("advntr-build", lambda k: hmm_utils.build_read_matcher_models(loci[cuts[k]:cuts[k + 1]], threads=t_build),
                    chunks, [], abort, (T, "build_models"))
     uploaded = _Stage("advntr-upload", upload, chunks, [built], abort, (T, "upload_models"))
-    encoded = _Stage("advntr-encode", lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_enc),), chunks, [], abort,
-                     (T, "encode_reads"))
+    # (read_lists: a list of str per locus, or the loci's reads as spans of one text -- TextReads)
+    prepare = (lambda k: (read_lists.prepare(cuts[k], cuts[k + 1], t_enc),)) if isinstance(read_lists, TextReads) else \
+              (lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_enc),))
+    encoded = _Stage("advntr-encode", prepare, chunks, [], abort, (T, "encode_reads"))
     bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
     stages = [built, uploaded, encoded, bound]
     # What follows a piece's kernels runs on a thread of its own: the aggregation and the maximum-likelihood genotypes of the

@@ -326,6 +326,37 @@ def make_prefilter_workload(n_loci=6719, n_reads=2000000, read_len=150, locus_ev
     return lines, fasta.tobytes(), rec_len
 
 
+def make_illumina_pipeline_workload(loci, candidates, n_reads=10000000, read_len=150, seed=20240605):
+    """The `advntr genotype` flow's input at model-database scale, for ONE timeline from file bytes to genotype rows: the
+    keyword lines of `loci` (15-mers, a keyword every 5 bases over 15 + VNTR + 15: vntr_finder.py:140-153, ids 1 .. n in locus
+    order) and the bytes of a two-line FASTA file of n_reads reads in which the loci's candidate reads (candidates[k]: forward
+    strands, read_len bases each) are planted at random record positions among windows of random sequence.  Returns (keyword
+    lines, fasta bytes, record length, planted record index per candidate in locus order)."""
+    from .filtering import get_keywords_for_filtering
+    rng = np.random.default_rng(seed)
+    lines = [(k + 1, get_keywords_for_filtering(l.left, l.units, l.right, l.units[0], True, 15)) for k, l in enumerate(loci)]
+    flat = [s for c in candidates for s in c]
+    if any(len(s) != read_len for s in flat):
+        raise ValueError("make_illumina_pipeline_workload: every candidate read must have %d bases" % read_len)
+    n_reads = max(int(n_reads), 2 * len(flat))
+    big = _ACGT[rng.integers(0, 4, read_len * 50000)]
+    r = np.arange(n_reads, dtype=np.int64)
+    rec_len = 10 + read_len + 1
+    fasta = np.empty((n_reads, rec_len), np.uint8)
+    fasta[:, 0], fasta[:, 1], fasta[:, 9], fasta[:, rec_len - 1] = ord(">"), ord("r"), 10, 10
+    for d in range(7):
+        fasta[:, 8 - d] = 48 + (r // 10 ** d) % 10
+    start = (r * 137) % (len(big) - read_len)
+    windows = np.lib.stride_tricks.sliding_window_view(big, read_len)
+    for lo in range(0, n_reads, 1 << 20):                               # (in slabs: the gather's temporaries stay small)
+        fasta[lo:lo + (1 << 20), 10:10 + read_len] = windows[start[lo:lo + (1 << 20)]]
+    at = np.sort(rng.choice(n_reads, len(flat), replace=False))
+    at = at[rng.permutation(len(flat))]                                 # a locus's reads are scattered over the file
+    if flat:
+        fasta[at, 10:10 + read_len] = np.frombuffer("".join(flat).encode(), np.uint8).reshape(len(flat), read_len)
+    return lines, fasta.tobytes(), rec_len, at
+
+
 def make_flank_align_workload(n_reads=4000, min_len=5000, max_len=15000, seed=11):
     """PacBio-sized input of advntr_flank_align: two 100-base flanks and n_reads reads of 5-15 kb, a third of which hold a
     noisy copy (12 %) of flank + repeats + flank.  Returns (left, right, reads)."""

@@ -40,6 +40,11 @@ def parse_args(argv=None):
                     help="one process, one GPU (--workload c3 or c4): partition the locus set for this many ranks (LPT, as --gpus N does), run every "
                          "rank's share as its own resident batch with the multi-GPU launch parameters and print a "
                          "`scale_rehearsal` record -- a PROJECTION of the strong-scaling line, not a measurement of it")
+    ap.add_argument("--processes", action="store_true",
+                    help="with --emulate-ranks N: start N rank PROCESSES that share this box's GPU(s) through the host communicator and "
+                         "run the N-rank strong-scaling line as they would on N GPUs -- what one GPU can show of the HOST side of an "
+                         "N-rank job: every rank's waits, helper threads and launch loop against the one CPU quota of the box "
+                         "(per-rank `host.nr_throttled_delta`); the rates of such a line are those of ranks sharing a GPU")
     ap.add_argument("--root-capacity", type=float, default=0.99,
                     help="c3/c4 with more than one rank: rank 0 (the root of the result gather, which also hosts the receive side "
                          "of every peer's records) gets this fraction of an equal share of the planned work (1.0 = equal shares)")
@@ -50,6 +55,9 @@ def parse_args(argv=None):
                     help="loci of the `pacbio_end_to_end` sub-record (whole 5-15 kb reads: 896 loci are 180 MB of read text)")
     ap.add_argument("--filter-reads", type=int, default=2000000, help="reads of the `prefilter` sub-record")
     ap.add_argument("--flank-reads", type=int, default=4000, help="reads of the `flank_align` sub-record")
+    ap.add_argument("--pipeline-reads", type=int, default=10000000,
+                    help="reads of the FASTA file of the `illumina_pipeline` sub-record (file bytes -> prefilter -> selection -> scoring "
+                         "-> genotypes -> VCF rows on one timeline; 10 M reads are 1.6 GB of text); 0 leaves the record out")
     ap.add_argument("--no-n1", action="store_true",
                     help="c3 / c4 with more than one rank: leave out `same_workload_n1` (rank 0 scoring the WHOLE set alone after the "
                          "timed region, the line's own baseline) and `efficiency_measured`")
@@ -65,7 +73,23 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def spawn_ranks(args, argv):
+def emulation_argv(argv, n):
+    """argv of the rank processes of `--emulate-ranks N --processes`: the same line as `--gpus N`."""
+    out, skip = [], 0
+    for a in argv:
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--emulate-ranks", "--gpus"):
+            skip = 1
+            continue
+        if a.startswith("--emulate-ranks=") or a.startswith("--gpus=") or a == "--processes":
+            continue
+        out.append(a)
+    return out + ["--gpus", str(n), "--no-n1"]
+
+
+def spawn_ranks(args, argv, n=None, extra_env=None):
     """Start the N ranks as children, forward rank 0's line, exit with their status.  The children are watched together:
     the first one to fail, or the overall deadline (--launch-timeout), ends the job -- the children this process started
     are killed (exactly those) and the status is non-zero; a rank left waiting in a collective for a peer that is gone
@@ -95,9 +119,11 @@ def spawn_ranks(args, argv):
             p.kill()
     try:
         with open(out_path, "wb") as out0:
-            for r in range(args.gpus):
-                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+            n_ranks = int(n or args.gpus)
+            for r in range(n_ranks):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                            MASTER_PORT=str(port), ADVNTR_RDZV_DIR=rdzv)
+                env.update(extra_env or {})
                 procs.append(subprocess.Popen([sys.executable, BENCH] + argv, env=env,
                                               stdout=out0 if r == 0 else subprocess.DEVNULL, start_new_session=True))
         deadline = time.time() + args.launch_timeout

@@ -1,9 +1,12 @@
-"""BASELINE config 2 (6 719 Illumina loci) on one GPU: the `end_to_end` and `c2` sub-records of the N = 1 line."""
+"""BASELINE config 2 (6 719 Illumina loci) on one GPU: the `end_to_end`, `c2` and `illumina_pipeline` sub-records of the N = 1 line."""
+import os
+import subprocess
+import tempfile
 import time
 
 import numpy as np
 
-from .common import HBM_PEAK_GBPS, cpu_model_name, load_json, pmc_section
+from .common import HBM_PEAK_GBPS, ROOT, cpu_model_name, load_json, pmc_section
 from .passes import two_in_flight_ms
 from .rehearsal import scale_rehearsal
 
@@ -135,3 +138,128 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
             e2e["reference_scoring_alone_s_pomegranate_equivalent"] = 2 * n_cand / (cps / ratio)
     batch.close()
     return e2e, c2
+
+
+# ------------------------------------------------------------------------------------------------
+# `advntr genotype` on ONE timeline: file bytes -> prefilter -> selection -> scoring -> recruit -> genotypes -> rows
+# ------------------------------------------------------------------------------------------------
+REF_FILTER = os.path.join(ROOT, "oracle", "_ref", "adVNTR-Filtering")
+
+
+def illumina_pipeline_input(workloads, c2_input, args):
+    """Made BEFORE the GPU is touched: the FASTA bytes (the C2 loci's candidate reads planted among background reads), the keyword
+    lines, and -- on a bounded head of the same file -- the REFERENCE's own filter binary started as a child (oracle/_ref,
+    kind "reference"), collected when the record is made."""
+    loci, reads, which, counts = c2_input[:4]
+    first = np.concatenate([[0], np.cumsum([nm + 2 * nu for nm, nu in counts])])
+    candidates = [reads[first[k]:first[k] + nm + nu] for k, (nm, nu) in enumerate(counts)]
+    t0 = time.perf_counter()
+    lines, fasta, rec_len, planted = workloads.make_illumina_pipeline_workload(loci, candidates, args.pipeline_reads)
+    inp = {"loci": loci, "lines": lines, "fasta": fasta, "rec_len": rec_len, "planted": planted,
+           "n_candidates_planted": int(len(planted)), "gen_s": time.perf_counter() - t0, "ref": None}
+    if os.path.exists(REF_FILTER) and not args.no_cpu:
+        sample = min(len(fasta) // rec_len, 50000)
+        d = tempfile.mkdtemp(prefix="advntr_pipeline_ref_")
+        kw, fa = os.path.join(d, "kw.txt"), os.path.join(d, "head.fa")
+        with open(kw, "w") as fh:
+            fh.write("".join("%d %s\n" % (v, " ".join(sorted(k))) for v, k in lines))
+        with open(fa, "wb") as fh:
+            fh.write(fasta[:sample * rec_len])
+        t0 = time.perf_counter()
+        with open(kw) as fin, open(fa + ".out", "wb") as fout:
+            child = subprocess.Popen([REF_FILTER, fa], stdin=fin, stdout=fout)
+        inp["ref"] = {"dir": d, "child": child, "t0": t0, "sample": sample, "out": fa + ".out", "kw": kw}
+    return inp
+
+
+def illumina_pipeline_record(_lib, inp, args):
+    """The reference's `advntr genotype` flow for unmapped short reads on one timeline (genome_analyzer.py:172-208: keywords ->
+    adVNTR-Filtering -> per-VNTR read ids; :262-297: per locus, the filtered reads of that VNTR -> both strands scored ->
+    recruit_read -> repeat counts -> genotype -> a row): FASTA BYTES of >= 10 M reads -> line index + advntr_kwfilter_scan_text ->
+    the selection of filtering/main.cc:286-331 on arrays (filtering.select_candidates) -> the candidates as spans of the same
+    bytes (vntr_finder.TextReads: encoded on host threads piece by piece, no Python object per read) -> genotype_loci_pipelined
+    (native model builder, both strands in one device batch, recruit rule on the device, advntr_genotype_illumina) -> VCF rows.
+    Checked: genotypes == the stage-by-stage route (the filter's stdout TEXT parsed as genome_analyzer.py:183-197 does, reads as
+    str, vntr_finder.genotype_loci on models built up front); the filter's stdout == the reference binary's on the file's head."""
+    from advntr_amd import filtering, genome_analyzer, hmm_utils, models as models_mod, vntr_finder
+    loci, lines, fasta = inp["loci"], inp["lines"], inp["fasta"]
+    desc = [(l.left, l.right, l.units, l.copies) for l in loci]
+    vntrs = []
+    for k, l in enumerate(loci):
+        v = models_mod.ReferenceVNTR(k + 1, l.units[0], 10000 * k, "chr%d" % (1 + k % 22), None, None, len(l.units))
+        v.init_from_xml(list(l.units), l.left, l.right)
+        vntrs.append(v)
+    best, totals = None, []
+    for _ in range(3):                              # (the first pass also sizes the process's buffer caches; all totals are listed)
+        T = {}
+        t0 = time.perf_counter()
+        kf = filtering.KeywordFilter(lines)
+        T["keywords_to_device"] = time.perf_counter() - t0
+        F = {}
+        locus_off, ridx, ss, se = kf.candidate_spans(fasta, min_matches=5, timings=F)
+        kf.close()
+        T.update({"line_index": F["line_index"], "prefilter_scan": F["scan"], "selection": F["select"]})
+        t1 = time.perf_counter()
+        text_reads = vntr_finder.TextReads(fasta, ss, se, locus_off)
+        P = {}
+        genotypes = vntr_finder.genotype_loci_pipelined(desc, text_reads, timings=P)
+        T["models_scoring_recruit_genotypes"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        rows = [genome_analyzer.vcf_header(vntrs, "reads.fa")] + \
+               [genome_analyzer.genotype_row("vcf", v, v.id, g) for v, g in zip(vntrs, genotypes)]
+        T["vcf_rows"] = time.perf_counter() - t2
+        T["total"] = time.perf_counter() - t0
+        totals.append(T["total"])
+        if best is None or T["total"] < best[0]["total"]:
+            best = (T, F, P, genotypes, rows, text_reads, ridx)
+    T, F, P, genotypes, rows, text_reads, ridx = best
+    n_reads = len(fasta) // inp["rec_len"]
+    rec = {"loci": len(loci), "fasta_reads": n_reads, "fasta_bytes": len(fasta), "keywords": int(sum(len(k) for _, k in lines)),
+           "planted_candidates": inp["n_candidates_planted"], "hit_records": F["hit_records"], "selected_candidates": F["candidates"],
+           "viterbi_calls": 2 * F["candidates"], "loci_with_genotype": sum(g.copy_numbers is not None for g in genotypes),
+           "vcf_rows": len(rows) - 1, "total_s": T["total"], "total_s_of_each_pass": totals,
+           "value": n_reads / T["total"], "unit": "reads of the file/s",
+           "stage_s": {k: v for k, v in T.items() if k != "total"}, "prefilter_kernel_ms": F["scan_kernel_ms"],
+           "scoring_stage_s_overlapped": {k: v for k, v in P.items() if k not in ("total", "trace")},
+           "note": "one process, one timeline: from the bytes of the read file to VCF rows; input generated in %.1f s (not timed)"
+                   % inp["gen_s"]}
+    # --- checks, outside the timed passes
+    t0 = time.perf_counter()
+    kw_text = "".join("%d %s\n" % (v, " ".join(sorted(k))) for v, k in lines)
+    stdout_text = filtering.run(fasta, kw_text, 5)
+    names, lists = {}, {}
+    for line in stdout_text.split("\n"):           # genome_analyzer.py:183-197
+        parts = line.split()
+        if len(parts) < 2:
+            continue
+        if parts[0].isdigit() and parts[1].isdigit():
+            lists[int(parts[0])] = set(parts[2:])
+        else:
+            names[parts[0]] = parts[1]
+    # (a VNTR's reads in the order of the binary's read lines -- ascending name -- as the per-locus loop meets them, :283)
+    read_lists = [[names[nm] for nm in sorted(lists.get(v.id, ()))] for v in vntrs]
+    same_reads = sum(sorted(a) == sorted(b) for a, b in zip(read_lists, text_reads.read_lists()))
+    models = hmm_utils.build_read_matcher_models(desc)
+    plain = vntr_finder.genotype_loci(models, read_lists)
+    same = sum(a.copy_numbers == b.copy_numbers and a.recruited_reads_count == b.recruited_reads_count
+               for a, b in zip(plain, genotypes))
+    rec["stage_by_stage_check_s"] = time.perf_counter() - t0
+    rec["candidate_lists_identical_to_stdout_route"] = same_reads == len(loci)
+    rec["genotypes_identical_to_stage_by_stage"] = same == len(loci)
+    assert same_reads == len(loci), "candidate lists differ from the filter's stdout on %d loci" % (len(loci) - same_reads)
+    assert same == len(loci), "one-timeline and stage-by-stage genotypes differ on %d loci" % (len(loci) - same)
+    ref = inp.get("ref")
+    if ref is not None:
+        import shutil
+        try:
+            ref["child"].wait(timeout=600)
+            took = time.perf_counter() - ref["t0"]
+            want = open(ref["out"], "rb").read().decode("latin-1")
+            got = filtering.run(fasta[:ref["sample"] * inp["rec_len"]], kw_text, 5)
+            rec["reference_filter"] = {"kind": "reference", "binary": "oracle/_ref/adVNTR-Filtering (g++ -O2 filtering/main.cc)",
+                                       "sample": "the first %d reads of the same file, all %d keyword lines" % (ref["sample"], len(lines)),
+                                       "stdout_identical": got == want, "wall_s_beside_the_gpu_work": took, "returncode": ref["child"].returncode}
+            assert got == want, "filter stdout differs from the reference binary's on the file's head"
+        finally:
+            shutil.rmtree(ref["dir"], ignore_errors=True)
+    return rec

@@ -6,11 +6,11 @@ import time
 
 import numpy as np
 
-from .cli import parse_args, spawn_ranks
+from .cli import emulation_argv, parse_args, spawn_ranks
 from .hostinfo import HostRegion, cpu_quota_cores
 from .common import (CLOCK_GHZ, HBM_PEAK_GBPS, SIMDS, algorithmic_bytes, cpu_baseline, cpu_model_name, load_json,
                      measured_clock_ghz, pmc_section, ru_concordance)
-from .illumina import target_configuration_records
+from .illumina import illumina_pipeline_input, illumina_pipeline_record, target_configuration_records
 from .passes import Passes, passes_of, two_in_flight_ms
 from .records import forward_record, s300_record
 from .rehearsal import scale_rehearsal
@@ -22,6 +22,10 @@ def main(argv=None):
     args = parse_args(argv)
     if "RANK" not in os.environ and args.gpus > 1:
         return spawn_ranks(args, argv)
+    if "RANK" not in os.environ and args.emulate_ranks > 1 and args.processes:
+        # N rank processes sharing this box's GPU(s) through the host communicator: the host side of an N-rank job on one box
+        return spawn_ranks(args, emulation_argv(argv, args.emulate_ranks), n=args.emulate_ranks,
+                           extra_env={"ADVNTR_DIST_BACKEND": "host", "ADVNTR_EMULATED_RANKS": str(args.emulate_ranks)})
 
     # stdout carries exactly ONE line, the JSON record: anything a library prints while the bench runs (RCCL's version
     # banner, HIP warnings) is sent to stderr
@@ -161,7 +165,7 @@ def main(argv=None):
         alg_bytes_total = float(np.sum(lens + (lens + 1) * ms[which] + (lens + ms[which]) + 32))
         relax_total = float(np.sum((lens + 1) * edges_per_locus[which]))
     else:
-        c2_input = upstream_input = None
+        c2_input = upstream_input = pipeline_input = None
         if world == 1 and workload == "c1" and not args.no_c2 and not args.no_s300:
             # the target configuration of the north star rides on the C1 line as sub-records `c2` / `end_to_end`; its
             # synthetic reads come out of a process pool, which must have gone before the GPU is touched (see above)
@@ -170,6 +174,7 @@ def main(argv=None):
                                                   return_counts=True) + (time.perf_counter() - t_gen,)
             # (a million read strings: out of the garbage collector's sight, or its passes land in the timed loops)
             upstream_input = None if args.no_upstream else upstream_inputs(workloads, host_workers, args)
+            pipeline_input = illumina_pipeline_input(workloads, c2_input, args) if args.pipeline_reads > 0 else None
             import gc
             gc.collect()
             gc.freeze()
@@ -369,6 +374,12 @@ def main(argv=None):
                                       "steps, warm-up and passes in flight; the N = 1 figure has no gather, an N-rank one has it "
                                       "inside its timed region")
         out["host"] = host_rec
+        if os.environ.get("ADVNTR_EMULATED_RANKS"):
+            out["emulated_ranks"] = {"ranks": world, "how": "%d rank processes share this box's GPU(s) through the host communicator "
+                                                            "(--emulate-ranks N --processes)" % world,
+                                     "what_it_shows": "the HOST side of an N-rank job against the box's one CPU quota: per-rank "
+                                                      "host.nr_throttled_delta / throttled_usec_delta around the timed region; the "
+                                                      "rates are those of ranks sharing a GPU, not a scaling measurement"}
         if comm:
             # what carried the gather, at the top level of the line: "rccl", or "host" when ADVNTR_COMM_FALLBACK=1 let the
             # ranks drop to the file rendezvous (without that variable a job whose RCCL cannot be set up ends with an error)
@@ -411,6 +422,8 @@ def main(argv=None):
             if c2_input is not None:
                 out["end_to_end"], out["c2"] = target_configuration_records(_lib, workloads, c2_input, flags, args)
                 out["scale_rehearsal"] = out["c2"].pop("scale_rehearsal")
+                if pipeline_input is not None:
+                    out["illumina_pipeline"] = illumina_pipeline_record(_lib, pipeline_input, args)
             if upstream_input is not None:
                 out["c4"] = c4_record(_lib, workloads, upstream_input, flags, args)
                 out["c4_scale_rehearsal"] = out["c4"].pop("scale_rehearsal")

@@ -89,3 +89,17 @@ def test_a_hanging_rank_is_ended_at_the_launch_deadline():
                        stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 124, (p.returncode, p.stderr[-400:])
     assert b"--launch-timeout" in p.stderr
+
+
+def test_emulate_ranks_as_processes_is_the_n_rank_line():
+    """--emulate-ranks N --processes: N rank processes (sharing the box's GPU through the host communicator when there is one) run
+    the N-rank line itself, so that one box shows the host side of an N-rank job -- every rank with its share of the host's CPUs and
+    the control group's throttle counters around its timed region."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--emulate-ranks", "3", "--processes",
+                          "--dry-run", "--loci", "30"], cwd=ROOT, stdout=subprocess.PIPE, check=True, timeout=300).stdout
+    d = _line(out)
+    assert d["n_gpus"] == 3 and d["config"]["comm"] == "host" and sum(d["config"]["loci_per_rank"]) == 30
+    assert len(d["config"]["per_rank"]) == 3 and all("nr_throttled_delta" in r["host"] for r in d["config"]["per_rank"])
+    from benchlib.cli import emulation_argv
+    assert emulation_argv(["--workload", "c3", "--emulate-ranks", "8", "--processes", "--steps", "5", "--gpus=1"], 8) == \
+        ["--workload", "c3", "--steps", "5", "--gpus", "8", "--no-n1"]

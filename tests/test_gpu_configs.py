@@ -171,6 +171,15 @@ def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
     a, b = np.load(one), np.load(two)
     assert np.array_equal(a["ids"], np.arange(len(a["ids"]))) and np.array_equal(b["ids"], a["ids"])
     assert np.array_equal(a["logp"], b["logp"]) and np.array_equal(a["summary"], b["summary"])
+    # one metric string family per workload for every N, and the 2-rank line carries its own one-rank baseline: rank 0 scored
+    # the WHOLE set alone after the timed region (here both ranks share one GPU, so the "efficiency" is about one half)
+    assert d1["metric"].replace("over 1 GPUs", "over 2 GPUs") == d2["metric"]
+    n1 = d2["same_workload_n1"]
+    assert n1["calls"] == d1["config"]["calls_this_rank"] and n1["value"] > 0 and n1["kernel_ms"] > 0 and n1["loci"] == 300
+    assert d2["efficiency_measured"] == d2["value"] / (2 * n1["value"]) and 0.1 < d2["efficiency_measured"] < 1.5
+    assert d2["summary"]["efficiency_measured"] == d2["efficiency_measured"] and list(d2.keys())[0] == "summary"
+    assert all(r["loop_ms"] > 0 and r["host"]["cpu_quota_cores"] >= 1 for r in d2["config"]["per_rank"])
+    assert d1["efficiency_measured"] == 1.0 and d1["same_workload_n1"]["where"] == "this line"
 
 
 def test_c4_two_ranks_gather_equals_one_rank(tmp_path):

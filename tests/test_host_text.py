@@ -164,3 +164,20 @@ def test_encode_ascii_list_walk_equals_general_route():
     c, d = _lib.encode_ascii(["ACGT", "ACGéT", "AC\ud800GT"], 1), _lib.encode_ascii(("ACGT", "ACGéT", "AC\ud800GT"), 1)
     assert all(np.array_equal(x, y) for x, y in zip(c, d)) and c[2].tolist() == [0, 2, 2]
     assert _lib._list_texts((1, 2)) is None and len(_lib._list_texts([])[0]) == 0
+
+
+def test_text_reads_drop_n_and_refuse_other_symbols():
+    """Reads holding N are dropped as the reference drops them (vntr_finder.py:237), any other foreign symbol raises as its viterbi
+    does (hmm.pyx:72,79) -- for reads taken as spans of a text exactly as for lists of str."""
+    from advntr_amd import vntr_finder
+    text = b">a\nACGTACGTAC\n>b\nACGTNCGTAC\n>c\nacgtacgtac\n"
+    starts, ends = np.array([3, 17, 31]), np.array([13, 27, 41])
+    tr = vntr_finder.TextReads(text, starts, ends, np.array([0, 2, 3]))
+    prep = tr.prepare(0, 2)
+    assert prep["locus"].tolist() == [0, 1] and prep["index"].tolist() == [0, 0] and prep["lens"].tolist() == [10, 10]
+    assert np.array_equal(prep["bases"][:10], prep["bases"][10:])              # (case folded like the str route)
+    assert tr.read_lists() == [["ACGTACGTAC", "ACGTNCGTAC"], ["acgtacgtac"]] and len(tr) == 2
+    assert tr.prepare(1, 1) is None
+    bad = vntr_finder.TextReads(b">x\nACGT-CGT\n", np.array([3]), np.array([11]), np.array([0, 1]))
+    with pytest.raises(ValueError):
+        bad.prepare(0, 1)
