@@ -176,21 +176,56 @@ class TextReads(object):
 
     def __init__(self, text, span_start, span_end, locus_off):
         self.text = text
+        self._ready = None
+        self._failed = None
         self.span_start = np.ascontiguousarray(span_start, np.int64)
         self.span_end = np.ascontiguousarray(span_end, np.int64)
         self.locus_off = np.ascontiguousarray(locus_off, np.int64)
+        self.n_loci = len(self.locus_off) - 1
+
+    @classmethod
+    def pending(cls, text, n_loci):
+        """The reads of n_loci loci that are still being selected (the prefilter runs on another thread): genotype_loci_pipelined
+        can be started on this object at once -- its model building and upload stages need no reads -- and its read-encoding
+        stage waits until fill() (or fail()) has been called."""
+        import threading
+        self = cls(text, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(int(n_loci) + 1, np.int64))
+        self._ready = threading.Event()
+        return self
+
+    def fill(self, span_start, span_end, locus_off):
+        if len(locus_off) != self.n_loci + 1:
+            raise ValueError("TextReads.fill: %d loci were announced, %d are given" % (self.n_loci, len(locus_off) - 1))
+        self.span_start = np.ascontiguousarray(span_start, np.int64)
+        self.span_end = np.ascontiguousarray(span_end, np.int64)
+        self.locus_off = np.ascontiguousarray(locus_off, np.int64)
+        if self._ready is not None:
+            self._ready.set()
+
+    def fail(self, error):
+        self._failed = error
+        if self._ready is not None:
+            self._ready.set()
+
+    def _wait(self):
+        if self._ready is not None:
+            self._ready.wait()
+        if self._failed is not None:
+            raise self._failed
 
     def __len__(self):
-        return len(self.locus_off) - 1
+        return self.n_loci
 
     def read_lists(self):
         """The same reads as lists of str (the stage-by-stage route and the tests)."""
+        self._wait()
         t = self.text
         return [[t[a:b].decode("latin-1") for a, b in zip(self.span_start[lo:hi].tolist(), self.span_end[lo:hi].tolist())]
                 for lo, hi in zip(self.locus_off[:-1].tolist(), self.locus_off[1:].tolist())]
 
     def prepare(self, lo, hi, threads=0):
         """_prepare_reads for loci lo .. hi - 1."""
+        self._wait()
         a, b = int(self.locus_off[lo]), int(self.locus_off[hi])
         if a == b:
             return None

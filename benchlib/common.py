@@ -77,7 +77,7 @@ def measured_clock_ghz():
 def pmc_section(workload, n_calls, kernel):
     """Counters per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the bench);
     None when no committed profile describes this workload / kernel / size."""
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         pmc = load_json("profiles", name)
         if not pmc:
             continue

@@ -71,6 +71,21 @@ def test_illumina_pipeline_one_timeline_200_loci(tmp_path):
         assert a.maximum_likelihood == b.maximum_likelihood
     assert sum(g.copy_numbers is not None for g in piped) > 100 and P["total"] > 0
 
+    # --- the scoring pipeline started BEFORE the reads are known (its model building and upload need none; its encoding stage
+    # waits): what the bench's `illumina_pipeline` record does while the prefilter still runs on another thread
+    import threading
+    import time
+    late = vntr_finder.TextReads.pending(fasta, 200)
+    threading.Timer(0.3, lambda: late.fill(ss, se, locus_off)).start()
+    t0 = time.perf_counter()
+    overlapped = vntr_finder.genotype_loci_pipelined(desc, late, chunks=5)
+    assert time.perf_counter() - t0 >= 0.25
+    assert [g.copy_numbers for g in overlapped] == [g.copy_numbers for g in plain]
+    broken = vntr_finder.TextReads.pending(fasta, 200)
+    threading.Timer(0.1, lambda: broken.fail(RuntimeError("the prefilter failed"))).start()
+    with pytest.raises(RuntimeError, match="the prefilter failed"):
+        vntr_finder.genotype_loci_pipelined(desc, broken, chunks=5)
+
     # --- rows
     vntrs = []
     for k, l in enumerate(loci):

@@ -16,7 +16,7 @@ def test_host_cpp_under_asan_ubsan(tmp_path, arena):
     exe = str(tmp_path / "asan_host")
     src = os.path.join(ROOT, "tests", "native", "asan_host.cpp")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-fno-omit-frame-pointer", "-pthread"] + (["-DADVNTR_ARENA_PLAIN"] if arena == "plain" else []) +
+                           "-fno-omit-frame-pointer", "-pthread", "-ldl"] + (["-DADVNTR_ARENA_PLAIN"] if arena == "plain" else []) +
                           ["-o", exe, src])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
