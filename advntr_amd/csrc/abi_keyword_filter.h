@@ -27,7 +27,26 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
     }
     // group keyword strings: packed key -> owners (in keyword order).  A keyword of more than 29 bases is filed under the
     // key of its 29-base prefix (tag KWF_LONG_TAG) with a record of what follows the prefix.
-    std::map<uint64_t, std::vector<int32_t>> groups;          // short keys: owners; long-prefix keys: indices into long_recs_h
+    // (collected as (key, value) pairs and grouped by ONE stable sort -- ascending key, keyword order inside a key: the order a
+    // std::map of vectors iterates in, which the first version used and which cost 0.3 of the 0.44 s this call took for the
+    // 430 000 keywords of the 6 719-locus set)
+    struct KwEntry { uint64_t key; int32_t val; };
+    struct KwSpan {
+        const KwEntry *b, *e;
+        struct It {
+            const KwEntry *p;
+            int32_t operator*() const { return p->val; }
+            It &operator++() { ++p; return *this; }
+            bool operator!=(const It &o) const { return p != o.p; }
+        };
+        size_t size() const { return (size_t)(e - b); }
+        It begin() const { return It{b}; }
+        It end() const { return It{e}; }
+        int32_t operator[](size_t i) const { return b[i].val; }
+    };
+    struct KwGroup { uint64_t first; KwSpan second; };       // short keys: owners; long-prefix keys: indices into long_recs_h
+    std::vector<KwEntry> entries;
+    entries.reserve((size_t)n_keywords);
     std::vector<KwfLongRec> long_recs_h;
     std::vector<uint8_t> long_bases;
     std::vector<std::pair<int, int>> lengths;                 // (window length, tag)
@@ -57,10 +76,10 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
                 return nullptr;
             }
             long_bases.insert(long_bases.end(), kw_bases + kw_off[w] + win, kw_bases + kw_off[w + 1]);
-            groups[key].push_back((int32_t)long_recs_h.size());
+            entries.push_back(KwEntry{key, (int32_t)long_recs_h.size()});
             long_recs_h.push_back(rec);
         } else {
-            groups[key].push_back(kw_vntr[w]);
+            entries.push_back(KwEntry{key, kw_vntr[w]});
         }
         if (std::find(lengths.begin(), lengths.end(), std::make_pair(win, tag)) == lengths.end()) lengths.emplace_back(win, tag);
     }
@@ -69,6 +88,14 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
         return nullptr;
     }
     std::sort(lengths.begin(), lengths.end());
+    std::stable_sort(entries.begin(), entries.end(), [](const KwEntry &a, const KwEntry &b) { return a.key < b.key; });
+    std::vector<KwGroup> groups;
+    for (size_t i = 0; i < entries.size();) {
+        size_t j = i + 1;
+        while (j < entries.size() && entries[j].key == entries[i].key) ++j;
+        groups.push_back(KwGroup{entries[i].key, KwSpan{entries.data() + i, entries.data() + j}});
+        i = j;
+    }
     size_t slots = 1024;
     while (slots < groups.size() * 4) slots <<= 1;
     std::vector<uint64_t> keys(slots, KWF_EMPTY);
@@ -127,7 +154,7 @@ extern "C" advntr_kwfilter *advntr_kwfilter_create(const uint8_t *kw_bases, cons
                 while (short_table[t].y != KWF_SHORT_EMPTY) t = (t + 1) & (slots - 1);
                 short_table[t] = make_uint2(k32, kv.second.size() == 1 ? (KWF_SHORT_ONE | (uint32_t)kv.second[0]) : vals[s]);
             }
-            ids.insert(ids.end(), kv.second.begin(), kv.second.end());
+            for (int32_t owner : kv.second) ids.push_back(owner);
         }
     }
     // one keyword length of at most 16 bases: the two blocked Bloom filters of keyword_filter_short_kernel (LDS: 1 Mbit, two

@@ -17,21 +17,34 @@ def _cgroup_dir():
     return d if os.path.isdir(d) else "/sys/fs/cgroup"
 
 
-def cpu_stat():
-    """{nr_periods, nr_throttled, throttled_usec} of the control group (walking up to the first cpu.stat that has them), or {}."""
+def _quota_dir():
+    """The control group whose CPU quota binds this process: walking up from its own group, the first level whose cpu.max holds a
+    quota (counters of a level without one never move), else the mounted root."""
     d = _cgroup_dir()
     while True:
-        for name in ("cpu.stat", os.path.join("cpu", "cpu.stat")):            # v2, then the v1 controller directory
-            try:
-                kv = dict(line.split()[:2] for line in open(os.path.join(d, name)) if len(line.split()) >= 2)
-            except OSError:
-                continue
-            if "nr_throttled" in kv:
-                usec = int(kv["throttled_usec"]) if "throttled_usec" in kv else int(kv.get("throttled_time", 0)) // 1000
-                return {"nr_periods": int(kv.get("nr_periods", 0)), "nr_throttled": int(kv["nr_throttled"]), "throttled_usec": usec}
-        if d in ("/sys/fs/cgroup", "/"):
-            return {}
-        d = os.path.dirname(d)
+        try:
+            first = open(os.path.join(d, "cpu.max")).read().split()
+            if first and first[0] != "max":
+                return d
+        except OSError:
+            pass
+        if d.rstrip("/") in ("/sys/fs/cgroup", ""):
+            return "/sys/fs/cgroup"
+        d = os.path.dirname(d.rstrip("/"))
+
+
+def cpu_stat():
+    """{nr_periods, nr_throttled, throttled_usec} of the control group whose quota binds the process, or {}."""
+    for path in (os.path.join(_quota_dir(), "cpu.stat"), "/sys/fs/cgroup/cpu/cpu.stat"):         # v2, then the v1 controller
+        try:
+            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if "nr_throttled" in kv:
+            usec = int(kv["throttled_usec"]) if "throttled_usec" in kv else int(kv.get("throttled_time", 0)) // 1000
+            return {"nr_periods": int(kv.get("nr_periods", 0)), "nr_throttled": int(kv["nr_throttled"]), "throttled_usec": usec,
+                    "file": path}
+    return {}
 
 
 def cpu_quota_cores():
@@ -53,7 +66,7 @@ class HostRegion(object):
 
     def record(self):
         b, a = self.before, getattr(self, "after", None) or cpu_stat()
-        rec = {"cpu_quota_cores": cpu_quota_cores(), "host_threads_available": os.cpu_count()}
+        rec = {"cpu_quota_cores": cpu_quota_cores(), "host_threads_available": os.cpu_count(), "cpu_stat_file": (a or {}).get("file")}
         if a and b:
             rec.update({"nr_periods_delta": a["nr_periods"] - b["nr_periods"], "nr_throttled_delta": a["nr_throttled"] - b["nr_throttled"],
                         "throttled_usec_delta": a["throttled_usec"] - b["throttled_usec"]})
