@@ -182,6 +182,21 @@ def test_c3_two_ranks_gather_equals_one_rank(tmp_path):
     assert d1["efficiency_measured"] == 1.0 and d1["same_workload_n1"]["where"] == "this line"
 
 
+def test_emulated_rank_processes_run_the_n_rank_line():
+    """--emulate-ranks 2 --processes: two rank PROCESSES share this box's GPU through the host communicator and run the 2-rank line
+    itself -- what one GPU can show of the host side of an N-rank job: every rank sleeps in its device waits, takes its share of the
+    host threads, and reports the control group's throttle counters around its timed region."""
+    d = _bench(["--workload", "c3", "--loci", "120", "--steps", "3", "--warmup", "1", "--no-cpu", "--emulate-ranks", "2", "--processes"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["comm"] == "host" and d["emulated_ranks"]["ranks"] == 2
+    assert d["same_workload_n1"]["value"] is None and d["efficiency_measured"] is None          # (--no-n1: ranks share one GPU)
+    ranks = d["config"]["per_rank"]
+    assert len(ranks) == 2 and sum(r["calls"] for r in ranks) == sum(d["config"]["calls_per_rank"])
+    for r in ranks:
+        assert r["loop_ms"] > 0 and r["kernel_ms"] > 0 and r["host"]["nr_throttled_delta"] is not None
+        assert r["host"]["cpu_quota_cores"] >= 1
+    assert d["summary"]["throttled_periods_in_timed_region"] is not None
+
+
 def test_c4_two_ranks_gather_equals_one_rank(tmp_path):
     """bench.py --workload c4 --gpus 2 (BASELINE config 5 in its sharded form, 60 loci here): ONE PacBio locus set, whole
     loci to ranks by the planned work, each rank's share scored by the long-read kernel, every call's record gathered to rank
