@@ -40,7 +40,7 @@ struct ColClass {             // 12 doubles = 96 B: six 16-byte LDS words.  (Rou
                               // kept the 8-byte reads of the anti-diagonal kernel off each other's banks; the row-blocked sweeps read
                               // the whole record every step, and as six ds_read_b128 -- 4 LDS cycles each -- instead of five
                               // ds_read2_b64 + one ds_read_b64 -- 8 each -- they run 2.6 % (Viterbi, REF150) and 2.9 % (sum-product)
-                              // faster: DESIGN.md 4.1)
+                              // faster: HISTORY.md, round 4)
     double iI, iM, iD, mI;    // I_c <- I_c, M_c, b_c (prev row);   M_c <- I_{c-1}
     double mM, mX, mD, dI;    // M_c <- M_{c-1}, X (row 0 only, value incl. source), b_{c-1};  b_c <- I_{c-1}
     double dM, dD, erw;       // b_c <- M_{c-1}, b_{c-1};  feed weight

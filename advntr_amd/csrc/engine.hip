@@ -202,7 +202,7 @@ extern "C" int advntr_set_device(int device)
     // ADVNTR_BLOCKING_SYNC=1: this process's waits on the device sleep instead of spinning (hipDeviceScheduleBlockingSync).  A rank
     // of a multi-GPU job sets it (advntr_amd/comm.py): N ranks spinning in hipStreamSynchronize beside RCCL's proxy threads burn N
     // cores of a CPU quota that the host stages need, and a process that exhausts its quota is stopped as a whole -- the thread
-    // that launches kernels included -- for the rest of the accounting period.  Must precede the first use
+    // that launches kernels included -- for the rest of the accounting period (DESIGN.md sections 7 and 8).  Must precede the first use
     // of the device; a runtime that refuses the flag (device already active) is not an error.
     if (const char *e = getenv("ADVNTR_BLOCKING_SYNC"))
         if (atoi(e) > 0 && hipSetDevice(device) == hipSuccess && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess)

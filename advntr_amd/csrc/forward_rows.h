@@ -51,7 +51,7 @@ __device__ __forceinline__ double rows_tail_forward_linear(const ColProgram *__r
 // {b_c(0), entry term of M_c} from a table padded like the info table (one running address, no clamping).  The
 // multiply-adds are explicit fma()s: the build contracts nothing by itself (-ffp-contract=off, for the Viterbi kernels and
 // the host builder), and 11 fused operations per cell instead of 17 separate ones is a third of this kernel's arithmetic.
-// Back-to-back sweeps as in rows_sweep (viterbi_rows.h, DESIGN 4.1c): a lane group takes up to ROWS_DEPTH reads one behind the
+// Back-to-back sweeps as in rows_sweep (viterbi_rows.h, DESIGN.md section 5.1): a lane group takes up to ROWS_DEPTH reads one behind the
 // other along the step axis (`queue` = the lane's rows of the reads after the first, rows_pack_read; `depth` = reads per
 // group), so the W - 1 steps of filling and draining the lanes are paid once per sweep instead of once per read.  Nothing is
 // reset between reads: column 0 of a column program takes nothing from a previous column (probability 0 here), the fan-in

@@ -7,7 +7,7 @@
 //     on column c = s - l for all of them.  The previous row of a lane's 2nd..Rth row is the lane's own register, so a
 //     step needs ONE cross-lane shift (3 fp64 = 6 DPP moves) for R cells instead of one (6-12 moves) per cell, and the
 //     column's info word and 88-B transition class are read from LDS once per R cells (the anti-diagonal kernel is
-//     co-limited by VALU issue and LDS reads, DESIGN.md section 4.1);
+//     co-limited by VALU issue and LDS reads, DESIGN.md section 5.1);
 //   * the skew of the systolic sweep is one column per LANE, not per row: G reads share a wavefront, each in a group of
 //     W = 64/G lanes, and a 150-base read costs (NC + 29) steps of 5 cells on 32 lanes: 88 % of the lane-steps do useful
 //     work instead of 70 %.  G = 2: `wave_shr:1` crosses from the first group into the second; the first group's last

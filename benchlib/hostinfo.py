@@ -1,6 +1,6 @@
 """What the host gives this process: the CPU quota of its control group, and how often the scheduler throttled the group while a
 region ran (cpu.stat: a process that exhausts its quota is stopped as a whole -- the thread that launches kernels included -- for
-the rest of the 100-ms accounting period)."""
+the rest of the 100-ms accounting period, DESIGN.md sections 7 and 8)."""
 import os
 
 

@@ -8,7 +8,7 @@ from .common import CLOCK_GHZ, HBM_PEAK_GBPS, SIMDS, algorithmic_bytes, measured
 F64_PEAK_TFLOPS = SIMDS * CLOCK_GHZ * 1e9 * 16 * 2 / 1e12      # 16 fp64 lanes per cycle and SIMD (a wave64 fp64 instruction
                                                                # issues over 4 cycles, profiles/r02_f64_issue_ubench.txt), fused
                                                                # multiply-add = 2 flop: 78.6 TFLOP/s
-FORWARD_FMA_PER_CELL = 11      # csrc/forward_rows.h: the linear-domain cell, three states (DESIGN 4.3)
+FORWARD_FMA_PER_CELL = 11      # csrc/forward_rows.h: the linear-domain cell, three states (DESIGN.md section 5.4)
 
 
 def forward_record(_lib, locus, batch, bases, off, n_reads, n, args):

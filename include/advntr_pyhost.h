@@ -4,7 +4,7 @@
  * Not part of the drop-in boundary: advntr_hip.h is plain C (pointers and sizes) and bindable from any host language; the one
  * entry point below knows what a Python list of str is.  It exists because the reference's host language IS Python and a
  * million read strings cost more interpreter time to join and measure than their scoring takes on the device (DESIGN.md
- * section 7); a host in another language hands its reads to advntr_encode_texts / advntr_encode_ascii directly.  The library
+ * section 8); a host in another language hands its reads to advntr_encode_texts / advntr_encode_ascii directly.  The library
  * does not link against libpython: the handful of C-API functions are looked up at run time (dlsym), and the entry point fails
  * with -1 in a process that is not a Python interpreter.
  */

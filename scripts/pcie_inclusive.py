@@ -1,4 +1,4 @@
-"""PCIe-inclusive rate of the one-shot C-ABI call (host buffers in, host results out), for DESIGN.md section 7."""
+"""PCIe-inclusive rate of the one-shot C-ABI call (host buffers in, host results out), for DESIGN.md section 8."""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')

@@ -28,7 +28,7 @@ RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29651 timeout
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29652 timeout 300 python3 bench.py --workload c4 --no-cpu --steps 3 --warmup 1 > $out/c4_1gpu_rccl_bench.json 2> $out/c4_rccl.err
 timeout 600 python3 scripts/pacbio_full_size.py 8960 $out/c5_full_size.json > /dev/null 2> $out/c5_full_size.err
 # the host side of an 8-rank job on this one box: 8 rank processes share the GPU through the host communicator; per-rank throttle
-# counters of the control group around the timed region (DESIGN.md section 6)
+# counters of the control group around the timed region (DESIGN.md section 7)
 timeout 600 python3 bench.py --workload c3 --emulate-ranks 8 --processes --no-cpu --steps 10 --warmup 3 > $out/c3_emulate_8_processes.json 2> $out/c3_emulate_8.err
 (cat /proc/self/cgroup; echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; cat /sys/fs/cgroup/cpu.stat 2>/dev/null; nproc) > $out/host_cgroup.txt 2>&1
 # (measurement build of the SAME tree: scripts/build_variant.sh wgclocks -DADVNTR_WG_CLOCKS before the call)
