@@ -57,16 +57,23 @@ class HostRegion(object):
     """Throttle counters around a region: `with HostRegion() as h: ...; h.record()`."""
 
     def __enter__(self):
+        import time
         self.before = cpu_stat()
+        self.t0, self.c0 = time.perf_counter(), time.process_time()
         return self
 
     def __exit__(self, *exc):
+        import time
+        self.wall_s, self.cpu_s = time.perf_counter() - self.t0, time.process_time() - self.c0
         self.after = cpu_stat()
         return False
 
     def record(self):
         b, a = self.before, getattr(self, "after", None) or cpu_stat()
-        rec = {"cpu_quota_cores": cpu_quota_cores(), "host_threads_available": os.cpu_count(), "cpu_stat_file": (a or {}).get("file")}
+        rec = {"cpu_quota_cores": cpu_quota_cores(), "host_threads_available": os.cpu_count(), "cpu_stat_file": (a or {}).get("file"),
+               # CPU seconds this PROCESS (all its threads) burned in the region, and the region's wall time: a rank that sleeps in its
+               # device waits (ADVNTR_BLOCKING_SYNC) shows a small fraction of a core, one that spins a whole one
+               "process_cpu_s": getattr(self, "cpu_s", None), "wall_s": getattr(self, "wall_s", None)}
         if a and b:
             rec.update({"nr_periods_delta": a["nr_periods"] - b["nr_periods"], "nr_throttled_delta": a["nr_throttled"] - b["nr_throttled"],
                         "throttled_usec_delta": a["throttled_usec"] - b["throttled_usec"]})

@@ -133,8 +133,10 @@ def main(argv=None):
             # the line's own baseline: rank 0 will score the WHOLE set alone after the timed region (same_workload_n1), so its reads
             # are made here, before the GPU is touched like every other synthetic input
             t_whole = time.perf_counter()
-            whole_input = (workloads.make_c4(n_loci, seed=20240603, workers=host_workers) if workload == "c4" else
-                           workloads.make_c2_parallel(n_loci, seed=20240602, build=False, workers=host_workers))
+            # (its peers are done with their shares after an Nth of this: rank 0's pool takes half of the job's CPUs)
+            whole_workers = max(host_workers, min(32, quota_total // 2))
+            whole_input = (workloads.make_c4(n_loci, seed=20240603, workers=whole_workers) if workload == "c4" else
+                           workloads.make_c2_parallel(n_loci, seed=20240602, build=False, workers=whole_workers))
             whole_input = whole_input + (time.perf_counter() - t_whole,)
         if workload == "c4":
             loci, reads, which = workloads.make_c4(n_loci, seed=20240603, workers=host_workers, only=mine)

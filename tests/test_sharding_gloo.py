@@ -401,8 +401,10 @@ def test_ranks_of_one_host_are_frugal_with_its_cpus(monkeypatch):
     """N ranks on one host: each rank's waits on the device sleep (ADVNTR_BLOCKING_SYNC) and its bulk host calls use 1 / N of the
     CPUs the job may use (ADVNTR_HOST_THREADS); values the caller set win."""
     from advntr_amd import _lib, comm
-    monkeypatch.delenv("ADVNTR_BLOCKING_SYNC", raising=False)
-    monkeypatch.delenv("ADVNTR_HOST_THREADS", raising=False)
+    # (set before deleted: monkeypatch then restores whatever the environment held, also for the values the call under test sets)
+    for name in ("ADVNTR_BLOCKING_SYNC", "ADVNTR_HOST_THREADS"):
+        monkeypatch.setenv(name, os.environ.get(name, ""))
+        monkeypatch.delenv(name)
     total = int(_lib.load().advntr_host_threads())
     got = comm.frugal_host_for_ranks(4)
     assert got["ADVNTR_BLOCKING_SYNC"] == "1" and int(got["ADVNTR_HOST_THREADS"]) == max(1, total // 4)
