@@ -81,3 +81,9 @@ class HostRegion(object):
             rec.update({"nr_periods_delta": None, "nr_throttled_delta": None, "throttled_usec_delta": None,
                         "note": "no cpu.stat with throttle counters in this control group"})
         return rec
+
+    @staticmethod
+    def since(region):
+        """The record of a region that was entered by hand and ends now."""
+        region.__exit__(None, None, None)
+        return region.record()

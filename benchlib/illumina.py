@@ -7,6 +7,7 @@ import time
 import numpy as np
 
 from .common import HBM_PEAK_GBPS, ROOT, cpu_model_name, load_json, pmc_section
+from .hostinfo import HostRegion
 from .passes import two_in_flight_ms
 from .rehearsal import scale_rehearsal
 
@@ -49,11 +50,13 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     # ... and overlapped
     # (three passes: host threads, page cache and the PCIe path make a single pass vary by +-15 %; the fastest one is reported,
     # all three totals are listed)
-    P, totals = None, []
+    P, totals, throttled = None, [], []
     for _ in range(3):
         Pk = {}
-        piped = vntr_finder.genotype_loci_pipelined(desc, candidates, timings=Pk)
+        with HostRegion() as h:
+            piped = vntr_finder.genotype_loci_pipelined(desc, candidates, timings=Pk)
         totals.append(Pk["total"])
+        throttled.append(h.record())
         if P is None or Pk["total"] < P["total"]:
             P = Pk
     same = sum(a.copy_numbers == b.copy_numbers and a.recruited_reads_count == b.recruited_reads_count
@@ -62,6 +65,10 @@ def target_configuration_records(_lib, workloads, c2_input, flags, args):
     e2e = {"loci": n_loci, "candidate_reads": n_cand, "viterbi_calls": 2 * n_cand, "recruited_reads": recruited,
            "loci_with_genotype": sum(g.copy_numbers is not None for g in piped),
            "value": 2 * n_cand / P["total"], "unit": "calls/s", "total_s": P["total"], "total_s_of_each_pass": totals,
+           # why the passes differ: a pass whose host stages exhaust the control group's CPU quota in a 100-ms period has ALL its
+           # threads stopped for the rest of that period (the one that launches kernels included)
+           "host_of_each_pass": [{k: t.get(k) for k in ("nr_throttled_delta", "throttled_usec_delta", "process_cpu_s", "wall_s")}
+                                 for t in throttled],
            "stage_s_overlapped": {k: v for k, v in P.items() if k != "total"},
            "stages_one_after_the_other": dict(T),
            "genotypes_identical_to_stage_by_stage": same == n_loci,
@@ -193,6 +200,7 @@ def illumina_pipeline_record(_lib, inp, args):
     best, totals = None, []
     for _ in range(3):                              # (the first pass also sizes the process's buffer caches; all totals are listed)
         T, F, P = {}, {}, {}
+        h0 = HostRegion().__enter__()
         t0 = time.perf_counter()
         # Two strands of work from the first moment: the PREFILTER -- keyword tables to the device beside the line index of the
         # file (both in the library, the interpreter lock released), then scan and selection -- on a thread of its own, and the
@@ -237,6 +245,7 @@ def illumina_pipeline_record(_lib, inp, args):
                [genome_analyzer.genotype_row("vcf", v, v.id, g) for v, g in zip(vntrs, genotypes)]
         T["vcf_rows"] = time.perf_counter() - t2
         T["total"] = time.perf_counter() - t0
+        T["host"] = {k: v for k, v in HostRegion.since(h0).items() if k in ("nr_throttled_delta", "throttled_usec_delta", "process_cpu_s")}
         totals.append(T["total"])
         if best is None or T["total"] < best[0]["total"]:
             best = (T, F, P, genotypes, rows, text_reads, picked["ridx"])
