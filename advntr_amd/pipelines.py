@@ -10,8 +10,7 @@ import numpy as np
 
 from . import _lib
 from .pomegranate import device_models
-from .vntr_finder import (GenotypeResult, _prepare_reads, _spanning_align, _spanning_pieces_encoded, _spanning_prepare, find_repeat_counts_of_loci,
-                          pacbio_max_copies)
+from . import vntr_finder as _vf      # (looked up at call time: the per-call pieces stay replaceable where they are defined)
 
 
 class TextReads(object):
@@ -70,7 +69,7 @@ class TextReads(object):
                 for lo, hi in zip(self.locus_off[:-1].tolist(), self.locus_off[1:].tolist())]
 
     def prepare(self, lo, hi, threads=0):
-        """_prepare_reads for loci lo .. hi - 1."""
+        """vntr_finder._prepare_reads for loci lo .. hi - 1."""
         self._wait()
         a, b = int(self.locus_off[lo]), int(self.locus_off[hi])
         if a == b:
@@ -226,7 +225,7 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
     uploaded = _Stage("advntr-upload", upload, chunks, [built], abort, (T, "upload_models"))
     # (read_lists: a list of str per locus, or the loci's reads as spans of one text -- TextReads)
     prepare = (lambda k: (read_lists.prepare(cuts[k], cuts[k + 1], t_enc),)) if isinstance(read_lists, TextReads) else \
-              (lambda k: (_prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_enc),))
+              (lambda k: (_vf._prepare_reads(read_lists[cuts[k]:cuts[k + 1]], t_enc),))
     encoded = _Stage("advntr-encode", prepare, chunks, [], abort, (T, "encode_reads"))
     bound = _Stage("advntr-bind", lambda k, models, prep: bind(k, models, prep[0]), chunks, [uploaded, encoded], abort, (T, "bind_batch"))
     stages = [built, uploaded, encoded, bound]
@@ -254,7 +253,7 @@ def genotype_loci_pipelined(loci, read_lists, scaled_scores=None, accuracy_filte
                 else:
                     locus, summ = selected
                 bounds = np.searchsorted(locus, np.arange(n_piece + 1)).astype(np.int64)
-                results[k] = find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=max(1, t_enc))
+                results[k] = _vf.find_repeat_counts_of_loci(summ, bounds, accuracy_filter, is_haploid, threads=max(1, t_enc))
                 T["aggregate_genotype"] += time.perf_counter() - t
             except BaseException as e:              # noqa: BLE001 -- handed to the caller after the join
                 after["error"] = e
@@ -370,14 +369,14 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
 
     def encode_whole(k):
         lo, hi = cuts[k], cuts[k + 1]
-        return _spanning_prepare([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
+        return _vf._spanning_prepare([(l[0], l[1]) for l in loci[lo:hi]], read_lists[lo:hi], flanking_region_size)
 
     def extract(k, prep):
         # (locus, read) uses that span -> the trimmed pieces as encoded reads, grouped by locus (hits come ordered by use)
-        H = _spanning_align(prep)
+        H = _vf._spanning_align(prep)
         if H is None or len(H["use"]) == 0:
             return None
-        return _spanning_pieces_encoded(H, flanking_region_size, threads)
+        return _vf._spanning_pieces_encoded(H, flanking_region_size, threads)
 
     def build(k, ext):
         if ext is None:
@@ -389,7 +388,7 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
         desc = []
         for i, n_max in zip(have.tolist(), longest.tolist()):
             left, right, segments, pattern = loci[lo + i]
-            desc.append((left[-flanking_region_size:], right[:flanking_region_size], segments, pacbio_max_copies([n_max], len(pattern))))
+            desc.append((left[-flanking_region_size:], right[:flanking_region_size], segments, _vf.pacbio_max_copies([n_max], len(pattern))))
         models = hmm_utils.build_read_matcher_models(desc, threads=threads)
         which = np.searchsorted(have, piece_locus).astype(np.int32)
         return have, models, (codes, off), which
@@ -473,7 +472,7 @@ def genotype_pacbio_loci(loci, read_lists, accuracy_filter=False, is_haploid=Fal
     np.cumsum(count, out=off[1:])
     ru = np.concatenate(ru_parts) if ru_parts else np.zeros(0, np.int32)       # pieces and loci in ascending order: grouped by locus
     geno, prob = _lib.genotype_observed(ru, off, accuracy_filter, is_haploid, threads)
-    out = [GenotypeResult(None if a < 0 else (a, b), int(c), int(c), 0, p)
+    out = [_vf.GenotypeResult(None if a < 0 else (a, b), int(c), int(c), 0, p)
            for (a, b), p, c in zip(geno.tolist(), prob.tolist(), count.tolist())]
     T["genotype"] = time.perf_counter() - t
     T["total"] = time.perf_counter() - t0
