@@ -103,3 +103,29 @@ def test_emulate_ranks_as_processes_is_the_n_rank_line():
     from benchlib.cli import emulation_argv
     assert emulation_argv(["--workload", "c3", "--emulate-ranks", "8", "--processes", "--steps", "5", "--gpus=1"], 8) == \
         ["--workload", "c3", "--steps", "5", "--gpus", "8", "--no-n1"]
+
+
+def test_line_order_summary_first_bulky_records_last():
+    """The line a driver may keep only the head of: `summary` first (every headline number, < 1 KB), the contract's keys next, the
+    per-share lists of the rehearsals last; keys nobody listed keep their place in between."""
+    from benchlib.main import line_summary, order_line
+    out = {"metric": "m", "value": 11.9e6, "unit": "reads/s", "n_gpus": 1, "ms_per_step": 8.4, "config": {"workload": "C1"},
+           "scale_rehearsal": {"projected_efficiency": 0.98, "projected_efficiency_one_pass_in_flight": 0.95, "shares": [{}] * 8},
+           "roofline": {"frac": 0.32, "kernel_ms": 8.4}, "s300": {"value": 37.5e6, "frac": 0.237, "kernel_ms": 2.54},
+           "c2": {"value": 11.9e6, "kernel_ms": 90.4, "roofline": {"frac": 0.33}}, "something_new": 1,
+           "end_to_end": {"total_s": 0.21}, "illumina_pipeline": {"total_s": 0.54}, "cpu_baseline": {"value": 716.0},
+           "host": {"nr_throttled_delta": 0}}
+    line = order_line(out)
+    keys = list(line)
+    assert keys[0] == "summary" and keys[-1] == "scale_rehearsal" and keys.index("metric") == 1
+    assert keys.index("roofline") < keys.index("config") < keys.index("s300") < keys.index("something_new") < keys.index("scale_rehearsal")
+    s = line["summary"]
+    assert s["value"] == 11.9e6 and s["roofline_frac"] == 0.32 and s["s300"] == {"value": 37.5e6, "frac": 0.237, "kernel_ms": 2.54}
+    assert s["c2"]["frac"] == 0.33 and s["end_to_end_total_s"] == 0.21 and s["illumina_pipeline_total_s"] == 0.54
+    assert s["projected_efficiency_c3_8_ranks"] == 0.98 and s["cpu_baseline_value"] == 716.0
+    assert s["throttled_periods_in_timed_region"] == 0 and len(json.dumps(s)) < 1000
+    multi = line_summary({"value": 80e6, "n_gpus": 8, "same_workload_n1": {"value": 11.7e6}, "efficiency_measured": 0.85,
+                          "config": {"per_rank": [{"loop_ms": 11.0, "kernel_ms": 10.5, "gather_ms": 0.4, "host": {"nr_throttled_delta": 0}},
+                                                  {"loop_ms": 11.6, "kernel_ms": 10.9, "gather_ms": 0.7, "host": {"nr_throttled_delta": 2}}]}})
+    assert multi["efficiency_measured"] == 0.85 and multi["same_workload_n1_value"] == 11.7e6
+    assert multi["slowest_rank_loop_ms"] == 11.6 and multi["max_gather_ms"] == 0.7 and multi["throttled_periods_in_timed_region"] == 2
