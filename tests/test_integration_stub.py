@@ -135,3 +135,50 @@ def test_stub_scores_and_recruits_like_the_reference(name):
     assert touched > 0 and any(r.get("recruit") or r.get("recruit_noscore") for r in g["reads"])
     from advntr_amd import _lib
     _lib.load().advntr_hmm_destroy(ctypes.c_void_p(h))
+
+
+@pytest.mark.gpu
+def test_short_read_flow_stub_prints_the_stage_by_stage_rows(tmp_path, capsys):
+    """INTEGRATION.md section 9 -- the body a maintainer gives GenomeAnalyzer.find_repeat_counts_from_short_reads -- taken out of
+    the document and executed as written on a duck-typed analyzer (40 loci, their candidate reads planted in a FASTA file of 30 000
+    reads): the rows it prints are the rows of the stage-by-stage route (filter stdout text parsed as the reference parses it,
+    reads as str, models built up front, vntr_finder.genotype_loci)."""
+    from advntr_amd import filtering, genome_analyzer, hmm_utils, models, vntr_finder, workloads
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    at = text.index("```python\n# advntr/genome_analyzer.py: the short-read flow on the engine")
+    body = text[at + len("```python\n"):]
+    ns = {}
+    exec(compile(body[:body.index("\n```")], "INTEGRATION.md:short_read_flow", "exec"), ns)
+    loci, cands = [], []
+    for k in range(40):
+        params, calls, (nm, nu) = workloads._c2_locus((k, 20240602, 150, 80, 40))
+        loci.append(workloads.Locus(*params))
+        cands.append(calls[:nm + nu])
+    lines, fasta, rec_len, _ = workloads.make_illumina_pipeline_workload(loci, cands, 30000)
+    fa = tmp_path / "unmapped.fa"
+    fa.write_bytes(fasta)
+    vntrs = {}
+    for k, l in enumerate(loci):
+        v = models.ReferenceVNTR(k + 1, l.units[0], 10000 * k, "chr1", None, None, len(l.units))
+        v.init_from_xml(list(l.units), l.left, l.right)
+        vntrs[v.id] = v
+
+    class Analyzer(object):
+        reference_vntrs, target_vntr_ids, outfmt, is_haploid = vntrs, sorted(vntrs), "text", False
+    capsys.readouterr()
+    ns["find_repeat_counts_from_short_reads"](Analyzer(), str(fa), False)
+    got = capsys.readouterr().out
+    # stage by stage
+    kw_text = "".join("%d %s\n" % (v, " ".join(sorted(k))) for v, k in lines)
+    names, lists = {}, {}
+    for line in filtering.run(fasta, kw_text, 5).split("\n"):
+        parts = line.split()
+        if len(parts) >= 2 and parts[0].isdigit() and parts[1].isdigit():
+            lists[int(parts[0])] = parts[2:]
+        elif len(parts) >= 2:
+            names[parts[0]] = parts[1]
+    read_lists = [[names[nm] for nm in sorted(lists.get(vid, ()))] for vid in sorted(vntrs)]
+    desc = [(l.left, l.right, l.units, l.copies) for l in loci]
+    plain = vntr_finder.genotype_loci(hmm_utils.build_read_matcher_models(desc), read_lists)
+    want = "".join(genome_analyzer.genotype_row("text", vntrs[vid], vid, g) for vid, g in zip(sorted(vntrs), plain))
+    assert got == want and got.count("\n") == 80 and sum(g.copy_numbers is not None for g in plain) > 20
