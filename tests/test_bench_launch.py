@@ -129,3 +129,32 @@ def test_line_order_summary_first_bulky_records_last():
                                                   {"loop_ms": 11.6, "kernel_ms": 10.9, "gather_ms": 0.7, "host": {"nr_throttled_delta": 2}}]}})
     assert multi["efficiency_measured"] == 0.85 and multi["same_workload_n1_value"] == 11.7e6
     assert multi["slowest_rank_loop_ms"] == 11.6 and multi["max_gather_ms"] == 0.7 and multi["throttled_periods_in_timed_region"] == 2
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The N = 1 line committed under profiles/ (taken on an MI355X with the driver's flags) carries what the contract asks of it:
+    the standard keys, `roofline` (bound / achieved / peak / unit / frac / traffic, achieved < peak, frac = achieved / peak, the kernel
+    not slower than the step), `cpu_baseline` (value / unit / cores / kind / sample), a `summary` that agrees with the records it
+    condenses, and no model vocabulary in `config`."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r06_c1_bench_driver_flags.json")))
+    assert list(d)[0] == "summary"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"] and "REF150" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["achieved"] < r["peak"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] < r["algorithmic_gb_per_launch"]
+    assert abs(r["achieved"] - 215108 * 100000 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.01 and abs(d["value"] - 100000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "reads/s" and c["value"] > 0 and "8000 reads" in c["sample"]
+    a = d["cpu_baseline_all_cores"]
+    assert a["cores"] == 16 and a["host_threads_available"] == 256 and a["nr_throttled"] is not None     # the cgroup quota, not the host
+    s = d["summary"]
+    assert s["value"] == d["value"] and s["roofline_frac"] == r["frac"] and s["s300"]["kernel_ms"] == d["s300"]["kernel_ms"]
+    assert s["c2"]["frac"] == d["c2"]["roofline"]["frac"] and s["illumina_pipeline_total_s"] == d["illumina_pipeline"]["total_s"]
+    assert d["illumina_pipeline"]["genotypes_identical_to_stage_by_stage"] and d["illumina_pipeline"]["reference_filter"]["stdout_identical"]
+    assert d["illumina_pipeline"]["fasta_reads"] >= 10000000 and len(json.dumps(s)) < 1500
